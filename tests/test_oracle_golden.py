@@ -1,0 +1,259 @@
+"""Pins the CPU oracle (oracle/cdlrm_oracle.py) against golden vectors captured from the imported
+reference (tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cdlrm_oracle as O
+
+torch.set_num_threads(1)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_isprime_and_next_prime(golden):
+    g = golden("isprime")
+    tab = np.array([O.is_prime_ref(n) for n in range(1, 5000)], dtype=np.uint8)
+    assert np.array_equal(tab, g["isprime_1_4999"])
+    # the quirk count SURVEY.md quotes: disagreements with true primality below 5000
+    true_p = np.array([n > 1 and all(n % d for d in range(2, int(n ** 0.5) + 1)) for n in range(1, 5000)])
+    assert int((tab.astype(bool) != true_p).sum()) == 388
+    for c, p in zip(g["next_prime_in"], g["next_prime_out"]):
+        assert O.find_next_prime(int(c)) == int(p)
+    assert O.find_next_prime(2000) == 2003 and O.find_next_prime(150000) == 150001
+
+
+def test_appendix_a_known_answer(golden):
+    g = golden("appendix_a")
+    host = [t(g["host"])]
+    P = int(g["P"][0])
+    occ = O.new_occupancy_tables([P], 2)
+    weights = [torch.zeros(2 * P + 4, 2)]
+    for w in range(2):
+        raw = t(g[f"w{w}_raw"]).view(1, -1)
+        rows, uniqs, maps = O.process_batch_slice(raw, host)
+        assert torch.equal(uniqs[0], t(g[f"w{w}_uniq"]))
+        assert list(maps[0].shape) == list(g[f"w{w}_map_shape"])
+        torch.manual_seed(w)
+        ev, det = O.cache_embeddings(rows, uniqs, occ, weights, [P])
+        assert torch.equal(det[0]["q"], t(g[f"w{w}_q"]))
+        assert torch.equal(det[0]["way"], t(g[f"w{w}_way"]))
+        assert torch.equal(occ[0], t(g[f"w{w}_occ"]))
+        assert torch.equal(weights[0], t(g[f"w{w}_weight"]))
+        assert torch.equal(ev[0][0], t(g[f"w{w}_ev_idx"]))
+        assert torch.equal(ev[0][1], t(g[f"w{w}_ev_rows"]))
+    # the numbers SURVEY.md Appendix A prints
+    assert occ[0].tolist() == [[-1, -1], [16, 26], [-1, -1], [8, 3], [-1, 4]]
+    ly, cg = O.cache_forward(occ, weights, [P], t(g["fwd_lS_o"]), t(g["fwd_lS_i"]), host)
+    assert cg[0].tolist() == [10, 1, 11, 6] and cg[0].dtype == torch.int32
+    assert torch.equal(cg[0], t(g["fwd_idx"]))
+    assert torch.equal(ly[0], t(g["fwd_ly"]))
+    assert torch.equal(weights[0], t(g["fwd_weight"]))
+
+
+@pytest.mark.parametrize("name", ["cache_windows_small", "cache_windows_uniform"])
+def test_cache_windows(golden, name):
+    g = golden(name)
+    ln_emb = [int(x) for x in g["ln_emb"]]
+    T, ways, B = len(ln_emb), int(g["ways"]), int(g["B"])
+    P, cache_sizes, rows_n = O.cache_geometry(ln_emb, int(g["cache_size"]), ways, B)
+    assert P == int(g["P"]) and cache_sizes == [int(x) for x in g["cache_sizes"]]
+    host = [t(g[f"host0_{k}"]).clone() for k in range(T)]
+    weights = [t(g[f"weight0_{k}"]).clone() for k in range(T)]
+    assert [w.shape[0] for w in weights] == rows_n
+    occ = O.new_occupancy_tables(cache_sizes, ways)
+    saw_evict = saw_contest = saw_hit = False
+    for w in range(int(g["nwin"])):
+        win = t(g[f"w{w}_win"])
+        rows, uniqs, _ = O.process_batch_slice(win, host)
+        for k in range(T):
+            assert torch.equal(uniqs[k], t(g[f"w{w}_uniq_{k}"]))
+            assert torch.equal(rows[k], t(g[f"w{w}_rows_{k}"]))
+        pre_occ = [o.clone() for o in occ]
+        torch.manual_seed(int(g[f"w{w}_qseed"]))
+        ev, det = O.cache_embeddings(rows, uniqs, occ, weights, cache_sizes)
+        for k in range(T):
+            assert torch.equal(det[k]["q"], t(g[f"w{w}_q_{k}"])), (w, k)
+            assert torch.equal(det[k]["way"], t(g[f"w{w}_way_{k}"])), (w, k)
+            assert torch.equal(occ[k], t(g[f"w{w}_occ_{k}"])), (w, k)
+            assert torch.equal(weights[k], t(g[f"w{w}_weight_{k}"])), (w, k)
+            assert torch.equal(ev[k][0], t(g[f"w{w}_ev_idx_{k}"])), (w, k)
+            assert torch.equal(ev[k][1], t(g[f"w{w}_ev_rows_{k}"])), (w, k)
+            saw_evict |= ev[k][0].numel() > 0
+            s = det[k]["slots"]
+            saw_contest |= s.numel() != torch.unique(s).numel()
+            saw_hit |= bool((pre_occ[k][uniqs[k] % cache_sizes[k]] == uniqs[k].view(-1, 1)).any())
+        O.eviction_writeback(host, ev, False)
+        for k in range(T):
+            assert torch.equal(host[k], t(g[f"w{w}_host_{k}"])), (w, k)
+        lS_i = t(g[f"w{w}_fwd_lS_i"])
+        lS_o = torch.arange(B).repeat(T, 1)
+        ly, cg = O.cache_forward(occ, weights, cache_sizes, lS_o, lS_i, host)
+        for k in range(T):
+            assert torch.equal(cg[k], t(g[f"w{w}_fwd_idx_{k}"])), (w, k)
+            assert torch.equal(ly[k], t(g[f"w{w}_fwd_ly_{k}"])), (w, k)
+            assert torch.equal(weights[k], t(g[f"w{w}_fwd_weight_{k}"])), (w, k)
+    assert saw_evict and saw_contest and saw_hit
+
+
+@pytest.mark.parametrize("avg", [0, 1])
+def test_eviction_writeback(golden, avg):
+    g = golden("writeback_avg%d" % avg)
+    host = [t(g[f"before_{k}"]).clone() for k in range(2)]
+    ev = [(t(g[f"idx_{k}"]), t(g[f"emb_{k}"])) for k in range(2)]
+    O.eviction_writeback(host, ev, bool(avg))
+    for k in range(2):
+        assert torch.equal(host[k], t(g[f"after_{k}"]))
+
+
+def test_init(golden):
+    g = golden("init")
+    seed = int(g["seed"])
+    ln_emb, m_spa = [int(x) for x in g["ln_emb"]], int(g["m_spa"])
+    np.random.seed(seed)
+    host = O.init_host_tables(ln_emb, m_spa)
+    for k in range(len(ln_emb)):
+        assert torch.equal(host[k][:4], t(g[f"host_head_{k}"]))
+        assert float(host[k].double().sum()) == float(g[f"host_sum_{k}"])
+    tr = O.OracleTrainer(ln_emb, m_spa, g["ln_bot"], g["ln_top"], cache_size=100, num_ways=4, mini_batch_size=32,
+                         seed=seed)
+    for k in range(len(ln_emb)):
+        assert list(tr.weights[0][k].shape) == list(g[f"cache_shape_{k}"])
+        assert torch.equal(tr.weights[0][k][:4], t(g[f"cache_head_{k}"]))
+    for i in range(len(tr.bot[0][0])):
+        assert torch.equal(tr.bot[0][0][i], t(g[f"bot_w{i}"])) and torch.equal(tr.bot[0][1][i], t(g[f"bot_b{i}"]))
+    for i in range(len(tr.top[0][0])):
+        assert torch.equal(tr.top[0][0][i], t(g[f"top_w{i}"])) and torch.equal(tr.top[0][1][i], t(g[f"top_b{i}"]))
+
+
+@pytest.mark.parametrize("itself", [0, 1])
+def test_dense_fwd_bwd(golden, itself):
+    g = golden("dense_itself%d" % itself)
+    nb, nt = len(g["ln_bot"]) - 1, len(g["ln_top"]) - 1
+    bw = [t(g[f"bot_w{i}"]).requires_grad_(True) for i in range(nb)]
+    bb = [t(g[f"bot_b{i}"]).requires_grad_(True) for i in range(nb)]
+    tw = [t(g[f"top_w{i}"]).requires_grad_(True) for i in range(nt)]
+    tb = [t(g[f"top_b{i}"]).requires_grad_(True) for i in range(nt)]
+    ly = [t(g[f"ly_{k}"]).requires_grad_(True) for k in range(5)]
+    X, Tt = t(g["X"]), t(g["T"])
+    x = O.mlp_forward(X, bw, bb)
+    R = O.interact_features(x, ly, "dot", bool(itself))
+    assert torch.equal(R, t(g["R"]))
+    Z = O.dlrm_forward(X, ly, (bw, bb), (tw, tb), "dot", bool(itself))
+    E = O.loss_fn(Z, Tt, "bce")
+    E.backward()
+    assert torch.equal(Z, t(g["Z"])) and float(E) == float(g["loss"])
+    for k in range(5):
+        assert torch.equal(ly[k].grad, t(g[f"ly_grad_{k}"]))
+    for i in range(nb):
+        assert torch.equal(bw[i].grad, t(g[f"bot_gw{i}"])) and torch.equal(bb[i].grad, t(g[f"bot_gb{i}"]))
+    for i in range(nt):
+        assert torch.equal(tw[i].grad, t(g[f"top_gw{i}"])) and torch.equal(tb[i].grad, t(g[f"top_gb{i}"]))
+
+
+@pytest.mark.parametrize("name", ["embsgd_onehot", "embsgd_multihot"])
+def test_embbag_bwd_sgd(golden, name):
+    g = golden(name)
+    w = t(g["w0"]).clone()
+    slots, offs = t(g["slots"]), t(g["offsets"])
+    V = torch.nn.functional.embedding_bag(slots, w, offs, mode="sum")
+    assert torch.equal(V, t(g["V"]))
+    O.embbag_bwd_sgd(w, slots, offs, t(g["grad"]), float(g["lr"]))
+    np.testing.assert_allclose(w.numpy(), g["w1"], rtol=1e-6, atol=1e-7)
+    touched = torch.unique(slots)
+    mask = torch.ones(w.shape[0], dtype=torch.bool)
+    mask[touched] = False
+    assert torch.equal(w[mask], t(g["w1"])[mask])
+
+
+def make_batches(g):
+    """The batch stream tools/make_golden.py:ref_train draws (numpy RandomState(seed+1))."""
+    ln_emb = [int(x) for x in g["ln_emb"]]
+    B, seed, alpha = int(g["B"]), int(g["seed"]), float(g["alpha"])
+    rng = np.random.RandomState(seed + 1)
+    T = len(ln_emb)
+    out = []
+    for j in range(int(g["nbatch"])):
+        X = torch.from_numpy(rng.rand(B, int(g["ln_bot"][0])).astype(np.float32))
+        lS_i = torch.stack([torch.from_numpy(((rng.zipf(alpha, size=B).astype(np.int64)) * 2654435761 % ln_emb[k])
+                                             .astype(np.int64)) for k in range(T)])
+        lS_o = torch.arange(B, dtype=torch.int64).repeat(T, 1)
+        Tt = torch.from_numpy(np.round(rng.rand(B, 1)).astype(np.float32))
+        out.append((X, lS_o, lS_i, Tt))
+    return out
+
+
+def run_oracle_training(g, world):
+    ln_emb = [int(x) for x in g["ln_emb"]]
+    L = int(g["L"])
+    tr = O.OracleTrainer(ln_emb, int(g["m_spa"]), g["ln_bot"], g["ln_top"] if "ln_top" in g.files else
+                         np.array([int(g["m_spa"]) + (len(ln_emb) + 1) * len(ln_emb) // 2] + list(g["top"])),
+                         cache_size=int(g["cache_size"]), num_ways=int(g["ways"]), mini_batch_size=int(g["B"]),
+                         world_size=world, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), lookahead=L,
+                         table_agg_freq=int(g["agg_freq"]) if "agg_freq" in g.files else 10 ** 9,
+                         table_agg_op=str(g["agg_op"]) if "agg_op" in g.files else "mean", seed=int(g["seed"]))
+    batches = make_batches(g)
+    for j, (X, lS_o, lS_i, Tt) in enumerate(batches):
+        if j % L == 0:
+            win = torch.cat([b[2] for b in batches[j:j + L]], dim=1)
+            torch.manual_seed(5000 + j)
+            tr.refill(win)
+        tr.step(j, X, lS_o, lS_i, Tt)
+    return tr
+
+
+@pytest.mark.parametrize("name", ["train_small", "train_c1"])
+def test_loss_trajectory_w1(golden, name):
+    g = golden(name)
+    tr = run_oracle_training(g, 1)
+    losses = np.array([l[0] for l in tr.losses])
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for k in range(len(g["ln_emb"])):
+        assert torch.equal(tr.occ[k], t(g[f"occ_{k}"]))          # tag state bit-exact
+        np.testing.assert_allclose(float(tr.host[k].double().sum()), float(g[f"host_sum_{k}"]), rtol=1e-6)
+    for i in range(len(tr.top[0][0])):
+        np.testing.assert_allclose(tr.top[0][0][i].numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["train_w2_mean", "train_w2_freq1", "train_w2_max"])
+def test_loss_trajectory_w2(golden, name):
+    g = golden(name)
+    tr = run_oracle_training(g, 2)
+    for r in range(2):
+        losses = np.array([l[r] for l in tr.losses])
+        np.testing.assert_allclose(losses, g[f"r{r}_losses"], rtol=1e-5)
+        for i in range(len(tr.top[r][0])):
+            np.testing.assert_allclose(tr.top[r][0][i].numpy(), g[f"r{r}_top_w{i}"], rtol=1e-4, atol=1e-6)
+            # bias grads are NOT all-reduced (main_no_ddp.py:237-245): per-rank biases drift apart
+            np.testing.assert_allclose(tr.top[r][1][i].numpy(), g[f"r{r}_top_b{i}"], rtol=1e-4, atol=1e-6)
+    assert not np.array_equal(g["r0_top_b0"], g["r1_top_b0"])
+    for k in range(len(g["ln_emb"])):
+        assert torch.equal(tr.occ[k], t(g[f"occ_{k}"]))
+
+
+def test_qr_operator(golden):
+    g = golden("qr")
+    c = int(g["c"])
+    big = t(g["big_idx"])
+    assert torch.equal((big / c).long(), t(g["big_q"]))
+    assert int((big / c).long()[4]) == 10_000_000                  # exact floor is 9_999_999
+    for op in ("mult", "add", "concat"):
+        wq, wr = t(g[f"{op}_wq"]).requires_grad_(True), t(g[f"{op}_wr"]).requires_grad_(True)
+        V = O.qr_embedding_bag(t(g[f"{op}_idx"]), t(g[f"{op}_offs"]), wq, wr, c, op)
+        assert torch.equal(V, t(g[f"{op}_V"]))
+        V.backward(t(g[f"{op}_G"]))
+        np.testing.assert_allclose(wq.grad.numpy(), g[f"{op}_gq"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(wr.grad.numpy(), g[f"{op}_gr"], rtol=1e-6, atol=1e-7)
+
+
+def test_window_groups(golden):
+    g = golden("window_groups")
+    ci = 0
+    while f"case{ci}_cfg" in g.files:
+        nb, L, cw = [int(x) for x in g[f"case{ci}_cfg"]]
+        want = [[int(x) for x in row if x >= 0] for row in g[f"case{ci}_groups"]]
+        assert O.window_groups(nb, L, cw) == want, (nb, L, cw)
+        ci += 1
+    assert ci >= 5
