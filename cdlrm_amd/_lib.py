@@ -1,0 +1,114 @@
+"""ctypes binding of libcdlrm_hip.so (include/cdlrm_hip.h).
+
+The library is the product path: there is no CPU fallback.  `lib()` raises `CdlrmLibraryError` when the
+shared object has not been built (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C cdlrm_amd/csrc`), and every compute entry point of the package goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcdlrm_hip.so")
+
+c_i32, c_i64, c_u64, c_f32 = C.c_int32, C.c_int64, C.c_uint64, C.c_float
+vp = C.c_void_p
+
+
+class CdlrmLibraryError(RuntimeError):
+    pass
+
+
+class CdlrmError(RuntimeError):
+    def __init__(self, rc: int, msg: str):
+        super().__init__("libcdlrm_hip: rc=%d: %s" % (rc, msg))
+        self.rc = rc
+
+
+class Geometry(C.Structure):
+    _fields_ = [("num_tables", c_i32), ("dim", c_i32), ("num_ways", c_i32), ("aux_rows", c_i32),
+                ("table_rows", C.POINTER(c_i64)), ("cache_sets", C.POINTER(c_i64)),
+                ("device", c_i32), ("reserved", c_i32)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("bitmap", vp), ("uniq", vp), ("uniq_off", vp), ("cap_uniq", c_i64),
+                ("prot", vp), ("hit", vp), ("kept", vp), ("kept_off", vp), ("way", vp), ("flags", vp),
+                ("winner", vp), ("win_claim", vp), ("win_idx", vp), ("win_row", vp), ("win_tag", vp),
+                ("win_off", vp), ("cap_win", c_i64), ("stage", vp), ("ev_tag", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/cdlrm_hip.h declares
+PROTOTYPES = {
+    "cdlrm_abi_version": (C.c_int, []),
+    "cdlrm_last_error": (C.c_char_p, []),
+    "cdlrm_ctx_create": (C.c_int, [C.POINTER(Geometry), C.POINTER(vp)]),
+    "cdlrm_ctx_destroy": (C.c_int, [vp]),
+    "cdlrm_ctx_bind_cache": (C.c_int, [vp, vp, vp]),
+    "cdlrm_ctx_bind_host_tables": (C.c_int, [vp, C.POINTER(vp)]),
+    "cdlrm_host_register": (C.c_int, [vp, c_u64, C.POINTER(vp)]),
+    "cdlrm_host_unregister": (C.c_int, [vp]),
+    "cdlrm_ctx_check_sync": (C.c_int, [vp, vp]),
+    "cdlrm_embbag_probe": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, vp, vp]),
+    "cdlrm_embbag_fwd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, vp]),
+    "cdlrm_embbag_bwd_work_bytes": (c_u64, [c_i32, c_i64, c_i32]),
+    "cdlrm_embbag_bwd_sgd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),
+    "cdlrm_window_unique": (C.c_int, [vp, C.POINTER(Plan), vp, c_i64, c_i64, vp]),
+    "cdlrm_plan_probe": (C.c_int, [vp, C.POINTER(Plan), vp]),
+    "cdlrm_plan_offsets_sync": (C.c_int, [vp, C.POINTER(Plan), vp, vp, vp, vp]),
+    "cdlrm_plan_assign": (C.c_int, [vp, C.POINTER(Plan), vp, c_u64, vp]),
+    "cdlrm_plan_fetch": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(vp), C.c_int, vp]),
+    "cdlrm_plan_commit": (C.c_int, [vp, C.POINTER(Plan), vp]),
+    "cdlrm_plan_writeback": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(vp), C.c_int, vp]),
+    "cdlrm_gather_rows": (C.c_int, [vp, vp, c_i64, c_i32, vp, vp]),
+    "cdlrm_agg_compact": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, vp]),
+    "cdlrm_agg_gather": (C.c_int, [vp, vp, vp, c_f32, vp, c_i64, vp]),
+    "cdlrm_agg_scatter": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
+    "cdlrm_interact_fwd": (C.c_int, [vp, c_i64, c_i32, c_i32, c_i32, vp, c_i64, vp]),
+    "cdlrm_interact_bwd": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp, vp]),
+    "cdlrm_linear_fwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp]),
+    "cdlrm_linear_bwd_work_bytes": (c_u64, [c_i64, c_i32, c_i32]),
+    "cdlrm_linear_bwd": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i32, c_i32,
+                                   c_i32, vp, vp]),
+    "cdlrm_bce_fwd_bwd": (C.c_int, [vp, vp, c_i64, vp, vp, vp]),
+    "cdlrm_sgd_step": (C.c_int, [vp, vp, c_i64, c_f32, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises loudly when it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CdlrmLibraryError(
+                "%s not found: build it with `make -C cdlrm_amd/csrc` (or __graft_entry__.build()). "
+                "cdlrm_amd has no CPU fallback for the cached training path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.cdlrm_abi_version() != 1:
+            raise CdlrmLibraryError("ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise CdlrmError(rc, lib().cdlrm_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t) -> Optional[int]:
+    """data_ptr of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(stream=None) -> int:
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream

@@ -1,0 +1,137 @@
+// Internal helpers shared by the gfx950 kernels of libcdlrm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cdlrm_hip.h"
+
+#define CDLRM_WAVE 64
+#define BM_WPB 1024   // bitmap words per scan block; table bitmaps are padded to this
+
+// Per-table descriptor, resident in HBM, read through the scalar path (wave-uniform table id).
+struct TableDesc {
+    int64_t n_rows;     // rows of the host master table
+    int64_t P;          // sets
+    int64_t tag_base;   // element offset of this table's [P, ways] tags
+    int64_t row_base;   // first cache row of this table in the flat weight buffer
+    int64_t set_base;   // first set of this table in flat per-set arrays (prot)
+    int64_t bm_base;    // first 64-bit word of this table's window bitmap
+    int64_t bm_words;   // ceil(n_rows / 64)
+    int64_t rows;       // ways * P + aux
+};
+
+struct cdlrm_ctx {
+    int T = 0, D = 0, ways = 0, aux = 0, device = 0;
+    std::vector<TableDesc> h_tab;
+    TableDesc* d_tab = nullptr;
+    int64_t total_rows = 0, total_tags = 0, total_sets = 0, total_bm_words = 0;
+    int64_t* tags = nullptr;
+    float* weight = nullptr;
+    float** d_host_rows = nullptr;       // device array [T] of device-visible pointers
+    std::vector<float*> h_host_rows;
+    float** d_ptr_fetch = nullptr;       // device arrays [T] for per-call pointer tables
+    float** d_ptr_wb = nullptr;
+    int* d_err = nullptr;                // device error word
+    int64_t* d_scan = nullptr;           // block sums for the scans
+    int64_t scan_cap = 0;
+    int64_t* d_small = nullptr;          // small device scratch (counters), 256 int64
+    int64_t* h_pinned = nullptr;         // pinned host staging for _sync reads, 1024 int64
+};
+
+void cdlrm_set_error(const char* fmt, ...);
+
+#define CDLRM_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            cdlrm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define CDLRM_REQUIRE(cond, msg)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            cdlrm_set_error("%s: requirement failed: %s (%s)", __func__, #cond, msg);      \
+            return CDLRM_EINVAL;                                                           \
+        }                                                                                  \
+    } while (0)
+
+#define CDLRM_LAUNCH_CHECK() CDLRM_HIP_CHECK(hipGetLastError())
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int64_t cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// ---- device helpers -----------------------------------------------------------------------------
+
+__device__ __forceinline__ int64_t mod_sets(int64_t idx, int64_t P) {
+    // idx % P for non-negative idx; 32-bit fast path (Criteo ids and set counts fit 32 bits)
+    if (((uint64_t)idx | (uint64_t)P) >> 32) return idx % P;
+    return (int64_t)((uint32_t)idx % (uint32_t)P);
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of one int per thread over the whole block (blockDim.x multiple of 64, <= 1024).
+// Returns the exclusive prefix; *total receives the block sum.  smem: >= 17 ints.
+__device__ __forceinline__ int block_excl_scan(int v, int* smem, int* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) smem[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        int w = lane < nw ? smem[lane] : 0;
+        int wi = wave_incl_scan(w);
+        if (lane < nw) smem[lane] = wi - w;
+        if (lane == nw - 1) smem[16] = wi;
+    }
+    __syncthreads();
+    int res = smem[wid] + inc - v;
+    *total = smem[16];
+    __syncthreads();
+    return res;
+}
+
+// first k in [lo, hi) with a[k] >= key
+__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* a, int64_t lo, int64_t hi, uint64_t key) {
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// number of entries of off[0..m) that are <= pos, minus 1  (bag of lookup `pos`)
+__device__ __forceinline__ int64_t bag_of(const int64_t* off, int64_t m, int64_t pos) {
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= pos) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+// table owning flat position p given offsets off[0..T]
+__device__ __forceinline__ int table_of(const int64_t* off, int T, int64_t p) {
+    int lo = 0, hi = T;   // find largest k with off[k] <= p
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// scan utilities implemented in scan.hip
+int cdlrm_scan_reserve(cdlrm_ctx* ctx, int64_t nblocks);

@@ -1,0 +1,123 @@
+// Context, binding and error plumbing of libcdlrm_hip.so (no kernels of the hot path live here).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void cdlrm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int cdlrm_abi_version(void) { return CDLRM_ABI_VERSION; }
+extern "C" const char* cdlrm_last_error(void) { return g_err; }
+
+extern "C" int cdlrm_ctx_create(const cdlrm_geometry* geo, cdlrm_ctx** out) {
+    CDLRM_REQUIRE(geo && out, "null argument");
+    CDLRM_REQUIRE(geo->num_tables >= 1 && geo->num_tables <= 1024, "1..1024 tables");
+    CDLRM_REQUIRE(geo->dim >= 4 && geo->dim % 4 == 0, "dim must be a positive multiple of 4");
+    CDLRM_REQUIRE(geo->num_ways >= 1 && geo->num_ways <= 64, "1..64 ways");
+    CDLRM_REQUIRE(geo->aux_rows >= 0, "aux_rows >= 0");
+    CDLRM_HIP_CHECK(hipSetDevice(geo->device));
+    cdlrm_ctx* c = new cdlrm_ctx();
+    c->T = geo->num_tables; c->D = geo->dim; c->ways = geo->num_ways; c->aux = geo->aux_rows;
+    c->device = geo->device;
+    int64_t tag = 0, row = 0, set = 0, bm = 0;
+    for (int k = 0; k < c->T; ++k) {
+        TableDesc d;
+        d.n_rows = geo->table_rows[k];
+        d.P = geo->cache_sets[k];
+        if (d.n_rows < 1 || d.P < 1 || d.P > d.n_rows ||
+            d.P * (int64_t)c->ways + c->aux >= ((int64_t)1 << 31)) {
+            delete c;
+            cdlrm_set_error("cdlrm_ctx_create: table %d has unsupported geometry (n=%lld P=%lld)", k,
+                            (long long)geo->table_rows[k], (long long)geo->cache_sets[k]);
+            return CDLRM_EINVAL;
+        }
+        d.tag_base = tag; d.row_base = row; d.set_base = set; d.bm_base = bm;
+        d.bm_words = ((d.n_rows + 63) / 64 + BM_WPB - 1) / BM_WPB * BM_WPB;
+        d.rows = d.P * c->ways + c->aux;
+        tag += d.P * c->ways; row += d.rows; set += d.P; bm += d.bm_words;
+        c->h_tab.push_back(d);
+    }
+    c->total_tags = tag; c->total_rows = row; c->total_sets = set; c->total_bm_words = bm;
+    c->h_host_rows.assign(c->T, nullptr);
+    CDLRM_HIP_CHECK(hipMalloc(&c->d_tab, sizeof(TableDesc) * c->T));
+    CDLRM_HIP_CHECK(hipMemcpy(c->d_tab, c->h_tab.data(), sizeof(TableDesc) * c->T, hipMemcpyHostToDevice));
+    CDLRM_HIP_CHECK(hipMalloc(&c->d_host_rows, sizeof(float*) * c->T));
+    CDLRM_HIP_CHECK(hipMemset(c->d_host_rows, 0, sizeof(float*) * c->T));
+    CDLRM_HIP_CHECK(hipMalloc(&c->d_ptr_fetch, sizeof(float*) * c->T));
+    CDLRM_HIP_CHECK(hipMalloc(&c->d_ptr_wb, sizeof(float*) * c->T));
+    CDLRM_HIP_CHECK(hipMalloc(&c->d_err, sizeof(int)));
+    CDLRM_HIP_CHECK(hipMemset(c->d_err, 0, sizeof(int)));
+    CDLRM_HIP_CHECK(hipMalloc(&c->d_small, sizeof(int64_t) * 256));
+    CDLRM_HIP_CHECK(hipMemset(c->d_small, 0, sizeof(int64_t) * 256));
+    CDLRM_HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, sizeof(int64_t) * 4096, hipHostMallocDefault));
+    int rc = cdlrm_scan_reserve(c, 1 << 16);
+    if (rc) { delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" int cdlrm_ctx_destroy(cdlrm_ctx* c) {
+    if (!c) return 0;
+    (void)hipFree(c->d_tab);
+    (void)hipFree(c->d_host_rows);
+    (void)hipFree(c->d_ptr_fetch);
+    (void)hipFree(c->d_ptr_wb);
+    (void)hipFree(c->d_err);
+    (void)hipFree(c->d_small);
+    (void)hipFree(c->d_scan);
+    (void)hipHostFree(c->h_pinned);
+    delete c;
+    return 0;
+}
+
+extern "C" int cdlrm_ctx_bind_cache(cdlrm_ctx* c, int64_t* tags, float* weight) {
+    CDLRM_REQUIRE(c && tags && weight, "null argument");
+    CDLRM_REQUIRE(((uintptr_t)weight & 15) == 0 && ((uintptr_t)tags & 15) == 0, "16-byte aligned buffers");
+    c->tags = tags;
+    c->weight = weight;
+    return 0;
+}
+
+extern "C" int cdlrm_ctx_bind_host_tables(cdlrm_ctx* c, float* const* host_rows) {
+    CDLRM_REQUIRE(c && host_rows, "null argument");
+    for (int k = 0; k < c->T; ++k) {
+        CDLRM_REQUIRE(host_rows[k] != nullptr && ((uintptr_t)host_rows[k] & 15) == 0, "16-byte aligned host tables");
+        c->h_host_rows[k] = host_rows[k];
+    }
+    CDLRM_HIP_CHECK(hipMemcpy(c->d_host_rows, c->h_host_rows.data(), sizeof(float*) * c->T, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int cdlrm_host_register(void* host_ptr, uint64_t bytes, void** device_alias) {
+    CDLRM_REQUIRE(host_ptr && bytes && device_alias, "null argument");
+    CDLRM_HIP_CHECK(hipHostRegister(host_ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    CDLRM_HIP_CHECK(hipHostGetDevicePointer(device_alias, host_ptr, 0));
+    return 0;
+}
+
+extern "C" int cdlrm_host_unregister(void* host_ptr) {
+    CDLRM_REQUIRE(host_ptr, "null argument");
+    CDLRM_HIP_CHECK(hipHostUnregister(host_ptr));
+    return 0;
+}
+
+extern "C" int cdlrm_ctx_check_sync(cdlrm_ctx* c, void* stream) {
+    CDLRM_REQUIRE(c, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    int* h = (int*)(c->h_pinned + 4000);
+    CDLRM_HIP_CHECK(hipMemcpyAsync(h, c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    CDLRM_HIP_CHECK(hipMemsetAsync(c->d_err, 0, sizeof(int), s));
+    CDLRM_HIP_CHECK(hipStreamSynchronize(s));
+    if (*h != 0) {
+        cdlrm_set_error("device error word = %d (1: index outside its table, 2: more misses than aux rows, "
+                        "4: plan capacity exceeded)", *h);
+        return CDLRM_ERANGE;
+    }
+    return 0;
+}

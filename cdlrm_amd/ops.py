@@ -1,0 +1,287 @@
+"""Thin functional layer over the C ABI (include/cdlrm_hip.h) on torch tensors.
+
+Torch is plumbing here (device memory, streams); every computation is a libcdlrm_hip.so call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import Geometry, Plan, check, ptr, stream_ptr
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError("cdlrm_amd: %s must live on the MI355X (got %s); there is no CPU path" % (name, t.device))
+
+
+class CacheCtx:
+    """Opaque library context of one cache group (geometry + bound cache state)."""
+
+    def __init__(self, table_rows: Sequence[int], cache_sets: Sequence[int], dim: int, num_ways: int,
+                 aux_rows: int, device: torch.device):
+        self.T = len(table_rows)
+        self.D, self.ways, self.aux = int(dim), int(num_ways), int(aux_rows)
+        self.table_rows = [int(x) for x in table_rows]
+        self.cache_sets = [int(x) for x in cache_sets]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("cdlrm_amd: a HIP device is required (no CPU fallback)")
+        self.rows = [self.ways * p + self.aux for p in self.cache_sets]
+        self.row_base, self.tag_base, self.set_base = [0], [0], [0]
+        for k in range(self.T):
+            self.row_base.append(self.row_base[-1] + self.rows[k])
+            self.tag_base.append(self.tag_base[-1] + self.cache_sets[k] * self.ways)
+            self.set_base.append(self.set_base[-1] + self.cache_sets[k])
+        self.total_rows, self.total_tags, self.total_sets = self.row_base[-1], self.tag_base[-1], self.set_base[-1]
+        self.bm_words = [((n + 63) // 64 + 1023) // 1024 * 1024 for n in self.table_rows]
+        self.total_bm_words = sum(self.bm_words)
+        tr = (C.c_int64 * self.T)(*self.table_rows)
+        cs = (C.c_int64 * self.T)(*self.cache_sets)
+        geo = Geometry(self.T, self.D, self.ways, self.aux, tr, cs, self.device.index or 0, 0)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().cdlrm_ctx_create(C.byref(geo), C.byref(h)))
+        self.handle = h
+        self._host_ptrs = None
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().cdlrm_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def bind_cache(self, tags: torch.Tensor, weight: torch.Tensor):
+        _require_cuda(tags, "tags"); _require_cuda(weight, "weight")
+        assert tags.dtype == torch.int64 and tags.numel() == self.total_tags and tags.is_contiguous()
+        assert weight.dtype == torch.float32 and tuple(weight.shape) == (self.total_rows, self.D) and weight.is_contiguous()
+        check(_lib.lib().cdlrm_ctx_bind_cache(self.handle, tags.data_ptr(), weight.data_ptr()))
+        self._keep = (tags, weight)
+
+    def bind_host_tables(self, ptrs: Sequence[int]):
+        ptrs = [int(p) for p in ptrs]
+        if ptrs == self._host_ptrs:
+            return
+        arr = (C.c_void_p * self.T)(*ptrs)
+        check(_lib.lib().cdlrm_ctx_bind_host_tables(self.handle, arr))
+        self._host_ptrs = ptrs
+
+    def check(self, stream=None):
+        """Raise if a kernel flagged out-of-range input (synchronises the stream)."""
+        check(_lib.lib().cdlrm_ctx_check_sync(self.handle, stream_ptr(stream)))
+
+
+# ---- per-iteration path --------------------------------------------------------------------------
+
+def embbag_probe(ctx: CacheCtx, idx: torch.Tensor, stream=None):
+    """idx int64 [T, n] on device -> (slots int32 [T, n], miss_pos int32 [T, n], miss_count int32 [T])."""
+    _require_cuda(idx, "idx")
+    assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.shape[0] == ctx.T and idx.stride(1) == 1
+    n = idx.shape[1]
+    slots = torch.empty((ctx.T, n), dtype=torch.int32, device=idx.device)
+    miss_pos = torch.empty((ctx.T, n), dtype=torch.int32, device=idx.device)
+    miss_count = torch.empty((ctx.T,), dtype=torch.int32, device=idx.device)
+    check(_lib.lib().cdlrm_embbag_probe(ctx.handle, idx.data_ptr(), n, idx.stride(0) if n else 0, slots.data_ptr(),
+                                        miss_pos.data_ptr(), miss_count.data_ptr(), stream_ptr(stream)))
+    return slots, miss_pos, miss_count
+
+
+def embbag_fwd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.Tensor], out: torch.Tensor,
+               ld_bag: int, ld_table: int, n_bags: Optional[int] = None, stream=None):
+    n = slots.shape[1]
+    nb = n if offsets is None else offsets.shape[1]
+    if n_bags is not None:
+        nb = n_bags
+    check(_lib.lib().cdlrm_embbag_fwd(ctx.handle, slots.data_ptr(), ptr(offsets), n, nb,
+                                      0 if offsets is None else offsets.stride(0), out.data_ptr(), ld_bag, ld_table,
+                                      stream_ptr(stream)))
+
+
+def embbag_bwd_work(ctx: CacheCtx, n: int, device) -> torch.Tensor:
+    nbytes = int(_lib.lib().cdlrm_embbag_bwd_work_bytes(ctx.T, n, ctx.D))
+    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+
+
+def embbag_bwd_sgd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.Tensor], grad: torch.Tensor,
+                   ld_bag: int, ld_table: int, lr: float, work: torch.Tensor, touched: Optional[torch.Tensor] = None,
+                   stream=None):
+    n = slots.shape[1]
+    nb = n if offsets is None else offsets.shape[1]
+    check(_lib.lib().cdlrm_embbag_bwd_sgd(ctx.handle, slots.data_ptr(), ptr(offsets), n, nb,
+                                          0 if offsets is None else offsets.stride(0), grad.data_ptr(), ld_bag,
+                                          ld_table, float(lr), work.data_ptr(), ptr(touched), stream_ptr(stream)))
+
+
+# ---- look-ahead window plan -------------------------------------------------------------------------
+
+class WindowPlan:
+    """Caller-owned buffers of one insert plan (cdlrm_plan in the header) + the call sequence."""
+
+    def __init__(self, ctx: CacheCtx, max_window: int, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None):
+        dev = ctx.device
+        self.ctx = ctx
+        per_table = [min(int(max_window), n) for n in ctx.table_rows]
+        self.cap_uniq = int(cap_uniq) if cap_uniq is not None else max(16, sum(per_table))
+        slots_cap = [min(u, ctx.ways * p) for u, p in zip(per_table, ctx.cache_sets)]
+        self.cap_win = int(cap_win) if cap_win is not None else max(16, sum(slots_cap))
+        i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+        z = lambda n, dt: torch.zeros(max(int(n), 1), dtype=dt, device=dev)
+        e = lambda n, dt: torch.empty(max(int(n), 1), dtype=dt, device=dev)
+        T = ctx.T
+        self.bitmap = z(ctx.total_bm_words, i64)
+        self.uniq = e(self.cap_uniq, i64)
+        self.uniq_off = z(T + 1, i64)
+        self.prot = z(ctx.total_sets, i64)
+        self.hit = e((self.cap_uniq + 15) // 16 * 16, u8)
+        self.kept = e(self.cap_uniq, i32)
+        self.kept_off = z(T + 1, i64)
+        self.way = e((self.cap_uniq + 15) // 16 * 16, u8)
+        self.flags = z((self.cap_uniq + 15) // 16 * 16, u8)
+        self.winner = torch.full((ctx.total_rows,), -1, dtype=i32, device=dev)
+        self.win_claim = e(self.cap_win, i32)
+        self.win_idx = e(self.cap_win, i64)
+        self.win_row = e(self.cap_win, i64)
+        self.win_tag = e(self.cap_win, i64)
+        self.win_off = z(T + 1, i64)
+        self.stage = torch.empty((self.cap_win, ctx.D), dtype=torch.float32, device=dev)
+        self.ev_tag = torch.full((self.cap_win,), -1, dtype=i64, device=dev)
+        self.c = Plan(self.bitmap.data_ptr(), self.uniq.data_ptr(), self.uniq_off.data_ptr(), self.cap_uniq,
+                      self.prot.data_ptr(), self.hit.data_ptr(), self.kept.data_ptr(), self.kept_off.data_ptr(),
+                      self.way.data_ptr(), self.flags.data_ptr(), self.winner.data_ptr(), self.win_claim.data_ptr(),
+                      self.win_idx.data_ptr(), self.win_row.data_ptr(), self.win_tag.data_ptr(),
+                      self.win_off.data_ptr(), self.cap_win, self.stage.data_ptr(), self.ev_tag.data_ptr())
+
+    # K1
+    def unique(self, idx: torch.Tensor, stream=None):
+        _require_cuda(idx, "window indices")
+        assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.shape[0] == self.ctx.T and idx.stride(1) == 1
+        check(_lib.lib().cdlrm_window_unique(self.ctx.handle, C.byref(self.c), idx.data_ptr(), idx.shape[1],
+                                             idx.stride(0), stream_ptr(stream)))
+
+    def set_unique(self, uniqs: Sequence[torch.Tensor]):
+        """CacheEmbeddings drop-in entry: the caller already has the sorted unique lists."""
+        off = [0]
+        for u in uniqs:
+            off.append(off[-1] + int(u.numel()))
+        if off[-1] > self.cap_uniq:
+            raise RuntimeError("plan capacity %d < %d unique indices" % (self.cap_uniq, off[-1]))
+        if off[-1]:
+            self.uniq[:off[-1]] = torch.cat([u.reshape(-1).to(self.uniq.device, torch.int64) for u in uniqs])
+        self.uniq_off.copy_(torch.tensor(off, dtype=torch.int64))
+
+    # K2
+    def probe(self, stream=None):
+        check(_lib.lib().cdlrm_plan_probe(self.ctx.handle, C.byref(self.c), stream_ptr(stream)))
+
+    def offsets(self, stream=None):
+        """(uniq_off, kept_off, win_off) as python lists; synchronises the stream."""
+        T = self.ctx.T
+        bufs = [(C.c_int64 * (T + 1))() for _ in range(3)]
+        check(_lib.lib().cdlrm_plan_offsets_sync(self.ctx.handle, C.byref(self.c), bufs[0], bufs[1], bufs[2],
+                                                 stream_ptr(stream)))
+        return [list(b) for b in bufs]
+
+    # K3
+    def assign(self, q: Optional[torch.Tensor] = None, seed: int = 0, stream=None):
+        if q is not None:
+            _require_cuda(q, "q")
+            assert q.dtype == torch.float32 and q.is_contiguous()
+        check(_lib.lib().cdlrm_plan_assign(self.ctx.handle, C.byref(self.c), ptr(q), int(seed) & (2 ** 64 - 1),
+                                           stream_ptr(stream)))
+
+    # K5a
+    def fetch(self, src_ptrs: Sequence[int], by_position: bool, stream=None):
+        arr = (C.c_void_p * self.ctx.T)(*[int(p) for p in src_ptrs])
+        check(_lib.lib().cdlrm_plan_fetch(self.ctx.handle, C.byref(self.c), arr, 1 if by_position else 0,
+                                          stream_ptr(stream)))
+
+    # K4 + K5b
+    def commit(self, stream=None):
+        check(_lib.lib().cdlrm_plan_commit(self.ctx.handle, C.byref(self.c), stream_ptr(stream)))
+
+    # K14
+    def writeback(self, dst_ptrs: Sequence[int], average: bool, stream=None):
+        arr = (C.c_void_p * self.ctx.T)(*[int(p) for p in dst_ptrs])
+        check(_lib.lib().cdlrm_plan_writeback(self.ctx.handle, C.byref(self.c), arr, 1 if average else 0,
+                                              stream_ptr(stream)))
+
+
+def gather_rows(src_ptr: int, index: torch.Tensor, dim: int, stream=None) -> torch.Tensor:
+    _require_cuda(index, "index")
+    out = torch.empty((index.numel(), dim), dtype=torch.float32, device=index.device)
+    check(_lib.lib().cdlrm_gather_rows(int(src_ptr), index.data_ptr(), index.numel(), dim, out.data_ptr(),
+                                       stream_ptr(stream)))
+    return out
+
+
+# ---- table aggregation -------------------------------------------------------------------------------
+
+def agg_compact(ctx: CacheCtx, touched: torch.Tensor, rows_out: torch.Tensor, count_out: torch.Tensor, stream=None):
+    check(_lib.lib().cdlrm_agg_compact(ctx.handle, touched.data_ptr(), touched.numel(), rows_out.data_ptr(),
+                                       rows_out.numel(), count_out.data_ptr(), stream_ptr(stream)))
+
+
+def agg_gather(ctx: CacheCtx, rows: torch.Tensor, count: torch.Tensor, scale: float, buf: torch.Tensor, cap: int,
+               stream=None):
+    check(_lib.lib().cdlrm_agg_gather(ctx.handle, rows.data_ptr(), count.data_ptr(), float(scale), buf.data_ptr(),
+                                      int(cap), stream_ptr(stream)))
+
+
+def agg_scatter(ctx: CacheCtx, rows: torch.Tensor, count: torch.Tensor, buf: torch.Tensor, cap: int, stream=None):
+    check(_lib.lib().cdlrm_agg_scatter(ctx.handle, rows.data_ptr(), count.data_ptr(), buf.data_ptr(), int(cap),
+                                       stream_ptr(stream)))
+
+
+# ---- dense model -------------------------------------------------------------------------------------
+
+def interact_fwd(feat: torch.Tensor, itself: bool, R: torch.Tensor, stream=None):
+    B, F, D = feat.shape
+    check(_lib.lib().cdlrm_interact_fwd(feat.data_ptr(), B, F, D, int(bool(itself)), R.data_ptr(), R.stride(0),
+                                        stream_ptr(stream)))
+
+
+def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None):
+    B, F, D = feat.shape
+    check(_lib.lib().cdlrm_interact_bwd(feat.data_ptr(), dR.data_ptr(), dR.stride(0), B, F, D, int(bool(itself)),
+                                        dfeat.data_ptr(), stream_ptr(stream)))
+
+
+ACT = {"none": 0, "relu": 1, "sigmoid": 2}
+
+
+def linear_fwd(X: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], Y: torch.Tensor, act: int, stream=None):
+    M, K = X.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and W.is_contiguous() and X.stride(1) == 1 and Y.stride(1) == 1
+    check(_lib.lib().cdlrm_linear_fwd(X.data_ptr(), X.stride(0), W.data_ptr(), ptr(b), Y.data_ptr(), Y.stride(0), M, N,
+                                      K, act, stream_ptr(stream)))
+
+
+def linear_bwd_work(M: int, N: int, K: int, device) -> torch.Tensor:
+    nbytes = int(_lib.lib().cdlrm_linear_bwd_work_bytes(M, N, K))
+    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+
+
+def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=None):
+    M, K = X.shape
+    N = W.shape[0]
+    check(_lib.lib().cdlrm_linear_bwd(X.data_ptr(), X.stride(0), W.data_ptr(), ptr(Y), 0 if Y is None else Y.stride(0),
+                                      dY.data_ptr(), dY.stride(0), ptr(dX), 0 if dX is None else dX.stride(0),
+                                      dW.data_ptr(), ptr(db), M, N, K, act, work.data_ptr(), stream_ptr(stream)))
+
+
+def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, dZ: Optional[torch.Tensor], stream=None):
+    assert loss_buf.numel() >= 65
+    check(_lib.lib().cdlrm_bce_fwd_bwd(Z.data_ptr(), target.data_ptr(), Z.numel(), loss_buf.data_ptr(), ptr(dZ),
+                                       stream_ptr(stream)))
+
+
+def sgd_step(param: torch.Tensor, grad: torch.Tensor, lr: float, stream=None):
+    assert param.is_contiguous() and grad.is_contiguous() and param.numel() == grad.numel()
+    check(_lib.lib().cdlrm_sgd_step(param.data_ptr(), grad.data_ptr(), param.numel(), float(lr), stream_ptr(stream)))

@@ -1,0 +1,241 @@
+/*
+ * libcdlrm_hip.so -- C ABI of the MI355X (gfx950) look-ahead embedding-cache training path.
+ *
+ * The reference (lkp411/cDLRM) is pure Python over stock ATen ops: it has NO FFI / plugin interface
+ * for this path.  This header is therefore the build's own thin lower boundary; every
+ * entry point names the reference call site (file:line in the reference tree) whose work it takes
+ * over.  The upper boundary (same names / argument meaning as the reference) is the Python package
+ * cdlrm_amd/{model_no_ddp,cache_manager,main_no_ddp}.py, which binds this library through ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t, or a negative CDLRM_E* code;
+ *     nothing throws across the ABI; cdlrm_last_error() returns a thread-local message.
+ *   - all tensor memory is CALLER-owned (torch tensors' data_ptr()); the library allocates only the
+ *     opaque context (descriptor copies, small scan scratch, one device error word).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); calls are
+ *     asynchronous on it unless the name ends in _sync.
+ *   - "device-visible" pointers may point to HBM or to pinned / registered host memory.
+ *   - slot ids follow the reference: slot = P_k * way + set, aux slots start at P_k * ways
+ *     (model_no_ddp.py:174, 177); tags are int64 [P_k, ways] row-major, -1 = empty (:144-147).
+ */
+#ifndef CDLRM_HIP_H
+#define CDLRM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDLRM_ABI_VERSION 1
+
+#define CDLRM_EINVAL (-22)   /* bad argument / shape the kernels do not support            */
+#define CDLRM_ERANGE (-34)   /* an index was outside its table, or a capacity was exceeded */
+#define CDLRM_ENOMEM (-12)
+
+typedef struct cdlrm_ctx cdlrm_ctx;
+
+/* Geometry of one cache group (Embedding_Table_Cache_Group.__init__, model_no_ddp.py:101-147). */
+typedef struct {
+    int32_t num_tables;          /* T                                                     */
+    int32_t dim;                 /* D, fp32 elements per row (multiple of 4)               */
+    int32_t num_ways;            /* 1..64                                                  */
+    int32_t aux_rows;            /* aux_table_size (main_no_ddp.py:348)                    */
+    const int64_t* table_rows;   /* [T] n_k  rows of the host master table                 */
+    const int64_t* cache_sets;   /* [T] P_k = min(n_k, find_next_prime(cache_size))        */
+    int32_t device;              /* HIP device ordinal                                     */
+    int32_t reserved;
+} cdlrm_geometry;
+
+int cdlrm_abi_version(void);
+const char* cdlrm_last_error(void);
+
+int cdlrm_ctx_create(const cdlrm_geometry* geo, cdlrm_ctx** out);
+int cdlrm_ctx_destroy(cdlrm_ctx* ctx);
+
+/* Bind the caller-owned cache state.  tags: int64 [sum_k P_k*ways] (table k at element offset
+ * sum_{j<k} P_j*ways); weight: fp32 [sum_k (ways*P_k+aux), D] (table k at row sum_{j<k} rows_j).
+ * Replaces the per-table nn.EmbeddingBag weights + CPU occupancy tables of model_no_ddp.py:130-147. */
+int cdlrm_ctx_bind_cache(cdlrm_ctx* ctx, int64_t* tags, float* weight);
+
+/* Bind the host master tables (Embedding_Table_Group.emb_l[k].weight, model_no_ddp.py:61-74):
+ * host_rows[k] is a device-visible pointer to fp32 [n_k, D] (pinned/registered host memory, or HBM). */
+int cdlrm_ctx_bind_host_tables(cdlrm_ctx* ctx, float* const* host_rows);
+
+/* Pin an existing host allocation so kernels can read/write it over PCIe; returns its device alias. */
+int cdlrm_host_register(void* host_ptr, uint64_t bytes, void** device_alias);
+int cdlrm_host_unregister(void* host_ptr);
+
+/* Read (and clear) the device error word set by kernels on out-of-range input (CDLRM_ERANGE). */
+int cdlrm_ctx_check_sync(cdlrm_ctx* ctx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-iteration path: Embedding_Table_Cache_Group.forward (model_no_ddp.py:149-212)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Tag probe + slot translation + aux-row fill (model_no_ddp.py:163-187).
+ *   idx        device int64 [T, n] (row stride ld_idx): the lookups of every table
+ *   slots_out  device int32 [T, n] contiguous: cache_group_idxs (model_no_ddp.py:204); misses get
+ *              aux slots P_k*ways + i in position order and aux row i is overwritten with the host
+ *              row (:176-179).
+ *   miss_pos   device int32 [T, n]: positions of table k's misses in order, first miss_count[k]
+ *              entries of row k valid (victim_cache_entries, model_no_ddp.py:187)
+ *   miss_count device int32 [T]: number of misses per table.                                     */
+int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx,
+                       int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, void* stream);
+
+/* Fused multi-table sum-pool gather: nn.EmbeddingBag(mode="sum") forward on the cache rows for all
+ * T tables in one launch (model_no_ddp.py:200-203).
+ *   slots    device int32 [T, n]
+ *   offsets  device int64 [T, n_bags] bag starts (row stride ld_off), or NULL for the Criteo layout
+ *            offsets == arange (one index per bag, n_bags == n; data_loader_terabyte.py:83-87)
+ *   out      device fp32: out[(b * ld_bag) + (t * ld_table) + c], c < D.  ld_bag = (T+1)*D and
+ *            ld_table = D with out pointing at feature 1 writes straight into the [B, T+1, D]
+ *            interaction operand (model_no_ddp.py:276).                                         */
+int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,
+                     int64_t n_bags, int64_t ld_off, float* out, int64_t ld_bag, int64_t ld_table,
+                     void* stream);
+
+/* EmbeddingBag backward + sparse SGD on the cache rows, fused and atomics-free
+ * (main_no_ddp.py:376, 409, 413): W[slot] -= lr * sum_{i: slot_i = slot} grad[bag(i)], repeated
+ * slots summed in position order.  Also marks the touched rows for the table-agg merge.
+ *   grad     device fp32, same addressing as `out` above (ld_bag / ld_table)
+ *   work     device scratch, cdlrm_embbag_bwd_work_bytes(T, n) bytes
+ *   touched  device uint8 [total cache rows] or NULL: set to 1 for every updated row
+ *            (replaces cache_group_idxs_window, main_no_ddp.py:417-423)                          */
+uint64_t cdlrm_embbag_bwd_work_bytes(int32_t num_tables, int64_t n, int32_t dim);
+int cdlrm_embbag_bwd_sgd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,
+                         int64_t n_bags, int64_t ld_off, const float* grad, int64_t ld_bag,
+                         int64_t ld_table, float lr, void* work, uint8_t* touched, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Look-ahead window path: Prefetcher.process_batch_slice (cache_manager.py:28-46) and
+ * CacheEmbeddings (main_no_ddp.py:148-209), split into plan (side stream, overlaps training of the
+ * previous window) and commit (at the window boundary).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Caller-owned plan buffers.  Capacities are in elements; a kernel that would exceed one sets the
+ * device error word (CDLRM_ERANGE) instead of writing out of bounds. */
+typedef struct {
+    /* lookahead scan */
+    uint64_t* bitmap;        /* [sum_k ceil(n_k/64)] zero on entry, zero again on return          */
+    int64_t*  uniq;          /* [cap_uniq] sorted unique indices, table-major                      */
+    int64_t*  uniq_off;      /* [T+1] start of table k in uniq                                     */
+    int64_t   cap_uniq;
+    /* insert plan */
+    uint64_t* prot;          /* [sum_k P_k] ways hit by this window, per set (bit w)               */
+    uint8_t*  hit;           /* [cap_uniq] 1 = already cached                                      */
+    int32_t*  kept;          /* [cap_uniq] positions (into uniq) of the claimants, ascending       */
+    int64_t*  kept_off;      /* [T+1]                                                              */
+    uint8_t*  way;           /* [cap_uniq] way chosen by claimant m                                */
+    uint8_t*  flags;         /* [cap_uniq] scratch for the compactions, 16-byte aligned            */
+    int32_t*  winner;        /* [total cache rows] scratch, -1 on entry and on return              */
+    int32_t*  win_claim;     /* [cap_win] claimant id m of winner w (ascending)                    */
+    int64_t*  win_idx;       /* [cap_win] index being inserted                                     */
+    int64_t*  win_row;       /* [cap_win] global cache row = row_base_k + P_k*way + set            */
+    int64_t*  win_tag;       /* [cap_win] global tag element = tag_base_k + set*ways + way         */
+    int64_t*  win_off;       /* [T+1]                                                              */
+    int64_t   cap_win;
+    float*    stage;         /* [cap_win, D] incoming rows; after commit: the rows they replaced   */
+    int64_t*  ev_tag;        /* [cap_win] after commit: tag that was evicted, -1 if slot was empty */
+} cdlrm_plan;
+
+/* K1: sorted unique of every table's window indices (torch.unique, cache_manager.py:32) by bitmap +
+ * popcount scan.  idx: device int64 [T, n] (row stride ld_idx).  Fills plan->uniq / uniq_off. */
+int cdlrm_window_unique(cdlrm_ctx* ctx, const cdlrm_plan* plan, const int64_t* idx, int64_t n,
+                        int64_t ld_idx, void* stream);
+
+/* K2: tag probe of the unique list + full-set filter (main_no_ddp.py:155-180).
+ * Fills hit / prot / kept / kept_off.  uniq and uniq_off must be valid (from cdlrm_window_unique or
+ * written by the caller for the CacheEmbeddings drop-in entry). */
+int cdlrm_plan_probe(cdlrm_ctx* ctx, const cdlrm_plan* plan, void* stream);
+
+/* Copy uniq_off / kept_off / win_off ([T+1] each, any may be NULL) to host memory and wait. */
+int cdlrm_plan_offsets_sync(cdlrm_ctx* ctx, const cdlrm_plan* plan, int64_t* uniq_off,
+                            int64_t* kept_off, int64_t* win_off, void* stream);
+
+/* K3: way choice + contested-slot resolution (main_no_ddp.py:171-185, 203-204).
+ *   q  device fp32 [M_total, ways] Exp(1) draws in claimant order (parity mode: drawn by the torch
+ *      CPU generator exactly as Categorical.sample() does), or NULL: counter-based Philox keyed by
+ *      `seed` on the device (perf mode, not bit-comparable with the reference).
+ * way = argmax_w((avail_w / sum avail) / q_w), first maximum; the claimant latest in ascending-index
+ * order wins a contested (set, way).  Fills way / win_* . */
+int cdlrm_plan_assign(cdlrm_ctx* ctx, const cdlrm_plan* plan, const float* q, uint64_t seed,
+                      void* stream);
+
+/* K5a: fetch the winners' rows into plan->stage.
+ *   src_rows [T] host array of device-visible base pointers; by_position = 0: row = src[k][index]
+ *   (host master tables, Embedding_Table_Group.fetch_unique_idx_slices, model_no_ddp.py:80-87);
+ *   by_position = 1: row = src[k][position in uniq_k] (the `cached_entries_per_table` argument of
+ *   CacheEmbeddings, main_no_ddp.py:205-206). */
+int cdlrm_plan_fetch(cdlrm_ctx* ctx, const cdlrm_plan* plan, const float* const* src_rows,
+                     int by_position, void* stream);
+
+/* K4+K5b: at the window boundary swap stage <-> cache rows and write the tags
+ * (main_no_ddp.py:190-206).  Afterwards stage[w] / ev_tag[w] hold the evicted row / tag. */
+int cdlrm_plan_commit(cdlrm_ctx* ctx, const cdlrm_plan* plan, void* stream);
+
+/* K14: eviction write-back (Prefetcher.eviction_manager, cache_manager.py:57-62):
+ * host[k][ev_tag] = row, or (host + row) / 2 with average != 0.  dst_rows as src_rows above. */
+int cdlrm_plan_writeback(cdlrm_ctx* ctx, const cdlrm_plan* plan, float* const* dst_rows,
+                         int average, void* stream);
+
+/* Generic row gather used by the drop-in process_batch_slice (rows = W_host[uniq],
+ * model_no_ddp.py:84): out[i, :] = src[index[i], :]. */
+int cdlrm_gather_rows(const float* src, const int64_t* index, int64_t count, int32_t dim,
+                      float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Table aggregation (broadcast_and_aggregate, main_no_ddp.py:250-292)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Compact the touched-row flags into a sorted row list (torch.unique over the gathered
+ * cache_group_idxs, :270) and clear them.  rows_out device int64 [cap]; count_out device int64 [1]. */
+int cdlrm_agg_compact(cdlrm_ctx* ctx, uint8_t* touched, int64_t total_rows, int64_t* rows_out,
+                      int64_t cap, int64_t* count_out, void* stream);
+/* buf[i,:] = weight[rows[i],:] * scale   (:273-281)   /   weight[rows[i],:] = buf[i,:]   (:288-292) */
+int cdlrm_agg_gather(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, float scale,
+                     float* buf, int64_t cap, void* stream);
+int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, const float* buf,
+                      int64_t cap, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense model: DLRM_Net (model_no_ddp.py:215-316), loss (main_no_ddp.py:212-221), SGD (:375, 415)
+ * ------------------------------------------------------------------------------------------- */
+
+/* interact_features "dot" (model_no_ddp.py:272-293): feat fp32 [B, F, D] (feature 0 = bottom-MLP
+ * output x); R[b] = [x_b, <f_i, f_j> for i in 0..F-1 for j in 0..i-1(+itself)] fp32 [B, ld_r]. */
+int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32_t itself,
+                       float* R, int64_t ld_r, void* stream);
+/* dfeat[b] = (G + G^T) feat_b with G the strictly-lower (or lower) triangle filled from dR, plus dR's
+ * first D columns added to feature 0. */
+int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F,
+                       int32_t D, int32_t itself, float* dfeat, void* stream);
+
+/* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
+ * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */
+int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y,
+                     int64_t ld_y, int64_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/* Backward of the same layer.  dY is overwritten in place by dZ = dY * act'(Y).
+ * dX [M, K] ld_dx (may be NULL for the first layer), dW [N, K], db [N].
+ * work: device scratch of cdlrm_linear_bwd_work_bytes(M, N, K) bytes (split-M partial slabs of dW,
+ * summed in a fixed order: bitwise reproducible). */
+uint64_t cdlrm_linear_bwd_work_bytes(int64_t M, int32_t N, int32_t K);
+int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y,
+                     float* dY, int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db,
+                     int64_t M, int32_t N, int32_t K, int32_t act, void* work, void* stream);
+
+/* BCELoss(mean) forward + backward on the sigmoid output (torch clamps log at -100):
+ * loss_out device fp32 [65]: [0] = loss, [1..64] = partial sums (fixed-order, reproducible);
+ * dZ[i] = (z - t) / (max((1 - z) z, 1e-12) * n), may be NULL. */
+int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* loss_out, float* dZ,
+                      void* stream);
+
+/* p -= lr * g over a flat fp32 buffer (optim.SGD without momentum, main_no_ddp.py:375, 415). */
+int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float lr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDLRM_HIP_H */

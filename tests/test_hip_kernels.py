@@ -1,0 +1,361 @@
+"""GPU parity tests of the C-ABI kernels against the CPU oracle and the reference's golden vectors.
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cdlrm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cdlrm_amd import ops as _ops
+    from cdlrm_amd import _lib
+    _lib.lib()
+    return _ops
+
+
+class DevState:
+    """Flat device cache state + pinned host tables built from per-table CPU tensors."""
+
+    def __init__(self, ops, ln_emb, cache_sizes, D, ways, aux, occ, weights, host):
+        self.ops = ops
+        self.ctx = ops.CacheCtx(ln_emb, cache_sizes, D, ways, aux, torch.device(DEV))
+        self.tags = torch.cat([o.reshape(-1) for o in occ]).to(DEV)
+        self.weight = torch.cat(list(weights)).contiguous().to(DEV)
+        self.ctx.bind_cache(self.tags, self.weight)
+        self.host = [h.clone().pin_memory() for h in host]
+        self.ctx.bind_host_tables([h.data_ptr() for h in self.host])
+        self.cache_sizes, self.ways = list(cache_sizes), ways
+
+    def occ(self, k):
+        c = self.ctx
+        return self.tags[c.tag_base[k]:c.tag_base[k + 1]].view(c.cache_sets[k], c.ways).cpu()
+
+    def w(self, k):
+        c = self.ctx
+        return self.weight[c.row_base[k]:c.row_base[k + 1]].cpu()
+
+
+def load_windows(g):
+    ln_emb = [int(x) for x in g["ln_emb"]]
+    T, ways, B = len(ln_emb), int(g["ways"]), int(g["B"])
+    cache_sizes = [int(x) for x in g["cache_sizes"]]
+    return ln_emb, T, ways, B, cache_sizes, int(g["m_spa"])
+
+
+@pytest.mark.parametrize("name", ["cache_windows_small", "cache_windows_uniform"])
+def test_probe_and_gather_forward(ops, golden, name):
+    g = golden(name)
+    ln_emb, T, ways, B, cache_sizes, D = load_windows(g)
+    for w in range(int(g["nwin"])):
+        occ = [t(g[f"w{w}_occ_{k}"]) for k in range(T)]
+        weights = [t(g[f"w{w}_weight_{k}"]) for k in range(T)]
+        host = [t(g[f"w{w}_host_{k}"]) for k in range(T)]
+        st = DevState(ops, ln_emb, cache_sizes, D, ways, B, occ, weights, host)
+        lS_i = t(g[f"w{w}_fwd_lS_i"]).to(DEV)
+        slots, miss_pos, miss_count = ops.embbag_probe(st.ctx, lS_i)
+        feat = torch.zeros(B, T + 1, D, device=DEV)
+        ops.embbag_fwd(st.ctx, slots, None, feat[:, 1:, :], (T + 1) * D, D)
+        st.ctx.check()
+        for k in range(T):
+            assert torch.equal(slots[k].cpu(), t(g[f"w{w}_fwd_idx_{k}"])), (w, k)          # bit-exact slot ids
+            assert torch.equal(feat[:, k + 1, :].cpu(), t(g[f"w{w}_fwd_ly_{k}"])), (w, k)  # exact row copies
+            assert torch.equal(st.w(k), t(g[f"w{w}_fwd_weight_{k}"])), (w, k)             # aux rows written
+            nm = int(miss_count[k])
+            want_miss = (t(g[f"w{w}_fwd_idx_{k}"]) >= cache_sizes[k] * ways).nonzero().flatten()
+            assert torch.equal(miss_pos[k, :nm].cpu().long(), want_miss)
+        assert torch.all(feat[:, 0, :] == 0)
+
+
+def test_appendix_a(ops, golden):
+    g = golden("appendix_a")
+    P = int(g["P"][0])
+    st = DevState(ops, [50], [P], 2 + 2, 2, 4, [torch.full((P, 2), -1, dtype=torch.int64)],
+                  [torch.zeros(2 * P + 4, 4)], [torch.cat([t(g["host"]), t(g["host"])], 1)])
+    plan = ops.WindowPlan(st.ctx, 64)
+    for w in range(2):
+        raw = t(g[f"w{w}_raw"]).view(1, -1).to(DEV)
+        plan.unique(raw)
+        plan.probe()
+        uo, ko, _ = plan.offsets()
+        assert torch.equal(plan.uniq[:uo[1]].cpu(), t(g[f"w{w}_uniq"]))
+        q = t(g[f"w{w}_q"]).to(DEV)
+        assert ko[1] == q.shape[0]
+        plan.assign(q)
+        plan.fetch([h.data_ptr() for h in st.host], False)
+        plan.commit()
+        plan.writeback([h.data_ptr() for h in st.host], False)
+        torch.cuda.synchronize()
+        st.ctx.check()
+        assert torch.equal(plan.way[:ko[1]].cpu().long(), t(g[f"w{w}_way"]))
+        assert torch.equal(st.occ(0), t(g[f"w{w}_occ"]))
+        assert torch.equal(st.w(0)[:, :2], t(g[f"w{w}_weight"]))
+    assert st.occ(0).tolist() == [[-1, -1], [16, 26], [-1, -1], [8, 3], [-1, 4]]
+
+
+@pytest.mark.parametrize("by_position", [False, True])
+@pytest.mark.parametrize("name", ["cache_windows_small", "cache_windows_uniform"])
+def test_window_insert_evict(ops, golden, name, by_position):
+    """unique scan -> probe -> way choice (reference's own q) -> fetch -> commit -> write-back over
+    consecutive windows: tags bit-exact, rows exact copies, evictions set-equal, host tables equal."""
+    g = golden(name)
+    ln_emb, T, ways, B, cache_sizes, D = load_windows(g)
+    occ = O.new_occupancy_tables(cache_sizes, ways)
+    weights = [t(g[f"weight0_{k}"]) for k in range(T)]
+    host = [t(g[f"host0_{k}"]) for k in range(T)]
+    st = DevState(ops, ln_emb, cache_sizes, D, ways, B, occ, weights, host)
+    plan = ops.WindowPlan(st.ctx, int(g["L"]) * B)
+    for w in range(int(g["nwin"])):
+        win = t(g[f"w{w}_win"]).to(DEV)
+        plan.unique(win)
+        plan.probe()
+        uo, ko, _ = plan.offsets()
+        q_parts = []
+        for k in range(T):
+            assert torch.equal(plan.uniq[uo[k]:uo[k + 1]].cpu(), t(g[f"w{w}_uniq_{k}"])), (w, k)
+            qk = t(g[f"w{w}_q_{k}"])
+            assert ko[k + 1] - ko[k] == qk.shape[0], (w, k)
+            q_parts.append(qk.reshape(-1, ways))
+        plan.assign(torch.cat(q_parts).contiguous().to(DEV))
+        if by_position:
+            rows = [ops.gather_rows(st.host[k].data_ptr(), plan.uniq[uo[k]:uo[k + 1]], D) for k in range(T)]
+            for k in range(T):
+                assert torch.equal(rows[k].cpu(), t(g[f"w{w}_rows_{k}"]))
+            # empty tables still need a valid pointer
+            plan.fetch([r.data_ptr() if r.numel() else st.weight.data_ptr() for r in rows], True)
+        else:
+            plan.fetch([h.data_ptr() for h in st.host], False)
+        plan.commit()
+        plan.writeback([h.data_ptr() for h in st.host], False)
+        _, _, wo = plan.offsets()
+        torch.cuda.synchronize()
+        st.ctx.check()
+        for k in range(T):
+            assert torch.equal(plan.way[ko[k]:ko[k + 1]].cpu().long(), t(g[f"w{w}_way_{k}"])), (w, k)
+            assert torch.equal(st.occ(k), t(g[f"w{w}_occ_{k}"])), (w, k)
+            nslots = cache_sizes[k] * ways
+            assert torch.equal(st.w(k)[:nslots], t(g[f"w{w}_weight_{k}"])[:nslots]), (w, k)
+            ev_tag = plan.ev_tag[wo[k]:wo[k + 1]].cpu()
+            ev_rows = plan.stage[wo[k]:wo[k + 1]].cpu()
+            valid = ev_tag != -1
+            gi, gr = O.dedup_evictions(t(g[f"w{w}_ev_idx_{k}"]), t(g[f"w{w}_ev_rows_{k}"]))
+            mi, mr = O.dedup_evictions(ev_tag[valid], ev_rows[valid])
+            assert torch.equal(mi, gi) and torch.equal(mr, gr), (w, k)
+            assert torch.equal(st.host[k], t(g[f"w{w}_host_{k}"])), (w, k)
+        # scratch must be clean for the next window
+        assert int((plan.winner != -1).sum()) == 0 and int(plan.prot.abs().sum()) == 0
+        assert int(plan.bitmap.abs().sum()) == 0
+
+
+def test_device_rng_mode_is_valid_insert(ops, golden):
+    """Perf mode (Philox on device) is not bit-comparable, but must produce a legal insert: no protected
+    way overwritten, tags unique per set, every resident tag maps to its set, rows match the host."""
+    g = golden("cache_windows_small")
+    ln_emb, T, ways, B, cache_sizes, D = load_windows(g)
+    occ = O.new_occupancy_tables(cache_sizes, ways)
+    st = DevState(ops, ln_emb, cache_sizes, D, ways, B, occ, [t(g[f"weight0_{k}"]) for k in range(T)],
+                  [t(g[f"host0_{k}"]) for k in range(T)])
+    plan = ops.WindowPlan(st.ctx, int(g["L"]) * B)
+    for w in range(int(g["nwin"])):
+        win = t(g[f"w{w}_win"]).to(DEV)
+        pre = [st.occ(k).clone() for k in range(T)]
+        plan.unique(win); plan.probe(); plan.assign(None, seed=1234 + w)
+        plan.fetch([h.data_ptr() for h in st.host], False); plan.commit()
+        plan.writeback([h.data_ptr() for h in st.host], False)
+        torch.cuda.synchronize(); st.ctx.check()
+        for k in range(T):
+            o = st.occ(k)
+            u = torch.unique(win[k].cpu())
+            P = cache_sizes[k]
+            # hits stay where they were
+            was = (pre[k][u % P] == u.view(-1, 1))
+            assert torch.equal(o[u % P][was], pre[k][u % P][was])
+            res = o[o != -1]
+            assert res.numel() == torch.unique(res).numel()
+            sets = (o != -1).nonzero()[:, 0]
+            assert torch.equal(res % P, sets)
+            slots_rows = st.w(k)[: P * ways].view(ways, P, D).permute(1, 0, 2)[o != -1]
+            # rows of tags inserted in THIS window equal the host rows (host is written back synchronously)
+            new = ~torch.isin(res, pre[k][pre[k] != -1])
+            assert torch.equal(slots_rows[new], st.host[k][res[new]])
+
+
+@pytest.mark.parametrize("name", ["embsgd_onehot", "embsgd_multihot"])
+def test_embbag_bwd_sgd_golden(ops, golden, name):
+    g = golden(name)
+    w0 = t(g["w0"])
+    rows, D = w0.shape
+    st = DevState(ops, [rows], [rows // 2], D, 2, 0, [torch.full((rows // 2, 2), -1, dtype=torch.int64)], [w0],
+                  [torch.zeros(rows, D)])
+    slots = t(g["slots"]).to(torch.int32).view(1, -1).to(DEV)
+    offs = t(g["offsets"]).view(1, -1).to(DEV)
+    nb = offs.shape[1]
+    onehot = name.endswith("onehot")
+    out = torch.zeros(nb, 1, D, device=DEV)
+    ops.embbag_fwd(st.ctx, slots, None if onehot else offs, out, D, D)
+    np.testing.assert_allclose(out[:, 0].cpu().numpy(), g["V"], rtol=1e-6, atol=1e-7)
+    grad = t(g["grad"]).view(nb, 1, D).contiguous().to(DEV)
+    work = ops.embbag_bwd_work(st.ctx, slots.shape[1], DEV)
+    touched = torch.zeros(st.ctx.total_rows, dtype=torch.uint8, device=DEV)
+    ops.embbag_bwd_sgd(st.ctx, slots, None if onehot else offs, grad, D, D, float(g["lr"]), work, touched)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st.w(0).numpy(), g["w1"], rtol=1e-6, atol=1e-7)
+    assert torch.equal(touched.cpu().nonzero().flatten(), torch.unique(t(g["slots"])))
+
+
+@pytest.mark.parametrize("T,n,D,nslots,hot", [(3, 1000, 16, 64, 0.0), (2, 9000, 32, 5000, 0.6), (1, 20000, 128, 300, 0.3),
+                                            (26, 2048, 64, 100000, 0.2)])
+def test_embbag_bwd_sgd_vs_oracle(ops, T, n, D, nslots, hot):
+    """Heavy repeats (long segments, multi-chunk sort/merge) against the oracle; result must also be
+    bitwise reproducible run to run (no atomics)."""
+    rng = np.random.RandomState(T * 1000 + n)
+    P = (nslots + 1) // 2
+    st = DevState(ops, [2 * P + 8] * T, [P] * T, D, 2, 8, [torch.full((P, 2), -1, dtype=torch.int64)] * T,
+                  [torch.from_numpy(rng.randn(2 * P + 8, D).astype(np.float32)) for _ in range(T)],
+                  [torch.zeros(2 * P + 8, D)] * T)
+    slots = rng.randint(0, 2 * P, (T, n))
+    if hot > 0:
+        m = rng.rand(T, n) < hot
+        slots[m] = 7
+    slots_t = torch.from_numpy(slots.astype(np.int32)).to(DEV)
+    grad = torch.from_numpy(rng.randn(n, T, D).astype(np.float32)).to(DEV)
+    w_before = st.weight.clone()
+    work = ops.embbag_bwd_work(st.ctx, n, DEV)
+    results = []
+    for rep in range(2):
+        st.weight.copy_(w_before)
+        ops.embbag_bwd_sgd(st.ctx, slots_t, None, grad, T * D, D, 0.25, work, None)
+        torch.cuda.synchronize()
+        results.append(st.weight.clone())
+    assert torch.equal(results[0], results[1])
+    for k in range(T):
+        w = w_before[st.ctx.row_base[k]:st.ctx.row_base[k + 1]].cpu().clone()
+        O.embbag_bwd_sgd(w, torch.from_numpy(slots[k]), torch.arange(n), grad[:, k, :].cpu(), 0.25)
+        np.testing.assert_allclose(st.w(k).numpy(), w.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("itself", [0, 1])
+def test_dense_golden(ops, golden, itself):
+    """DLRM_Net forward/backward from the reference: R, Z, loss and every gradient."""
+    g = golden("dense_itself%d" % itself)
+    nb, nt = len(g["ln_bot"]) - 1, len(g["ln_top"]) - 1
+    X, Tt = t(g["X"]).to(DEV), t(g["T"]).to(DEV)
+    B = X.shape[0]
+    ly = [t(g[f"ly_{k}"]) for k in range(5)]
+    D = ly[0].shape[1]
+    F = 6
+    feat = torch.zeros(B, F, D, device=DEV)
+    for k in range(5):
+        feat[:, k + 1] = ly[k].to(DEV)
+
+    def run_mlp(x, pre, n, last_sigmoid, out_last=None):
+        acts, cur = [x], x
+        for i in range(n):
+            W, b = t(g[f"{pre}_w{i}"]).to(DEV), t(g[f"{pre}_b{i}"]).to(DEV)
+            if out_last is not None and i == n - 1:
+                y = out_last
+            else:
+                y = torch.empty(B, W.shape[0], device=DEV)
+            ops.linear_fwd(cur, W, b, y, 2 if (last_sigmoid and i == n - 1) else 1)
+            acts.append(y)
+            cur = y
+        return acts
+
+    bot = run_mlp(X, "bot", nb, False, out_last=feat[:, 0, :])
+    npairs = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+    R = torch.empty(B, D + npairs, device=DEV)
+    ops.interact_fwd(feat, bool(itself), R)
+    top = run_mlp(R, "top", nt, True)
+    Z = top[-1]
+    lossbuf = torch.zeros(65, device=DEV)
+    dZ = torch.empty_like(Z)
+    ops.bce_fwd_bwd(Z, Tt, lossbuf, dZ)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(R.cpu().numpy(), g["R"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Z.cpu().numpy(), g["Z"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(lossbuf[0]), float(g["loss"]), rtol=1e-6)
+
+    def back_mlp(acts, pre, n, last_sigmoid, dY, need_dx):
+        for i in reversed(range(n)):
+            W = t(g[f"{pre}_w{i}"]).to(DEV)
+            Xi, Yi = acts[i], acts[i + 1]
+            dW, db = torch.empty_like(W), torch.empty(W.shape[0], device=DEV)
+            dX = torch.empty(B, W.shape[1], device=DEV) if (i > 0 or need_dx) else None
+            work = ops.linear_bwd_work(B, W.shape[0], W.shape[1], DEV)
+            ops.linear_bwd(Xi, W, Yi, dY, dX, dW, db, 2 if (last_sigmoid and i == n - 1) else 1, work)
+            np.testing.assert_allclose(dW.cpu().numpy(), g[f"{pre}_gw{i}"], rtol=2e-4, atol=1e-7)
+            np.testing.assert_allclose(db.cpu().numpy(), g[f"{pre}_gb{i}"], rtol=2e-4, atol=1e-7)
+            dY = dX
+        return dY
+
+    dR = back_mlp(top, "top", nt, True, dZ, True)
+    dfeat = torch.empty_like(feat)
+    ops.interact_bwd(feat, dR, bool(itself), dfeat)
+    torch.cuda.synchronize()
+    for k in range(5):
+        np.testing.assert_allclose(dfeat[:, k + 1].cpu().numpy(), g[f"ly_grad_{k}"], rtol=2e-4, atol=1e-8)
+    back_mlp(bot, "bot", nb, False, dfeat[:, 0, :].contiguous(), False)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(8192, 512, 13, 1), (1000, 256, 512, 1), (777, 1, 256, 2), (4096, 512, 479, 1),
+                                       (130, 70, 33, 0)])
+def test_linear_vs_torch_fp32(ops, M, N, K, act):
+    """FP32-MFMA Linear fwd/bwd against a plain torch fp32 reference (CPU, float64 accumulate for the bound)."""
+    rng = np.random.RandomState(M + N + K)
+    X = torch.from_numpy(rng.randn(M, K).astype(np.float32))
+    W = torch.from_numpy((rng.randn(N, K) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rng.randn(N).astype(np.float32))
+    Xd, Wd, bd = X.to(DEV), W.to(DEV), b.to(DEV)
+    Y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(Xd, Wd, bd, Y, act)
+    pre = X.double() @ W.double().t() + b.double()
+    ref = {0: pre, 1: torch.relu(pre), 2: torch.sigmoid(pre)}[act]
+    np.testing.assert_allclose(Y.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
+    dY = torch.from_numpy(rng.randn(M, N).astype(np.float32))
+    dYd = dY.clone().to(DEV)
+    dX, dW, db = torch.empty(M, K, device=DEV), torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    work = ops.linear_bwd_work(M, N, K, DEV)
+    ops.linear_bwd(Xd, Wd, Y, dYd, dX, dW, db, act, work)
+    Yc = Y.cpu().double()
+    dZ = {0: dY.double(), 1: dY.double() * (Yc > 0), 2: dY.double() * Yc * (1 - Yc)}[act]
+    scale = float(np.sqrt(M))
+    np.testing.assert_allclose(dYd.cpu().numpy(), dZ.float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dX.cpu().numpy(), (dZ @ W.double()).float().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dW.cpu().numpy(), (dZ.t() @ X.double()).float().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), dZ.sum(0).float().numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_sgd_and_agg(ops):
+    p = torch.randn(100003, device=DEV)
+    gr = torch.randn(100003, device=DEV)
+    want = (p.cpu() + (-0.37) * gr.cpu())
+    ops.sgd_step(p, gr, 0.37)
+    np.testing.assert_allclose(p.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
+    st = DevState(ops, [500, 40], [101, 40], 8, 4, 16, [torch.full((101, 4), -1, dtype=torch.int64),
+                                                       torch.full((40, 4), -1, dtype=torch.int64)],
+                  [torch.randn(4 * 101 + 16, 8), torch.randn(4 * 40 + 16, 8)], [torch.zeros(500, 8), torch.zeros(40, 8)])
+    total = st.ctx.total_rows
+    touched = torch.zeros(total, dtype=torch.uint8, device=DEV)
+    rows = torch.randperm(total)[:57].sort().values
+    touched[rows.to(DEV)] = 1
+    out = torch.empty(total, dtype=torch.int64, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.agg_compact(st.ctx, touched, out, cnt)
+    assert int(cnt) == 57 and torch.equal(out[:57].cpu(), rows) and int(touched.sum()) == 0
+    buf = torch.empty(total, 8, device=DEV)
+    before = st.weight.clone()
+    ops.agg_gather(st.ctx, out, cnt, 2.0, buf, total)
+    assert torch.equal(buf[:57].cpu(), before[rows.to(DEV)].cpu() / 2.0)
+    ops.agg_scatter(st.ctx, out, cnt, buf, total)
+    want = before.clone()
+    want[rows.to(DEV)] = before[rows.to(DEV)] / 2.0
+    assert torch.equal(st.weight, want)
