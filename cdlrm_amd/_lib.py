@@ -74,6 +74,9 @@ PROTOTYPES = {
                                    c_i32, vp, vp]),
     "cdlrm_bce_fwd_bwd": (C.c_int, [vp, vp, c_i64, vp, vp, vp]),
     "cdlrm_sgd_step": (C.c_int, [vp, vp, c_i64, c_f32, vp]),
+    "cdlrm_scale_div": (C.c_int, [vp, c_i64, c_f32, vp]),
+    "cdlrm_scatter_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, C.c_int, vp]),
+    "cdlrm_mark_rows": (C.c_int, [vp, vp, c_i64, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -483,3 +483,20 @@ extern "C" int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float 
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
+
+// x /= divisor  (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239) -- a true
+// division so the result matches the reference for every world size, not only powers of two
+__global__ void __launch_bounds__(256) k_scale_div(float* __restrict__ x, int64_t n, float divisor) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = x[i] / divisor;
+}
+
+extern "C" int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream) {
+    CDLRM_REQUIRE(x && n >= 0 && divisor != 0.f, "bad argument");
+    if (n == 0) return 0;
+    int64_t gx = cdiv(n, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_scale_div, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, n, divisor);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}

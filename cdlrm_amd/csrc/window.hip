@@ -591,3 +591,59 @@ extern "C" int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int6
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// small generic helpers of the drop-in surface
+// ---------------------------------------------------------------------------------------------
+// dst[index[i], :] = rows[i, :]  or  (dst + rows) / 2   (Prefetcher.eviction_manager, cache_manager.py:57-62)
+__global__ void __launch_bounds__(256) k_scatter_rows(float4* __restrict__ dst, const int64_t* __restrict__ index,
+                                                      const float4* __restrict__ rows, int64_t count, int D4, int average) {
+    const int64_t total = count * D4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / D4;
+        const int c = (int)(e % D4);
+        float4 v = rows[e];
+        float4* d = dst + index[r] * D4 + c;
+        if (average) {
+            const float4 h = *d;
+            v.x = (h.x + v.x) / 2; v.y = (h.y + v.y) / 2; v.z = (h.z + v.z) / 2; v.w = (h.w + v.w) / 2;
+        }
+        *d = v;
+    }
+}
+
+extern "C" int cdlrm_scatter_rows(float* dst, const int64_t* index, const float* rows, int64_t count, int32_t dim,
+                                  int average, void* stream) {
+    CDLRM_REQUIRE(dst && index && rows && dim % 4 == 0, "bad argument");
+    CDLRM_REQUIRE((((uintptr_t)dst | (uintptr_t)rows) & 15) == 0, "16-byte aligned rows");
+    if (count == 0) return 0;
+    int64_t gx = cdiv(count * (dim / 4), 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(dst), index, reinterpret_cast<const float4*>(rows), count, dim / 4,
+                       average);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// touched[row_base_t + slots[t, i]] = 1  (cache_group_idxs -> touched-row flags, main_no_ddp.py:417-423)
+__global__ void __launch_bounds__(256) k_mark_rows(const TableDesc* __restrict__ tab, const int32_t* __restrict__ slots,
+                                                   int64_t n, uint8_t* __restrict__ touched) {
+    const int t = blockIdx.y;
+    const int64_t rb = tab[t].row_base, rows = tab[t].rows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = slots[(int64_t)t * n + i];
+        if (s >= 0 && s < rows) touched[rb + s] = 1;
+    }
+}
+
+extern "C" int cdlrm_mark_rows(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, uint8_t* touched, void* stream) {
+    CDLRM_REQUIRE(ctx && slots && touched, "null argument");
+    if (n == 0) return 0;
+    int64_t gx = cdiv(n, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_mark_rows, dim3((unsigned)gx, (unsigned)ctx->T), dim3(256), 0, (hipStream_t)stream, ctx->d_tab,
+                       slots, n, touched);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}

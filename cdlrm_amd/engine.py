@@ -1,0 +1,288 @@
+"""The fused per-GPU training engine behind `main_no_ddp.Run` and bench.py.
+
+`TrainEngine.step()` is the reference's loop body (main_no_ddp.py:401-423) as one fixed sequence of
+libcdlrm_hip.so launches on preallocated buffers -- no autograd graph, no per-table Python loop:
+
+    probe -> gather -> bottom MLP -> interaction -> top MLP -> BCE -> top MLP bwd -> interaction bwd
+          -> fused embedding bwd + sparse SGD  ||  bottom MLP bwd -> grad all-reduce (RCCL) -> dense SGD
+          -> every table_agg_freq steps: touched-row merge across ranks
+
+`WindowPipeline` is the look-ahead side: it plans window w+1 (unique scan, tag probe, way choice, winners-
+only pinned-host -> HBM row fetch) on a side HIP stream while window w trains, and commits it at the
+boundary (main_no_ddp.py:393-399, 148-209; cache_manager.py:66-115).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group, _linears
+
+
+class WindowPipeline:
+    def __init__(self, cache_group: Embedding_Table_Cache_Group, host_tables: Embedding_Table_Group, max_window: int,
+                 *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
+                 world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None):
+        self.cg, self.host = cache_group, host_tables
+        self.ctx = cache_group.ctx
+        self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
+        self.side = torch.cuda.Stream(device=cache_group.weight.device)
+        self.parity_rng, self.seed, self.avg = parity_rng, int(seed), average_on_writeback
+        self.rank, self.world = rank, world_size
+        self.host_ptrs = host_tables.device_pointers()
+        self.ctx.bind_host_tables(self.host_ptrs)
+        self.window_no = 0
+        self.planned = None          # event: plan of the next window is ready
+        self.written_back = None     # event: evictions of the last commit are in the host tables
+        self.last_offsets = None
+
+    def plan_window(self, window_idx: torch.Tensor, q_source=None):
+        """Launch the plan of one window ([T, n] int64 on device) on the side stream."""
+        plan, side = self.plan, self.side
+        side.wait_stream(torch.cuda.current_stream())          # window_idx may have been produced there
+        with torch.cuda.stream(side):
+            plan.unique(window_idx, stream=side)
+            plan.probe(stream=side)
+            if self.parity_rng:
+                # Categorical.sample() draws from the torch CPU generator, table by table (main_no_ddp.py:184-185)
+                uo, ko, _ = plan.offsets(stream=side)
+                T, ways = self.ctx.T, self.ctx.ways
+                src = q_source if q_source is not None else (lambda M, w: torch.empty(M, w).exponential_(1) if M else torch.empty(0, w))
+                qs = [src(ko[k + 1] - ko[k], ways) for k in range(T)]
+                q = torch.cat(qs).contiguous().to(window_idx.device, non_blocking=False) if ko[T] else None
+                self.last_offsets = (uo, ko)
+                plan.assign(q if q is not None else torch.empty(1, ways, device=window_idx.device), stream=side)
+            else:
+                plan.assign(None, seed=self.seed * 1000003 + self.window_no, stream=side)
+            plan.fetch(self.host_ptrs, False, stream=side)
+            window_idx.record_stream(side)
+            self.planned = torch.cuda.Event()
+            self.planned.record(side)
+        self.window_no += 1
+
+    def commit(self):
+        """At the window boundary: swap the fetched rows in, write the tags, write the evicted rows back."""
+        main = torch.cuda.current_stream()
+        assert self.planned is not None, "plan_window() first"
+        main.wait_event(self.planned)
+        self.plan.commit(stream=main)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(done)
+            if self.rank == 0:      # evictions come from rank 0's copy only (main_no_ddp.py:208, 312-315)
+                self.plan.writeback(self.host_ptrs, self.avg, stream=self.side)
+            self.written_back = torch.cuda.Event()
+            self.written_back.record(self.side)
+        self.planned = None
+
+    def wait_writeback(self):
+        """Host-side: the evicted rows are in the host tables (all ranks may read them afterwards)."""
+        if self.written_back is not None:
+            self.written_back.synchronize()
+        if self.world > 1:
+            dist.barrier()
+
+    def eviction_data(self):
+        """(idx, rows) per table, as the reference queues them (main_no_ddp.py:199); synchronises."""
+        _, _, wo = self.plan.offsets()
+        out = []
+        for k in range(self.ctx.T):
+            tag = self.plan.ev_tag[wo[k]:wo[k + 1]]
+            valid = tag != -1
+            out.append((tag[valid], self.plan.stage[wo[k]:wo[k + 1]][valid]))
+        return out
+
+
+class TrainEngine:
+    def __init__(self, cache_group: Embedding_Table_Cache_Group, dlrm: DLRM_Net, host_tables: Embedding_Table_Group,
+                 *, lr: float, lr_embeds: float, world_size: int = 1, rank: int = 0, table_agg_freq: int = 1,
+                 table_agg_op: str = "mean", process_group=None):
+        self.cg, self.dlrm, self.host = cache_group, dlrm, host_tables
+        self.ctx = cache_group.ctx
+        self.dev = cache_group.weight.device
+        self.lr, self.lr_embeds = float(lr), float(lr_embeds)
+        self.world, self.rank = int(world_size), int(rank)
+        self.agg_freq, self.agg_op = int(table_agg_freq), table_agg_op
+        self.pg = process_group
+        self.T, self.D = self.ctx.T, self.ctx.D
+        self.F = self.T + 1
+        self.itself = bool(dlrm.arch_interaction_itself)
+        assert dlrm.arch_interaction_op == "dot", "the fused engine implements the dot interaction"
+        self.bot = dlrm._acts(dlrm.bot_l, dlrm.sigmoid_bot)
+        self.top = dlrm._acts(dlrm.top_l, dlrm.sigmoid_top)
+        self._flatten_params()
+        self.ctx.bind_host_tables(host_tables.device_pointers())
+        self._bufs = {}
+        self.iter = 0
+        self.comm = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.agg_rows = None
+
+    # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
+    def _flatten_params(self):
+        lin = _linears(self.dlrm.bot_l) + _linears(self.dlrm.top_l)
+        nw = sum(l.weight.numel() for l in lin)
+        nb = sum(l.bias.numel() for l in lin)
+        self.param_flat = torch.empty(nw + nb, dtype=torch.float32, device=self.dev)
+        self.grad_flat = torch.zeros(nw + nb, dtype=torch.float32, device=self.dev)
+        self.n_weight = nw
+        off_w, off_b = 0, nw
+        self.gW, self.gb = {}, {}
+        for l in lin:
+            n = l.weight.numel()
+            self.param_flat[off_w:off_w + n].copy_(l.weight.data.reshape(-1))
+            l.weight.data = self.param_flat[off_w:off_w + n].view_as(l.weight.data)
+            self.gW[l] = self.grad_flat[off_w:off_w + n].view_as(l.weight.data)
+            l.weight.grad = self.gW[l]
+            off_w += n
+            m = l.bias.numel()
+            self.param_flat[off_b:off_b + m].copy_(l.bias.data)
+            l.bias.data = self.param_flat[off_b:off_b + m]
+            self.gb[l] = self.grad_flat[off_b:off_b + m]
+            l.bias.grad = self.gb[l]
+            off_b += m
+
+    def _buffers(self, B):
+        if B in self._bufs:
+            return self._bufs[B]
+        dev, D, F = self.dev, self.D, self.F
+        f32 = torch.float32
+        npairs = F * (F + 1) // 2 if self.itself else F * (F - 1) // 2
+        b = dict()
+        b["feat"] = torch.empty(B, F, D, dtype=f32, device=dev)
+        b["dfeat"] = torch.empty(B, F, D, dtype=f32, device=dev)
+        b["R"] = torch.empty(B, D + npairs, dtype=f32, device=dev)
+        b["dR"] = torch.empty(B, D + npairs, dtype=f32, device=dev)
+        # activations / gradients of the hidden layers
+        b["bot_y"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.bot[:-1]]
+        b["bot_dy"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.bot[:-1]]
+        b["top_y"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.top]
+        b["top_dy"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.top]
+        b["loss"] = torch.zeros(65, dtype=f32, device=dev)
+        work = 0
+        for l, _ in self.bot + self.top:
+            work = max(work, ops.linear_bwd_work(B, l.out_features, l.in_features, dev).numel())
+        b["lin_work"] = torch.empty(work, dtype=torch.uint8, device=dev)
+        self._bufs[B] = b
+        return b
+
+    def _emb_work(self, n):
+        key = ("emb", n)
+        if key not in self._bufs:
+            self._bufs[key] = ops.embbag_bwd_work(self.ctx, n, self.dev)
+        return self._bufs[key]
+
+    # ----------------------------------------------------------------------------------------------
+    def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
+             j: Optional[int] = None):
+        """One training iteration on this rank's slice.  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
+        on the device; lS_o None = Criteo layout; j = batch number inside the epoch (table-agg schedule).
+        Returns the device loss buffer (element 0 = BCE loss)."""
+        ctx, cg = self.ctx, self.cg
+        B = X.shape[0]
+        n = lS_i.shape[1]
+        buf = self._buffers(B)
+        feat, dfeat, R, dR = buf["feat"], buf["dfeat"], buf["R"], buf["dR"]
+        F, D = self.F, self.D
+        # ---- forward ----
+        slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i)
+        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+        cur = X
+        bot_acts = [X]
+        for i, (l, act) in enumerate(self.bot):
+            y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
+            ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
+            bot_acts.append(y)
+            cur = y
+        ops.interact_fwd(feat, self.itself, R)
+        cur = R
+        top_acts = [R]
+        for i, (l, act) in enumerate(self.top):
+            y = buf["top_y"][i]
+            ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
+            top_acts.append(y)
+            cur = y
+        Z = cur
+        ops.bce_fwd_bwd(Z, T, buf["loss"], buf["top_dy"][-1])
+        # ---- backward ----
+        dY = buf["top_dy"][-1]
+        for i in reversed(range(len(self.top))):
+            l, act = self.top[i]
+            dX = dR if i == 0 else buf["top_dy"][i - 1]
+            ops.linear_bwd(top_acts[i], l.weight.data, top_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
+                           buf["lin_work"])
+            dY = dX
+        ops.interact_bwd(feat, dR, self.itself, dfeat)
+        # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
+        # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            ops.embbag_bwd_sgd(ctx, slots, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, self._emb_work(n),
+                               cg.touched, stream=self.side)
+            slots.record_stream(self.side)
+        dY = dfeat[:, 0, :]
+        for i in reversed(range(len(self.bot))):
+            l, act = self.bot[i]
+            dX = None if i == 0 else buf["bot_dy"][i - 1]
+            ops.linear_bwd(bot_acts[i], l.weight.data, bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
+                           buf["lin_work"])
+            dY = dX
+        # ---- dense gradient exchange + SGD ----
+        if self.world > 1:
+            gw = self.grad_flat[:self.n_weight]
+            ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
+            self.comm.wait_stream(main)
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
+            main.wait_stream(self.comm)
+        ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
+        main.wait_stream(self.side)
+        # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
+        if j is None:
+            j = self.iter
+        if j > 0 and j % self.agg_freq == 0:
+            self.table_aggregate()
+        self.iter += 1
+        return buf["loss"]
+
+    def table_aggregate(self):
+        """broadcast_and_aggregate (main_no_ddp.py:250-292): average the rows any rank touched since the last
+        merge.  Slot ids are global, so the union of touched rows is an all-reduce(MAX) of the flag bytes; the
+        rows then travel as one compacted [U, D] buffer."""
+        cg, ctx = self.cg, self.ctx
+        touched = cg.touched
+        if self.world == 1:
+            # a single rank averages with itself: W[u] = W[u] / 1; only the bookkeeping is reset
+            touched.zero_()
+            return
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=self.pg)
+        total = ctx.total_rows
+        if self.agg_rows is None:
+            self.agg_rows = torch.empty(total, dtype=torch.int64, device=self.dev)
+            self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.agg_count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        ops.agg_compact(ctx, touched, self.agg_rows, self.agg_count)
+        self.agg_count_host.copy_(self.agg_count, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        U = int(self.agg_count_host[0])
+        if U == 0:
+            return
+        buf = torch.empty(U, self.D, dtype=torch.float32, device=self.dev)
+        if self.agg_op == "mean":
+            ops.agg_gather(ctx, self.agg_rows, self.agg_count, float(self.world), buf, U)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        elif self.agg_op == "sum":
+            ops.agg_gather(ctx, self.agg_rows, self.agg_count, 1.0, buf, U)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        elif self.agg_op == "max":
+            ops.agg_gather(ctx, self.agg_rows, self.agg_count, 1.0, buf, U)
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.pg)
+        else:
+            raise ValueError(self.agg_op)
+        ops.agg_scatter(ctx, self.agg_rows, self.agg_count, buf, U)

@@ -282,6 +282,24 @@ def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, d
                                        stream_ptr(stream)))
 
 
+def scale_div(x: torch.Tensor, divisor: float, stream=None):
+    assert x.is_contiguous()
+    check(_lib.lib().cdlrm_scale_div(x.data_ptr(), x.numel(), float(divisor), stream_ptr(stream)))
+
+
+def scatter_rows(dst_ptr: int, index: torch.Tensor, rows: torch.Tensor, average: bool, stream=None):
+    _require_cuda(index, "index"); _require_cuda(rows, "rows")
+    assert rows.is_contiguous() and index.is_contiguous() and index.dtype == torch.int64
+    check(_lib.lib().cdlrm_scatter_rows(int(dst_ptr), index.data_ptr(), rows.data_ptr(), index.numel(), rows.shape[1],
+                                        1 if average else 0, stream_ptr(stream)))
+
+
+def mark_rows(ctx: CacheCtx, slots: torch.Tensor, touched: torch.Tensor, stream=None):
+    assert slots.dtype == torch.int32 and slots.is_contiguous() and slots.shape[0] == ctx.T
+    check(_lib.lib().cdlrm_mark_rows(ctx.handle, slots.data_ptr(), slots.shape[1], touched.data_ptr(),
+                                     stream_ptr(stream)))
+
+
 def sgd_step(param: torch.Tensor, grad: torch.Tensor, lr: float, stream=None):
     assert param.is_contiguous() and grad.is_contiguous() and param.numel() == grad.numel()
     check(_lib.lib().cdlrm_sgd_step(param.data_ptr(), grad.data_ptr(), param.numel(), float(lr), stream_ptr(stream)))

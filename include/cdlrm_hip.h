@@ -186,9 +186,18 @@ int cdlrm_plan_writeback(cdlrm_ctx* ctx, const cdlrm_plan* plan, float* const* d
 int cdlrm_gather_rows(const float* src, const int64_t* index, int64_t count, int32_t dim,
                       float* out, void* stream);
 
+/* Generic row scatter used by the drop-in Prefetcher.eviction_manager (cache_manager.py:57-62):
+ * dst[index[i], :] = rows[i, :], or (dst + rows) / 2 with average != 0.  dst is device-visible. */
+int cdlrm_scatter_rows(float* dst, const int64_t* index, const float* rows, int64_t count,
+                       int32_t dim, int average, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Table aggregation (broadcast_and_aggregate, main_no_ddp.py:250-292)
  * ------------------------------------------------------------------------------------------- */
+
+/* touched[row_base_t + slots[t, i]] = 1 for slots int32 [T, n]: turns gathered cache_group_idxs
+ * (main_no_ddp.py:254-268) into the touched-row flags cdlrm_agg_compact consumes. */
+int cdlrm_mark_rows(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, uint8_t* touched, void* stream);
 
 /* Compact the touched-row flags into a sorted row list (torch.unique over the gathered
  * cache_group_idxs, :270) and clear them.  rows_out device int64 [cap]; count_out device int64 [1]. */
@@ -234,6 +243,9 @@ int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* los
 
 /* p -= lr * g over a flat fp32 buffer (optim.SGD without momentum, main_no_ddp.py:375, 415). */
 int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float lr, void* stream);
+
+/* x /= divisor (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239, 244). */
+int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream);
 
 #ifdef __cplusplus
 }
