@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/sec of the cached data-parallel DLRM step on Criteo-Terabyte-shaped
+synthetic data (BASELINE.json metric), plus the HBM roofline of the cached EmbeddingBag gather.
+
+    python bench.py --gpus 1 --steps 3000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: tag probe -> cached gather -> bottom MLP -> dot interaction
+-> top MLP -> BCE -> backward -> fused sparse SGD + dense SGD (+ grad all-reduce and periodic cache-row merge at
+N > 1); the wall time of the timed region includes the look-ahead refills (window scan, insert/evict, host row
+prefetch) that fall into it.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[2] (README.md:7): the configuration the metric is quoted on
+    "c3": dict(name="criteo-terabyte-shape synthetic, 26 tables, D=128, B=8192, L=3000, cache 150k x 16-way, agg 100",
+               tables="terabyte", D=128, bot=[13, 512, 256, 128], top=[512, 512, 256, 1], B=8192, L=3000,
+               cache=150000, ways=16, agg=100, lr=0.8, lr_emb=0.8),
+    # BASELINE.json configs[1]
+    "c2": dict(name="criteo-kaggle-shape synthetic, 26 tables, D=32, B=2048, L=200, cache 50k x 8-way",
+               tables="kaggle", D=32, bot=[13, 512, 256, 32], top=[512, 256, 1], B=2048, L=200, cache=50000, ways=8,
+               agg=100, lr=0.1, lr_emb=0.3),
+    # BASELINE.json configs[4]
+    "c5": dict(name="criteo-terabyte-shape synthetic large batch, D=128, B=65536, L=8000, cache 500k x 16-way",
+               tables="terabyte", D=128, bot=[13, 512, 256, 128], top=[512, 512, 256, 1], B=65536, L=8000,
+               cache=500000, ways=16, agg=100, lr=0.8, lr_emb=0.8),
+    # BASELINE.json configs[0] shape on the GPU (plumbing-size)
+    "c1": dict(name="8 tables x 10k rows, D=16, B=128, L=32, cache 2k x 4-way", tables=[10000] * 8, D=16,
+               bot=[13, 64, 16], top=[64, 32, 1], B=128, L=32, cache=2000, ways=4, agg=10, lr=0.1, lr_emb=0.3),
+}
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--alpha", type=float, default=1.05, help="Zipf exponent of the synthetic indices (0 = uniform)")
+    ap.add_argument("--max-ind-range", type=int, default=-1, help="cap rows per table (main_no_ddp.py:64)")
+    ap.add_argument("--lookahead", type=int, default=-1, help="override the config's lookahead window")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-sample", type=int, default=8, help="time the gather kernel every k-th step")
+    ap.add_argument("--seed", type=int, default=123)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, ln_emb_full, seed):
+    """The oracle (CPU restatement of the reference's path, kind "port") timed on this box's host cores, on a
+    bounded sample of the same workload: same B, D, MLPs, ways and table count, tables capped at 200k rows and the
+    cache at 20k sets so the host state is ~2 GB; 1 refill (L=3) + 3 iterations."""
+    from oracle import cdlrm_oracle as O
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    ln_emb = [min(n, 200000) for n in ln_emb_full]
+    B, D, L = cfg["B"], cfg["D"], 3
+    nf = len(ln_emb) + 1
+    ln_top = np.array([D + nf * (nf - 1) // 2] + cfg["top"])
+    rng = np.random.RandomState(seed)
+    host = [torch.from_numpy(rng.uniform(-1, 1, size=(n, D)).astype(np.float32) * np.float32(np.sqrt(1.0 / n)))
+            for n in ln_emb]
+    tr = O.OracleTrainer(ln_emb, D, np.array(cfg["bot"]), ln_top, cache_size=min(cfg["cache"], 20000),
+                         num_ways=cfg["ways"], mini_batch_size=B, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], lookahead=L,
+                         table_agg_freq=10 ** 9, seed=seed, host_tables=host, cache_init="zeros")
+    from cdlrm_amd.synth import CriteoSynth
+    syn = CriteoSynth(ln_emb, cfg["bot"][0], B, seed=seed, alpha=1.05, device="cpu")
+    win = syn.window(0, L)
+    lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+    t0 = time.perf_counter()
+    tr.refill(win)
+    for j in range(L):
+        X, T = syn.dense(j)
+        tr.step(j, X, lS_o, win[:, j * B:(j + 1) * B], T)
+    dt = time.perf_counter() - t0
+    return {"value": L * B / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch-CPU restatement): %d iterations + 1 refill at L=%d, B=%d, D=%d, 26 tables capped "
+                      "at 200k rows, cache %d x %d-way; %.1f s" % (L, L, B, D, min(cfg["cache"], 20000), cfg["ways"], dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    from cdlrm_amd import synth
+    from cdlrm_amd.engine import TrainEngine, WindowPipeline
+    from cdlrm_amd.hostmem import make_host_tables
+    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group
+
+    cfg = dict(CONFIGS[a.config])
+    if a.lookahead > 0:
+        cfg["L"] = a.lookahead
+    tables = cfg["tables"]
+    ln_emb = list(synth.TERABYTE_COUNTS if tables == "terabyte" else synth.KAGGLE_COUNTS if tables == "kaggle" else tables)
+    if a.max_ind_range > 0:
+        ln_emb = [min(n, a.max_ind_range) for n in ln_emb]
+    D, B, L = cfg["D"], cfg["B"], cfg["L"]
+    lbs = math.ceil(B / world)
+    nf = len(ln_emb) + 1
+    ln_bot = np.array(cfg["bot"])
+    ln_top = np.array([D + nf * (nf - 1) // 2] + cfg["top"])
+
+    t_setup = time.perf_counter()
+    np.random.seed(a.seed)
+    torch.manual_seed(a.seed)
+    host = make_host_tables(ln_emb, D, device=dev, seed=a.seed, rank=rank, world=world,
+                            shm_name="cdlrm_bench_%s" % os.environ.get("MASTER_PORT", "0"), barrier=barrier)
+    cg = Embedding_Table_Cache_Group(D, np.array(ln_emb), cfg["cache"], B, cfg["ways"], cache_init="empty").to(dev)
+    np.random.seed(a.seed)
+    dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
+    eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
+                      table_agg_freq=cfg["agg"], table_agg_op="mean")
+    pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world)
+    syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=a.seed, alpha=a.alpha, device=dev)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+
+    total_steps = a.warmup + a.steps
+    state = {"win": None, "next": None, "w": -1}
+    plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
+    ev_pairs = []
+
+    def begin_window(w):
+        if state["next"] is None:           # very first window: plan it synchronously
+            state["next"] = syn.window(w, L)
+            pipe.plan_window(state["next"])
+        pipe.commit()
+        state["win"], state["next"], state["w"] = state["next"], None, w
+        if world > 1:
+            eng.sync_touched_to_rank0()
+
+    def run_step(j, timed):
+        w, jj = divmod(j, L)
+        if jj == 0:
+            begin_window(w)
+        if jj == plan_at or (L == 1):
+            pipe.wait_writeback()
+            state["next"] = syn.window(w + 1, L)
+            pipe.plan_window(state["next"])
+        col = jj * B + rank * lbs
+        idx = state["win"][:, col:col + lbs]
+        X, T = syn.dense(j)
+        X, T = X[rank * lbs:(rank + 1) * lbs], T[rank * lbs:(rank + 1) * lbs]
+        sample = timed and a.gather_sample > 0 and (j % a.gather_sample == 0)
+        eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None)
+
+    for j in range(a.warmup):
+        run_step(j, False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(a.warmup, total_steps):
+        run_step(j, True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    cg.ctx.check()
+    loss = float(eng._bufs[lbs]["loss"][0])
+
+    if rank == 0:
+        gather_ms = [e0.elapsed_time(e1) for e0, e1 in ev_pairs]
+        gather_ms = float(np.mean(gather_ms)) if gather_ms else float("nan")
+        lookups = lbs * len(ln_emb)
+        alg_bytes = lookups * (8 * D + 16)          # fp32 row read + fp32 row write + int64 index + int64 offset
+        achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms == gather_ms and gather_ms > 0 else None
+        out = {
+            "metric": "training samples/sec, Criteo-Terabyte-shape synthetic (cached data-parallel DLRM step, refills included)",
+            "value": B * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "config_id": a.config, "global_batch": B, "local_batch": lbs,
+                       "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
+                       "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1)},
+            "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "bytes_per_launch": alg_bytes, "avg_launch_us": gather_ms * 1e3 if gather_ms == gather_ms else None,
+                         "launches_timed": len(ev_pairs)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, ln_emb, a.seed)
+        print(json.dumps(out))
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

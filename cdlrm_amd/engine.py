@@ -178,8 +178,36 @@ class TrainEngine:
         return self._bufs[key]
 
     # ----------------------------------------------------------------------------------------------
+    def sync_touched_to_rank0(self):
+        """The reference refills rank 0's cache and then broadcasts EVERY cache table from rank 0
+        (main_no_ddp.py:318-319), which also overwrites whatever the other ranks changed since the last
+        table-agg merge.  Same result without moving 10.9 GB: only the rows some rank touched since that merge can
+        differ, so broadcast exactly those (union of the touched flags), leaving the flags set for the next merge."""
+        if self.world == 1:
+            return
+        ctx = self.ctx
+        flags = self.cg.touched.clone()
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
+        if self.agg_rows is None:
+            self._agg_alloc()
+        ops.agg_compact(ctx, flags, self.agg_rows, self.agg_count)
+        self.agg_count_host.copy_(self.agg_count, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        U = int(self.agg_count_host[0])
+        if U == 0:
+            return
+        buf = torch.empty(U, self.D, dtype=torch.float32, device=self.dev)
+        ops.agg_gather(ctx, self.agg_rows, self.agg_count, 1.0, buf, U)
+        dist.broadcast(buf, src=0, group=self.pg)
+        ops.agg_scatter(ctx, self.agg_rows, self.agg_count, buf, U)
+
+    def _agg_alloc(self):
+        self.agg_rows = torch.empty(self.ctx.total_rows, dtype=torch.int64, device=self.dev)
+        self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.agg_count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
-             j: Optional[int] = None):
+             j: Optional[int] = None, gather_events: Optional[list] = None):
         """One training iteration on this rank's slice.  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
         on the device; lS_o None = Criteo layout; j = batch number inside the epoch (table-agg schedule).
         Returns the device loss buffer (element 0 = BCE loss)."""
@@ -191,7 +219,14 @@ class TrainEngine:
         F, D = self.F, self.D
         # ---- forward ----
         slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i)
-        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+        if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on its own stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+            e1.record()
+            gather_events.append((e0, e1))
+        else:
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
         cur = X
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
@@ -262,11 +297,8 @@ class TrainEngine:
             touched.zero_()
             return
         dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=self.pg)
-        total = ctx.total_rows
         if self.agg_rows is None:
-            self.agg_rows = torch.empty(total, dtype=torch.int64, device=self.dev)
-            self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
-            self.agg_count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self._agg_alloc()
         ops.agg_compact(ctx, touched, self.agg_rows, self.agg_count)
         self.agg_count_host.copy_(self.agg_count, non_blocking=True)
         torch.cuda.current_stream().synchronize()

@@ -1,0 +1,69 @@
+"""Host master-table memory for the GPU path: pinned (single process) or shared + registered (one
+process per GPU, all mapping the same /dev/shm file, main_no_ddp.py:621-622 `emb_tables.share_memory()`)."""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .model_no_ddp import Embedding_Table_Group
+
+
+def fill_uniform_from_device(dst: torch.Tensor, n_rows: int, device, seed: int, chunk_rows: int = 1 << 21):
+    """dst[n, m] ~ U(-sqrt(1/n), sqrt(1/n)) (the reference's init distribution, model_no_ddp.py:70-73), drawn on
+    the GPU and copied down in chunks: fast enough for the 96 GB Terabyte-shape tables."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    bound = float(np.sqrt(1.0 / n_rows))
+    m = dst.shape[1]
+    for r0 in range(0, n_rows, chunk_rows):
+        r1 = min(n_rows, r0 + chunk_rows)
+        t = torch.rand(r1 - r0, m, generator=g, device=device, dtype=torch.float32)
+        t.mul_(2 * bound).sub_(bound)
+        dst[r0:r1].copy_(t, non_blocking=False)
+
+
+def make_host_tables(ln_emb: Sequence[int], m_spa: int, *, device, seed: int = 123, rank: int = 0, world: int = 1,
+                     shm_name: str = "cdlrm_host_tables", barrier=None) -> Embedding_Table_Group:
+    """Synthetic host tables for bench / Run on synthetic data."""
+    ln = [int(n) for n in ln_emb]
+    eg = Embedding_Table_Group(m_spa, np.array(ln), init="empty_meta")
+    if world == 1:
+        for k, n in enumerate(ln):
+            w = torch.empty(n, m_spa, dtype=torch.float32, pin_memory=True)
+            fill_uniform_from_device(w, n, device, seed * 1009 + k)
+            eg.emb_l[k].weight.data = w
+        eg._pinned = True
+        return eg
+    total = sum(ln) * m_spa
+    path = os.path.join("/dev/shm", shm_name)
+    if rank == 0:
+        if os.path.exists(path):
+            os.unlink(path)
+        with open(path, "wb") as f:
+            f.truncate(total * 4)
+    barrier()
+    flat = torch.from_file(path, shared=True, size=total, dtype=torch.float32)
+    off = 0
+    for k, n in enumerate(ln):
+        eg.emb_l[k].weight.data = flat[off:off + n * m_spa].view(n, m_spa)
+        off += n * m_spa
+    eg._flat = flat
+    # one registration for the whole mapping
+    from . import _lib
+    import ctypes as C
+    alias = C.c_void_p()
+    _lib.check(_lib.lib().cdlrm_host_register(flat.data_ptr(), total * 4, C.byref(alias)))
+    if alias.value != flat.data_ptr():
+        raise RuntimeError("registered host memory has a different device alias; unsupported")
+    eg._registered.append(flat.data_ptr())
+    eg._pinned = True
+    if rank == 0:
+        for k, n in enumerate(ln):
+            fill_uniform_from_device(eg.emb_l[k].weight.data, n, device, seed * 1009 + k)
+    barrier()
+    if rank == 0:
+        os.unlink(path)          # the mappings keep the memory alive; nothing is left behind in /dev/shm
+    return eg

@@ -40,6 +40,19 @@ def isPrime(n):
 # --------------------------------------------------------------------------------------------------
 
 
+class _HostTable(nn.Module):
+    """emb_l[k] of the host group: `.weight` fp32 [n, m] (the reference keeps an nn.EmbeddingBag here,
+    model_no_ddp.py:67-74); calling it is EmbeddingBag(mode="sum") on the host rows."""
+
+    def __init__(self, n, m, weight):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = n, m
+        self.weight = nn.Parameter(weight, requires_grad=False)
+
+    def forward(self, input, offsets=None):
+        return torch.nn.functional.embedding_bag(input, self.weight, offsets, mode="sum")
+
+
 class Embedding_Table_Group(nn.Module):
     """Full embedding tables in host memory (model_no_ddp.py:21-98).  `emb_l[k].weight` is the fp32
     [n_k, m] master table, initialised U(-sqrt(1/n), sqrt(1/n)) from the numpy global RNG exactly as the
@@ -74,11 +87,11 @@ class Embedding_Table_Group(nn.Module):
                 Wt = torch.from_numpy(W)
             elif init == "empty":
                 Wt = torch.empty(n, m, dtype=torch.float32)
+            elif init == "empty_meta":      # storage is attached by the caller (hostmem.make_host_tables)
+                Wt = torch.empty(0, m, dtype=torch.float32)
             else:
                 raise ValueError(init)
-            EE = nn.EmbeddingBag(n, m, mode="sum", sparse=True, _weight=Wt)
-            EE.weight.requires_grad = False
-            emb_l.append(EE)
+            emb_l.append(_HostTable(n, m, Wt))
         return emb_l
 
     # -- GPU visibility ---------------------------------------------------------------------------
