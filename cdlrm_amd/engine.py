@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import _streams as S
 from . import ops
 from .model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group, _linears
 
@@ -30,7 +31,8 @@ class WindowPipeline:
         self.cg, self.host = cache_group, host_tables
         self.ctx = cache_group.ctx
         self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
-        self.side = torch.cuda.Stream(device=cache_group.weight.device)
+        self.dev = cache_group.weight.device
+        self.side = S.new_stream(self.dev)
         self.parity_rng, self.seed, self.avg = parity_rng, int(seed), average_on_writeback
         self.rank, self.world = rank, world_size
         self.host_ptrs = host_tables.device_pointers()
@@ -43,8 +45,8 @@ class WindowPipeline:
     def plan_window(self, window_idx: torch.Tensor, q_source=None):
         """Launch the plan of one window ([T, n] int64 on device) on the side stream."""
         plan, side = self.plan, self.side
-        side.wait_stream(torch.cuda.current_stream())          # window_idx may have been produced there
-        with torch.cuda.stream(side):
+        side.wait_stream(S.current_stream(self.dev))          # window_idx may have been produced there
+        with S.on_stream(side):
             plan.unique(window_idx, stream=side)
             plan.probe(stream=side)
             if self.parity_rng:
@@ -59,24 +61,25 @@ class WindowPipeline:
             else:
                 plan.assign(None, seed=self.seed * 1000003 + self.window_no, stream=side)
             plan.fetch(self.host_ptrs, False, stream=side)
-            window_idx.record_stream(side)
-            self.planned = torch.cuda.Event()
+            if window_idx.is_cuda:
+                window_idx.record_stream(side)
+            self.planned = S.new_event(self.dev)
             self.planned.record(side)
         self.window_no += 1
 
     def commit(self):
         """At the window boundary: swap the fetched rows in, write the tags, write the evicted rows back."""
-        main = torch.cuda.current_stream()
+        main = S.current_stream(self.dev)
         assert self.planned is not None, "plan_window() first"
         main.wait_event(self.planned)
         self.plan.commit(stream=main)
-        done = torch.cuda.Event()
+        done = S.new_event(self.dev)
         done.record(main)
-        with torch.cuda.stream(self.side):
+        with S.on_stream(self.side):
             self.side.wait_event(done)
             if self.rank == 0:      # evictions come from rank 0's copy only (main_no_ddp.py:208, 312-315)
                 self.plan.writeback(self.host_ptrs, self.avg, stream=self.side)
-            self.written_back = torch.cuda.Event()
+            self.written_back = S.new_event(self.dev)
             self.written_back.record(self.side)
         self.planned = None
 
@@ -119,8 +122,8 @@ class TrainEngine:
         self.ctx.bind_host_tables(host_tables.device_pointers())
         self._bufs = {}
         self.iter = 0
-        self.comm = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
-        self.side = torch.cuda.Stream(device=self.dev)
+        self.comm = S.new_stream(self.dev) if self.world > 1 else None
+        self.side = S.new_stream(self.dev)
         self.agg_rows = None
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
@@ -192,7 +195,7 @@ class TrainEngine:
             self._agg_alloc()
         ops.agg_compact(ctx, flags, self.agg_rows, self.agg_count)
         self.agg_count_host.copy_(self.agg_count, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        S.current_stream(self.dev).synchronize()
         U = int(self.agg_count_host[0])
         if U == 0:
             return
@@ -204,7 +207,7 @@ class TrainEngine:
     def _agg_alloc(self):
         self.agg_rows = torch.empty(self.ctx.total_rows, dtype=torch.int64, device=self.dev)
         self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.agg_count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.agg_count_host = S.pinned(torch.zeros(1, dtype=torch.int64), self.dev)
 
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
              j: Optional[int] = None, gather_events: Optional[list] = None):
@@ -218,15 +221,25 @@ class TrainEngine:
         feat, dfeat, R, dR = buf["feat"], buf["dfeat"], buf["R"], buf["dR"]
         F, D = self.F, self.D
         # ---- forward ----
-        slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i)
-        if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on its own stream
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
-            e1.record()
-            gather_events.append((e0, e1))
-        else:
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+        # embedding path (probe -> aux fill over PCIe -> gather) on the side stream, under the bottom MLP
+        main = S.current_stream(self.dev)
+        side = self.side
+        side.wait_stream(main)
+        with S.on_stream(side):
+            slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side)
+            if gather_events is not None:   # bench.py: HIP events around the roofline kernel, on ITS stream
+                e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
+                e0.record(side)
+                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B, stream=side)
+                e1.record(side)
+                gather_events.append((e0, e1))
+            else:
+                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B, stream=side)
+            gathered = S.new_event(self.dev)
+            gathered.record(side)
+            # the backward's sort of the slot ids needs nothing but the probe result: run it here, under the MLPs
+            emb_work = self._emb_work(n)
+            ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         cur = X
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
@@ -234,6 +247,7 @@ class TrainEngine:
             ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
             bot_acts.append(y)
             cur = y
+        main.wait_event(gathered)
         ops.interact_fwd(feat, self.itself, R)
         cur = R
         top_acts = [R]
@@ -255,12 +269,10 @@ class TrainEngine:
         ops.interact_bwd(feat, dR, self.itself, dfeat)
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
-        main = torch.cuda.current_stream()
         self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            ops.embbag_bwd_sgd(ctx, slots, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, self._emb_work(n),
-                               cg.touched, stream=self.side)
-            slots.record_stream(self.side)
+        with S.on_stream(self.side):
+            ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, emb_work, cg.touched,
+                                 stream=self.side)
         dY = dfeat[:, 0, :]
         for i in reversed(range(len(self.bot))):
             l, act = self.bot[i]
@@ -273,7 +285,7 @@ class TrainEngine:
             gw = self.grad_flat[:self.n_weight]
             ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
             self.comm.wait_stream(main)
-            with torch.cuda.stream(self.comm):
+            with S.on_stream(self.comm):
                 dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
             main.wait_stream(self.comm)
         ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
@@ -301,7 +313,7 @@ class TrainEngine:
             self._agg_alloc()
         ops.agg_compact(ctx, touched, self.agg_rows, self.agg_count)
         self.agg_count_host.copy_(self.agg_count, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        S.current_stream(self.dev).synchronize()
         U = int(self.agg_count_host[0])
         if U == 0:
             return

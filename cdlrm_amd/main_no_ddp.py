@@ -1,0 +1,450 @@
+"""Host-side mirror of the reference's main_no_ddp.py: CLI, cache control plane and trainer loop.
+
+    ProcessArgs                       main_no_ddp.py:34-145    (every flag accepted; the live set is implemented)
+    CacheEmbeddings                   :148-209  set-associative insert/evict of one window (HIP plan/commit)
+    loss_fn_wrap / time_wrap / wait_wrap                       :212-231
+    aggregate_gradients               :234-247  dense weight-grad mean all-reduce (RCCL), biases NOT reduced
+    broadcast_and_aggregate           :250-292  touched-row merge across ranks
+    share_occupancy_tables            :295-306
+    load_caches_and_broadcast         :309-321
+    Run                               :324-502  per-GPU trainer
+
+Launch: one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m cdlrm_amd.main_no_ddp ...`) or a
+single process for --world-size 1.  The reference's mp.spawn + Manager queues are replaced by torchrun + in-process
+threads/streams; tensors never cross a process boundary.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import queue
+import sys
+import threading
+import time
+from timeit import default_timer as timer
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .cache_manager import Prefetcher
+from .model_no_ddp import (CacheSGD, DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group, HipBCELoss, _linears)
+
+
+def ProcessArgs(argv=None):
+    parser = argparse.ArgumentParser(description="Train Deep Learning Recommendation Model (DLRM)")
+    # ---- model ----
+    parser.add_argument("--arch-sparse-feature-size", type=int, default=2)
+    parser.add_argument("--arch-embedding-size", type=str, default="4-3-2")
+    parser.add_argument("--arch-mlp-bot", type=str, default="4-3-2")
+    parser.add_argument("--arch-mlp-top", type=str, default="4-2-1")
+    parser.add_argument("--arch-interaction-op", type=str, default="dot")
+    parser.add_argument("--arch-interaction-itself", action="store_true", default=False)
+    # ---- activation and loss ----
+    parser.add_argument("--activation-function", type=str, default="relu")
+    parser.add_argument("--loss-function", type=str, default="mse")  # or bce or wbce
+    parser.add_argument("--loss-weights", type=str, default="1.0-1.0")
+    parser.add_argument("--loss-threshold", type=float, default=0.0)
+    parser.add_argument("--round-targets", type=bool, default=False)
+    # ---- data ----
+    parser.add_argument("--data-size", type=int, default=1)
+    parser.add_argument("--num-batches", type=int, default=0)
+    parser.add_argument("--data-generation", type=str, default="random")
+    parser.add_argument("--data-trace-file", type=str, default="./input/dist_emb_j.log")
+    parser.add_argument("--data-set", type=str, default="kaggle")
+    parser.add_argument("--raw-data-file", type=str, default="")
+    parser.add_argument("--processed-data-file", type=str, default="")
+    parser.add_argument("--data-randomize", type=str, default="total")
+    parser.add_argument("--data-trace-enable-padding", type=bool, default=False)
+    parser.add_argument("--max-ind-range", type=int, default=-1)
+    parser.add_argument("--data-sub-sample-rate", type=float, default=0.0)
+    parser.add_argument("--num-indices-per-lookup", type=int, default=10)
+    parser.add_argument("--num-indices-per-lookup-fixed", type=bool, default=False)
+    parser.add_argument("--num-workers", type=int, default=0)
+    parser.add_argument("--memory-map", action="store_true", default=False)
+    # ---- embedding table args ----
+    parser.add_argument("--md-flag", action="store_true", default=False)
+    parser.add_argument("--md-threshold", type=int, default=200)
+    parser.add_argument("--md-temperature", type=float, default=0.3)
+    parser.add_argument("--md-round-dims", action="store_true", default=False)
+    parser.add_argument("--qr-flag", action="store_true", default=False)
+    parser.add_argument("--qr-threshold", type=int, default=200)
+    parser.add_argument("--qr-operation", type=str, default="mult")
+    parser.add_argument("--qr-collisions", type=int, default=4)
+    # ---- training ----
+    parser.add_argument("--mini-batch-size", type=int, default=1)
+    parser.add_argument("--nepochs", type=int, default=1)
+    parser.add_argument("--learning-rate", type=float, default=0.1)
+    parser.add_argument("--lr-embeds", type=float, default=0.3)
+    parser.add_argument("--print-precision", type=int, default=5)
+    parser.add_argument("--numpy-rand-seed", type=int, default=123)
+    parser.add_argument("--sync-dense-params", type=bool, default=True)
+    parser.add_argument("--lookahead", type=int, default=2)
+    parser.add_argument("--cache-workers", type=int, default=2)
+    parser.add_argument("--cache-size", type=int, default=10240)
+    parser.add_argument("--num-ways", type=int, default=4)
+    parser.add_argument("--average-on-writeback", action="store_true", default=False)
+    parser.add_argument("--evict-victim-cache", action="store_true", default=False)
+    # ---- debugging and profiling ----
+    parser.add_argument("--print-freq", type=int, default=1)
+    parser.add_argument("--test-freq", type=int, default=-1)
+    parser.add_argument("--test-mini-batch-size", type=int, default=-1)
+    parser.add_argument("--test-num-workers", type=int, default=-1)
+    parser.add_argument("--print-time", action="store_true", default=False)
+    parser.add_argument("--debug-mode", action="store_true", default=False)
+    parser.add_argument("--enable-profiling", action="store_true", default=False)
+    parser.add_argument("--plot-compute-graph", action="store_true", default=False)
+    # ---- store/load model ----
+    parser.add_argument("--save-model", type=str, default="")
+    parser.add_argument("--load-model", type=str, default="")
+    # ---- mlperf ----
+    parser.add_argument("--mlperf-logging", action="store_true", default=False)
+    parser.add_argument("--mlperf-acc-threshold", type=float, default=0.0)
+    parser.add_argument("--mlperf-auc-threshold", type=float, default=0.0)
+    parser.add_argument("--mlperf-bin-loader", action="store_true", default=False)
+    parser.add_argument("--mlperf-bin-shuffle", action="store_true", default=False)
+    parser.add_argument("--large-batch", action="store_true", default=False)
+    # ---- distributed training ----
+    parser.add_argument("--world-size", type=int, default=2)
+    parser.add_argument("--master-port", type=int, default=12345)
+    parser.add_argument("--trainer-start-core", type=int, default=7)
+    parser.add_argument("--main-start-core", type=int, default=0)
+    parser.add_argument("--dense-threshold", type=int, default=1000)
+    parser.add_argument("--table-agg-op", type=str, default="mean")
+    parser.add_argument("--table-agg-freq", type=int, default=1)
+    parser.add_argument("--batch-fifo-size", type=int, default=8)
+    parser.add_argument("--eviction-fifo-size", type=int, default=8)
+    parser.add_argument("--eviction-fifo-timeout", type=int, default=300)
+    # ---- misc ----
+    parser.add_argument("--inference-only", action="store_true", default=False)
+    parser.add_argument("--save-onnx", action="store_true", default=False)
+    parser.add_argument("--use-gpu", action="store_true", default=False)
+    # ---- this build (not in the reference) ----
+    parser.add_argument("--synthetic-alpha", type=float, default=1.05,
+                        help="Zipf exponent of --data-generation=criteo-synthetic indices (0 = uniform)")
+    parser.add_argument("--device-rng", action="store_true", default=False,
+                        help="way choice by counter-based Philox on the GPU (perf mode; not bit-comparable with the "
+                             "reference's torch-CPU Categorical draw)")
+    return parser.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------------
+# cache control plane
+# --------------------------------------------------------------------------------------------------
+
+
+def _compat_plan(cache_group: Embedding_Table_Cache_Group, n_uniq: int) -> ops.WindowPlan:
+    plan = getattr(cache_group, "_compat_plan", None)
+    if plan is None or plan.cap_uniq < n_uniq or plan.ctx is not cache_group.ctx:
+        cap = max(1024, int(n_uniq * 1.25))
+        plan = ops.WindowPlan(cache_group.ctx, cap, cap_uniq=cap, cap_win=min(cap, cache_group.ctx.total_tags) + 16)
+        cache_group._compat_plan = plan
+    return plan
+
+
+@torch.no_grad()
+def CacheEmbeddings(cached_entries_per_table, lists_of_unique_idxs, unique_indices_maps, cache_group, eviction_fifo, rank):
+    """main_no_ddp.py:148-209 with the reference's signature.  Tag probe of the window's unique ids, full-set
+    filter, way choice (the Exp(1) draw comes from the torch CPU generator, table by table, exactly like
+    Categorical.sample()), contested-slot resolution, eviction gather, tag + row update -- all on the GPU."""
+    dev = cache_group.weight.device
+    T = len(cached_entries_per_table)
+    plan = _compat_plan(cache_group, sum(int(u.numel()) for u in lists_of_unique_idxs))
+    plan.set_unique(lists_of_unique_idxs)
+    plan.probe()
+    uo, ko, _ = plan.offsets()
+    ways = cache_group.num_ways
+    qs = []
+    for k in range(T):
+        M = ko[k + 1] - ko[k]
+        qs.append(torch.empty(M, ways).exponential_(1) if M > 0 else torch.empty(0, ways))
+    q = torch.cat(qs).contiguous().to(dev) if ko[T] > 0 else torch.empty(1, ways, device=dev)
+    plan.assign(q)
+    rows = [r.to(dev, torch.float32).contiguous() for r in cached_entries_per_table]
+    plan.fetch([r.data_ptr() if r.numel() else cache_group.weight.data_ptr() for r in rows], True)
+    plan.commit()
+    _, _, wo = plan.offsets()
+    cache_group.ctx.check()
+    eviction_data = []
+    for k in range(T):
+        tag = plan.ev_tag[wo[k]:wo[k + 1]]
+        valid = tag != -1
+        eviction_data.append((tag[valid].clone(), plan.stage[wo[k]:wo[k + 1]][valid].clone()))
+    if rank == 0:
+        eviction_fifo.put(eviction_data)
+
+
+def loss_fn_wrap(Z, T, loss_fn, args, loss_ws=None):
+    if args.loss_function == "mse" or args.loss_function == "bce":
+        return loss_fn(Z, T)
+    elif args.loss_function == "wbce":
+        loss_ws_ = loss_ws[T.data.view(-1).long()].view_as(T)
+        loss_fn_ = loss_fn(Z, T)
+    loss_sc_ = loss_ws_ * loss_fn_
+    return loss_sc_.mean()
+
+
+def time_wrap(rank):
+    torch.cuda.synchronize(rank)
+    return time.time()
+
+
+def wait_wrap(req_objs):
+    for obj in req_objs:
+        obj.wait()
+
+
+def aggregate_gradients(dlrm):
+    """main_no_ddp.py:234-247: every Linear's weight.grad /= world, async all-reduce SUM; bias grads are not
+    reduced (reference behaviour, kept)."""
+    request_objs_mlp = []
+    for seq in (dlrm.bot_l, dlrm.top_l):
+        for layer in seq:
+            if isinstance(layer, nn.modules.linear.Linear):
+                ops.scale_div(layer.weight.grad, float(dist.get_world_size()))
+                request_objs_mlp.append(dist.all_reduce(layer.weight.grad, async_op=True))
+    return request_objs_mlp
+
+
+@torch.no_grad()
+def broadcast_and_aggregate(cache_group, cache_group_idxs, rank, reduce_op="mean"):
+    """main_no_ddp.py:250-292.  cache_group_idxs: int32 [T, m] slot ids this rank looked up since the last merge.
+    The union over ranks (the reference all-gathers the lists and calls torch.unique per table) is the union of
+    touched-row flags; the rows travel as one compacted [U, D] buffer instead of T separate all-reduces."""
+    ctx = cache_group.ctx
+    dev = cache_group.weight.device
+    W = dist.get_world_size()
+    flags = torch.zeros(ctx.total_rows, dtype=torch.uint8, device=dev)
+    ops.mark_rows(ctx, cache_group_idxs.to(dev, torch.int32).contiguous(), flags)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    rows = torch.empty(ctx.total_rows, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.agg_compact(ctx, flags, rows, count)
+    U = int(count.item())
+    if U == 0:
+        return
+    buf = torch.empty(U, ctx.D, dtype=torch.float32, device=dev)
+    if reduce_op == "sum":
+        ops.agg_gather(ctx, rows, count, 1.0, buf, U)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    elif reduce_op == "mean":
+        ops.agg_gather(ctx, rows, count, float(W), buf, U)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    elif reduce_op == "max":
+        ops.agg_gather(ctx, rows, count, 1.0, buf, U)
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+    ops.agg_scatter(ctx, rows, count, buf, U)
+
+
+def share_occupancy_tables(cache_group, occupancy_tables_fifos, rank):
+    """main_no_ddp.py:295-306.  The reference shares ONE CPU tag table between the ranks; here every GPU keeps its
+    own replica in HBM and all replicas evolve identically (same window payload, same way draws), so there is
+    nothing to hand over -- the function only checks that the replicas start out equal."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        chk = cache_group.tags.to(torch.float64).sum().view(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo) == float(hi), "cache tag replicas differ between ranks"
+
+
+@torch.no_grad()
+def load_caches_and_broadcast(cache_group, batch_fifo, eviction_fifo, rank):
+    """main_no_ddp.py:309-321.  Reference: rank 0 inserts, then EVERY cache table is broadcast from rank 0
+    (10.9 GB at the README config).  Here every rank performs the same deterministic insert from the same window
+    payload (each rank's Prefetcher produces it), after first taking rank 0's copy of the rows that can differ
+    between ranks (those touched since the last merge) -- the same end state without the whole-cache broadcast.
+    Rank 0's draw of the way choice is shared so the replicas stay identical."""
+    cached_entries_per_table, lists_of_unique_idxs, unique_indices_maps = batch_fifo.get()
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if multi:
+        # ranks other than 0 must consume the same Exp(1) stream as rank 0: share its generator state
+        state = torch.get_rng_state().to(cache_group.weight.device)
+        dist.broadcast(state, src=0)
+        torch.set_rng_state(state.cpu())
+    CacheEmbeddings(cached_entries_per_table, lists_of_unique_idxs, unique_indices_maps, cache_group, eviction_fifo, rank)
+    return []
+
+
+# --------------------------------------------------------------------------------------------------
+# trainer
+# --------------------------------------------------------------------------------------------------
+
+
+def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, eviction_fifo, occupancy_tables_fifos,
+        emb_tables, args):
+    """main_no_ddp.py:324-502 on the fused engine.  One process per GPU; `rank` is the device index and the
+    distributed rank.  train_ld yields (X, lS_o, lS_i, T) global batches; every rank takes its slice."""
+    from .engine import TrainEngine, WindowPipeline
+    try:
+        from setproctitle import setproctitle
+        setproctitle("DlrmTrainer:" + str(rank))
+    except ImportError:
+        pass
+    np.random.seed(args.numpy_rand_seed)
+    torch.cuda.manual_seed(args.numpy_rand_seed)
+    torch.manual_seed(args.numpy_rand_seed)
+    np.set_printoptions(precision=args.print_precision)
+    torch.set_printoptions(precision=args.print_precision)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    world = args.world_size
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    local_batch_size = math.ceil(args.mini_batch_size / world)
+
+    cache_group = Embedding_Table_Cache_Group(m_spa, ln_emb, max_cache_size=args.cache_size,
+                                              aux_table_size=args.mini_batch_size, num_ways=args.num_ways).to(dev)
+    dlrm = DLRM_Net(ln_bot, ln_top, arch_interaction_op=args.arch_interaction_op,
+                    arch_interaction_itself=args.arch_interaction_itself, sync_dense_params=args.sync_dense_params,
+                    sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_threshold=args.loss_threshold).to(dev)
+    share_occupancy_tables(cache_group, occupancy_tables_fifos, rank)
+    if args.loss_function != "bce":
+        raise NotImplementedError("the fused engine implements --loss-function=bce (the north-star metric); "
+                                  "mse / wbce run through the autograd surface (model_no_ddp.DLRM_Net)")
+    emb_tables.pin() if not getattr(emb_tables, "_pinned", False) else None
+    eng = TrainEngine(cache_group, dlrm, emb_tables, lr=args.learning_rate, lr_embeds=args.lr_embeds, world_size=world,
+                      rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op)
+    L = args.lookahead
+    pipe = WindowPipeline(cache_group, emb_tables, L * args.mini_batch_size * 2, parity_rng=not args.device_rng,
+                          seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
+                          world_size=world)
+
+    total_time = total_iter = total_samp = 0
+    total_loss = total_accu = 0.0
+    caching_overhead = []
+    for epoch in range(args.nepochs):
+        it = iter(train_ld)
+        window = []
+        j = 0
+        while True:
+            if not window:
+                # look-ahead: read the next L batches, plan their insert while nothing else is pending
+                for _ in range(L):
+                    try:
+                        window.append(next(it))
+                    except StopIteration:
+                        break
+                if not window:
+                    break
+                start = timer()
+                win_idx = torch.cat([torch.as_tensor(b[2]) if not isinstance(b[2], (list, tuple)) else
+                                     torch.stack([torch.as_tensor(s).reshape(-1) for s in b[2]]) for b in window], dim=1)
+                if world > 1:
+                    eng.sync_touched_to_rank0()
+                pipe.plan_window(win_idx.to(dev))
+                pipe.commit()
+                pipe.wait_writeback()
+                caching_overhead.append(timer() - start)
+            X, lS_o, lS_i, T = window.pop(0)
+            lS_i = torch.as_tensor(lS_i) if not isinstance(lS_i, (list, tuple)) else torch.stack(
+                [torch.as_tensor(s).reshape(-1) for s in lS_i])
+            sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
+            Xr = X[sl, :].to(dev)
+            Ir = lS_i[:, sl].to(dev)
+            Tr = T[sl, :].to(dev)
+            t1 = time_wrap(rank)
+            lossbuf = eng.step(Xr, Ir, Tr, j=j)
+            t2 = time_wrap(rank)
+            mbs = Tr.shape[0]
+            Z = eng._bufs[Xr.shape[0]]["top_y"][-1]
+            stats = torch.stack([lossbuf[0] * mbs, (torch.round(Z) == Tr).sum().to(torch.float32),
+                                 torch.tensor(float(mbs), device=dev)])
+            if world > 1:
+                dist.all_reduce(stats)
+            total_time += t2 - t1
+            total_iter += 1
+            if rank == 0:
+                s = stats.tolist()
+                total_loss += s[0] / world
+                total_accu += s[1] / world
+                total_samp += mbs
+                if j > 0 and j % args.print_freq == 0:
+                    gT = 1000.0 * total_time / total_iter
+                    gA = total_accu / total_samp
+                    gL = total_loss / total_samp
+                    avg_caching_overhead = np.mean(caching_overhead) / args.lookahead if caching_overhead else 0.0
+                    print('Epoch {}: Finished {}/{} in {} ms/it. Caching overhead = {}. Loss = {}, Train Acc = {}'.format(
+                        epoch, j, len(train_ld), gT, 1000 * avg_caching_overhead, gL, gA), flush=True)
+                    total_time = total_iter = total_samp = 0
+                    total_loss = total_accu = 0.0
+                    caching_overhead = []
+            j += 1
+    torch.cuda.synchronize()
+    return eng
+
+
+class _SyntheticLoader:
+    """Criteo-layout synthetic loader (X, lS_o, lS_i, T) on the host side of the reference's loop."""
+
+    def __init__(self, syn, num_batches, B):
+        self.syn, self.n, self.B = syn, num_batches, B
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        T = len(self.syn.ln_emb)
+        lS_o = torch.arange(self.B).repeat(T, 1)
+        for j in range(self.n):
+            idx = self.syn.window(j, 1)
+            X, Tt = self.syn.dense(j)
+            yield X, lS_o, idx, Tt
+
+
+def main(argv=None):
+    args = ProcessArgs(argv)
+    np.random.seed(args.numpy_rand_seed)
+    torch.manual_seed(args.numpy_rand_seed)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if "WORLD_SIZE" in os.environ:
+        args.world_size = int(os.environ["WORLD_SIZE"])
+    ln_bot = np.fromstring(args.arch_mlp_bot, dtype=int, sep="-")
+    if args.data_generation not in ("random", "criteo-synthetic"):
+        sys.exit("ERROR: --data-generation=%s needs the Criteo files; this build generates Criteo-shaped synthetic "
+                 "data (--data-generation=criteo-synthetic)" % args.data_generation)
+    ln_emb = np.fromstring(args.arch_embedding_size, dtype=int, sep="-")
+    if args.max_ind_range > 0:
+        ln_emb = np.minimum(ln_emb, args.max_ind_range)
+    m_den = ln_bot[0]
+    m_spa = args.arch_sparse_feature_size
+    num_fea = ln_emb.size + 1
+    m_den_out = ln_bot[ln_bot.size - 1]
+    if args.arch_interaction_op == "dot":
+        num_int = (num_fea * (num_fea + 1)) // 2 + m_den_out if args.arch_interaction_itself else \
+            (num_fea * (num_fea - 1)) // 2 + m_den_out
+    elif args.arch_interaction_op == "cat":
+        num_int = num_fea * m_den_out
+    else:
+        sys.exit("ERROR: --arch-interaction-op=" + args.arch_interaction_op + " is not supported")
+    ln_top = np.fromstring(str(num_int) + "-" + args.arch_mlp_top, dtype=int, sep="-")
+    if m_spa != m_den_out:
+        sys.exit("ERROR: arch-sparse-feature-size " + str(m_spa) + " does not match last dim of bottom mlp " + str(m_den_out))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if args.world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        dist.init_process_group("nccl", rank=rank, world_size=args.world_size)
+    from . import synth
+    from .hostmem import make_host_tables
+    emb_tables = make_host_tables(ln_emb, m_spa, device=dev, seed=args.numpy_rand_seed, rank=rank, world=args.world_size,
+                                  shm_name="cdlrm_run_%d" % args.master_port,
+                                  barrier=(dist.barrier if args.world_size > 1 else (lambda: None)))
+    nb = args.num_batches if args.num_batches > 0 else max(1, args.data_size // args.mini_batch_size)
+    syn = synth.CriteoSynth(ln_emb, int(m_den), args.mini_batch_size, seed=args.numpy_rand_seed,
+                            alpha=args.synthetic_alpha, device="cpu")
+    train_ld = _SyntheticLoader(syn, nb, args.mini_batch_size)
+    Run(local_rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, None, None, None, None, emb_tables, args)
+    if args.world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

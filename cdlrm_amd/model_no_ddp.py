@@ -280,9 +280,7 @@ class Embedding_Table_Cache_Group(nn.Module):
     @property
     def ctx(self) -> ops.CacheCtx:
         if self._ctx is None:
-            if not self.weight.is_cuda:
-                raise RuntimeError("Embedding_Table_Cache_Group must be moved to the MI355X first (.to(rank)); "
-                                   "cdlrm_amd has no CPU path")
+            # ops.CacheCtx refuses any non-HIP device: the module must be moved to the MI355X first (.to(rank))
             self._ctx = ops.CacheCtx([int(n) for n in self.ln_emb], self.cache_sizes, self.m_spa, self.num_ways,
                                      self.aux_table_size, self.weight.device)
             self._ctx.bind_cache(self.tags, self.weight.data)

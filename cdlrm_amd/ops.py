@@ -118,6 +118,19 @@ def embbag_bwd_sgd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.T
                                           ld_table, float(lr), work.data_ptr(), ptr(touched), stream_ptr(stream)))
 
 
+def embbag_bwd_prepare(ctx: CacheCtx, slots: torch.Tensor, work: torch.Tensor, stream=None):
+    check(_lib.lib().cdlrm_embbag_bwd_prepare(ctx.handle, slots.data_ptr(), slots.shape[1], work.data_ptr(),
+                                              stream_ptr(stream)))
+
+
+def embbag_bwd_apply(ctx: CacheCtx, n: int, offsets: Optional[torch.Tensor], grad: torch.Tensor, ld_bag: int,
+                     ld_table: int, lr: float, work: torch.Tensor, touched: Optional[torch.Tensor] = None, stream=None):
+    nb = n if offsets is None else offsets.shape[1]
+    check(_lib.lib().cdlrm_embbag_bwd_apply(ctx.handle, ptr(offsets), n, nb, 0 if offsets is None else offsets.stride(0),
+                                            grad.data_ptr(), ld_bag, ld_table, float(lr), work.data_ptr(), ptr(touched),
+                                            stream_ptr(stream)))
+
+
 # ---- look-ahead window plan -------------------------------------------------------------------------
 
 class WindowPlan:

@@ -1,0 +1,169 @@
+"""CPU-only tests of the host side: the reference-shaped surface (names, geometry, init, CLI, window
+grouping), the C-ABI library's symbol table, and that the product path refuses to run without the HIP
+library / device instead of falling back to anything."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    from cdlrm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    """include/cdlrm_hip.h is the boundary: every function it declares must be exported by the .so and bound in
+    cdlrm_amd/_lib.py (no compute call is made here: there is no GPU)."""
+    from cdlrm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "cdlrm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cdlrm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(built_lib, name), "libcdlrm_hip.so does not export " + name
+        assert name in _lib.PROTOTYPES, "cdlrm_amd/_lib.py does not bind " + name
+    assert set(_lib.PROTOTYPES) <= declared, set(_lib.PROTOTYPES) - declared
+    assert built_lib.cdlrm_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    from cdlrm_amd import ops
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Cache_Group, Embedding_Table_Group
+    with pytest.raises(RuntimeError):
+        ops.CacheCtx([100], [10], 8, 2, 4, torch.device("cpu"))
+    np.random.seed(0)
+    cg = Embedding_Table_Cache_Group(8, np.array([100, 7]), 10, 4, 2, cache_init="zeros")
+    eg = Embedding_Table_Group(8, np.array([100, 7]))
+    with pytest.raises(RuntimeError):
+        cg(torch.arange(4).repeat(2, 1), torch.zeros(2, 4, dtype=torch.int64), eg, "cpu")
+    if not torch.cuda.is_available():
+        from cdlrm_amd.cache_manager import Prefetcher
+        with pytest.raises(RuntimeError):
+            Prefetcher.process_batch_slice(torch.zeros(2, 4, dtype=torch.int64), eg)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from cdlrm_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CdlrmLibraryError):
+        _lib.lib()
+
+
+def test_isprime_and_geometry(golden):
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Cache_Group, isPrime
+    g = golden("isprime")
+    assert np.array_equal(np.array([isPrime(n) for n in range(1, 5000)], dtype=np.uint8), g["isprime_1_4999"])
+    cg = Embedding_Table_Cache_Group(4, np.array([3000, 50, 7, 1200]), 40, 16, 4, cache_init="zeros")
+    for c, p in zip(g["next_prime_in"], g["next_prime_out"]):
+        assert cg.find_next_prime(int(c)) == int(p)
+    gw = golden("cache_windows_small")
+    assert cg.max_cache_size == int(gw["P"]) and cg.cache_sizes == [int(x) for x in gw["cache_sizes"]]
+    occ = cg.occupancy_tables
+    for k, P in enumerate(cg.cache_sizes):
+        assert tuple(occ[k].shape) == (P, 4) and occ[k].dtype == torch.int64 and int((occ[k] != -1).sum()) == 0
+        assert tuple(cg.emb_l[k].weight.shape) == (4 * P + 16, 4)
+    assert torch.equal(cg.compute_set_indices(0, torch.tensor([0, 41, 82, 100])), torch.tensor([0, 0, 0, 100 % 41]))
+
+
+def test_init_matches_reference(golden):
+    """numpy-seeded init of host tables and MLPs (model_no_ddp.py:70-73, 255-261) and the cache rows' default
+    N(0,1) init from the torch CPU generator (:138)."""
+    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group, _linears
+    g = golden("init")
+    seed = int(g["seed"])
+    ln_emb, m_spa = g["ln_emb"], int(g["m_spa"])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    eg = Embedding_Table_Group(m_spa, ln_emb)
+    for k in range(len(ln_emb)):
+        assert torch.equal(eg.emb_l[k].weight.data[:4], t(g[f"host_head_{k}"]))
+        assert float(eg.emb_l[k].weight.data.double().sum()) == float(g[f"host_sum_{k}"])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    cg = Embedding_Table_Cache_Group(m_spa, ln_emb, 100, 32, 4)
+    dl = DLRM_Net(g["ln_bot"], g["ln_top"], "dot", False, True, -1, len(g["ln_top"]) - 2, 0.0)
+    for k in range(len(ln_emb)):
+        assert list(cg.emb_l[k].weight.shape) == list(g[f"cache_shape_{k}"])
+        assert torch.equal(cg.emb_l[k].weight[:4], t(g[f"cache_head_{k}"]))
+    for i, l in enumerate(_linears(dl.bot_l)):
+        assert torch.equal(l.weight.data, t(g[f"bot_w{i}"])) and torch.equal(l.bias.data, t(g[f"bot_b{i}"]))
+    for i, l in enumerate(_linears(dl.top_l)):
+        assert torch.equal(l.weight.data, t(g[f"top_w{i}"])) and torch.equal(l.bias.data, t(g[f"top_b{i}"]))
+    assert isinstance(dl.top_l[-1], torch.nn.Sigmoid) and isinstance(dl.bot_l[-1], torch.nn.ReLU)
+
+
+def test_window_grouping_matches_reference(golden):
+    """The order in which Prefetcher.run groups loader batches into FIFO entries (cache_manager.py:85-110),
+    captured by running the reference's Prefetcher on a fake loader."""
+    import types
+    from cdlrm_amd.cache_manager import Prefetcher, window_groups
+    g = golden("window_groups")
+    ci = 0
+    while f"case{ci}_cfg" in g.files:
+        nb, L, cw = [int(x) for x in g[f"case{ci}_cfg"]]
+        want = [[int(x) for x in row if x >= 0] for row in g[f"case{ci}_groups"]]
+        assert window_groups(nb, L, cw) == want
+        B = 4
+        ld = [(None, None, torch.stack([torch.arange(j * B, (j + 1) * B), torch.arange(j * B, (j + 1) * B) % 7]), None)
+              for j in range(nb)]
+        args = types.SimpleNamespace(lookahead=L, cache_workers=cw, nepochs=1)
+        pf = Prefetcher(args, None, None, None, None, ld)
+        got = [sorted(set((s[0] // B).tolist())) for s in pf.window_slices()]
+        assert got == want
+        ci += 1
+
+
+def test_process_args_accepts_reference_cli():
+    from cdlrm_amd.main_no_ddp import ProcessArgs
+    a = ProcessArgs([])
+    assert (a.lookahead, a.cache_workers, a.cache_size, a.num_ways, a.world_size, a.table_agg_freq) == (2, 2, 10240, 4, 2, 1)
+    assert a.loss_function == "mse" and a.numpy_rand_seed == 123 and a.lr_embeds == 0.3
+    readme = ("--arch-sparse-feature-size=128 --arch-mlp-bot=13-512-256-128 --arch-mlp-top=512-512-256-1 "
+              "--data-generation=dataset --data-set=terabyte --loss-function=bce --round-targets=True "
+              "--learning-rate=0.8 --lr-embeds=0.8 --mini-batch-size=8192 --print-freq=1024 --test-freq=20000 "
+              "--lookahead=3000 --cache-size=150000 --num-ways=16 --table-agg-freq=100 --batch-fifo-size=8 "
+              "--cache-workers=4 --world-size=8 --data-sub-sample-rate=0.875 --large-batch --memory-map "
+              "--master-port=29500 --average-on-writeback --mlperf-bin-loader").split()
+    a = ProcessArgs(readme)
+    assert a.lookahead == 3000 and a.cache_size == 150000 and a.num_ways == 16 and a.world_size == 8
+    assert a.round_targets is True and a.average_on_writeback and a.large_batch
+
+
+def test_unique_index_map():
+    from cdlrm_amd.cache_manager import UniqueIndexMap
+    u = torch.tensor([1, 3, 6, 8, 11, 13])
+    m = UniqueIndexMap(u)
+    assert list(m.shape) == [14, 1]
+    assert m[torch.tensor([6, 1, 13, 2])].flatten().tolist() == [2, 0, 5, -1]
+
+
+def test_synthetic_is_counter_based():
+    from cdlrm_amd.synth import CriteoSynth, KAGGLE_COUNTS, TERABYTE_COUNTS
+    assert len(KAGGLE_COUNTS) == 26 and len(TERABYTE_COUNTS) == 26 and sum(TERABYTE_COUNTS) == 187767399
+    s1 = CriteoSynth([1000, 7, 50000], 13, 16, seed=5, device="cpu")
+    s2 = CriteoSynth([1000, 7, 50000], 13, 16, seed=5, device="cpu")
+    w = s1.window(3, 4)
+    assert torch.equal(w, s2.window(3, 4)) and w.shape == (3, 64) and w.dtype == torch.int64
+    assert not torch.equal(w, s1.window(4, 4))
+    for k, n in enumerate([1000, 7, 50000]):
+        assert int(w[k].min()) >= 0 and int(w[k].max()) < n
+    X, T = s1.dense(0)
+    assert X.shape == (16, 13) and set(T.unique().tolist()) <= {0.0, 1.0}
+    # skew: the hottest id of the big table covers far more than 1/n of the lookups
+    big = CriteoSynth([50000], 13, 4096, seed=1, alpha=1.05, device="cpu").window(0, 4)[0]
+    assert torch.bincount(big).max().item() > 50 * big.numel() / 50000

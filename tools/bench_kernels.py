@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmarks on the MI355X (c3 shapes by default): time with HIP events over many
+launches, report GB/s against algorithmic bytes or TFLOP/s.  Development aid; bench.py is the contract."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdlrm_amd import ops, synth  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, reps=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=8192)
+    ap.add_argument("--D", type=int, default=128)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--alpha", type=float, default=1.05)
+    a = ap.parse_args()
+    B, D = a.B, a.D
+    only = set(a.only.split(",")) if a.only else None
+    want = lambda n: only is None or n in only
+
+    if want("emb"):
+        ln_emb = synth.TERABYTE_COUNTS
+        T = len(ln_emb)
+        P = 150001
+        cs = [min(n, P) for n in ln_emb]
+        ctx = ops.CacheCtx(ln_emb, cs, D, 16, B, DEV)
+        tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+        weight = torch.randn(ctx.total_rows, D, device=DEV)
+        ctx.bind_cache(tags, weight)
+        hostbuf = torch.zeros(64, D).pin_memory()
+        ctx.bind_host_tables([hostbuf.data_ptr()] * T)
+        # resident tags: fill every set/way with an id that maps to it, so the probe hits
+        for k in range(T):
+            Pk = cs[k]
+            ids = torch.arange(Pk * 16, device=DEV) % ln_emb[k]
+            sets = ids % Pk
+            # way-major fill: way w of set s holds s + w*Pk when that id exists
+            w = torch.arange(16, device=DEV).view(1, 16)
+            s = torch.arange(Pk, device=DEV).view(Pk, 1)
+            cand = s + w * Pk
+            cand = torch.where(cand < ln_emb[k], cand, torch.full_like(cand, -1))
+            tags[ctx.tag_base[k]:ctx.tag_base[k + 1]] = cand.reshape(-1)
+        syn = synth.CriteoSynth(ln_emb, 13, B, alpha=a.alpha, device=DEV)
+        idx = syn.window(0, 1)
+        for k in range(T):      # restrict to resident ids
+            idx[k] %= min(ln_emb[k], cs[k] * 16)
+        slots, mp, mc = ops.embbag_probe(ctx, idx)
+        torch.cuda.synchronize()
+        print("misses:", int(mc.sum()), " distinct slots/lookups: %.3f" % (
+            sum(int(torch.unique(slots[k]).numel()) for k in range(T)) / (T * B)))
+        feat = torch.empty(B, T + 1, D, device=DEV)
+        grad = torch.randn(B, T + 1, D, device=DEV)
+        work = ops.embbag_bwd_work(ctx, B, DEV)
+        touched = torch.zeros(ctx.total_rows, dtype=torch.uint8, device=DEV)
+        look = B * T
+        us = timeit(lambda: ops.embbag_probe(ctx, idx))
+        print("probe+resolve+fill   %8.1f us   %7.1f GB/s (idx 8B + tags 128B per lookup)" % (us, look * 136 / us / 1e3))
+        us = timeit(lambda: ops.embbag_fwd(ctx, slots, None, feat[:, 1:, :], (T + 1) * D, D))
+        print("embbag_fwd (gather)  %8.1f us   %7.1f GB/s algorithmic (8D+16 B/lookup) = %.1f%% of 8 TB/s" % (
+            us, look * (8 * D + 16) / us / 1e3, look * (8 * D + 16) / us / 1e3 / 80))
+        us = timeit(lambda: ops.embbag_bwd_sgd(ctx, slots, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched))
+        print("embbag_bwd_sgd       %8.1f us   %7.1f GB/s algorithmic (12D+8 B/lookup)" % (us, look * (12 * D + 8) / us / 1e3))
+
+    if want("interact"):
+        F = 27
+        feat = torch.randn(B, F, D, device=DEV)
+        npairs = F * (F - 1) // 2
+        R = torch.empty(B, D + npairs, device=DEV)
+        dR = torch.randn(B, D + npairs, device=DEV)
+        dfeat = torch.empty_like(feat)
+        us = timeit(lambda: ops.interact_fwd(feat, False, R))
+        byt = B * (F * D * 4 + (D + npairs) * 4)
+        print("interact_fwd         %8.1f us   %7.1f GB/s   %6.1f TFLOP/s" % (us, byt / us / 1e3, 2 * B * 32 * 32 * D / us / 1e6))
+        us = timeit(lambda: ops.interact_bwd(feat, dR, False, dfeat))
+        byt = B * (2 * F * D * 4 + (D + npairs) * 4)
+        print("interact_bwd         %8.1f us   %7.1f GB/s" % (us, byt / us / 1e3))
+
+    if want("gemm"):
+        layers = [(13, 512, 1), (512, 256, 1), (256, 128, 1), (D + 351, 512, 1), (512, 512, 1), (512, 256, 1), (256, 1, 2)]
+        tot_f = tot_b = 0.0
+        for K, N, act in layers:
+            X = torch.randn(B, K, device=DEV)
+            W = torch.randn(N, K, device=DEV) / np.sqrt(K)
+            b = torch.randn(N, device=DEV)
+            Y = torch.empty(B, N, device=DEV)
+            dY = torch.randn(B, N, device=DEV)
+            dX, dW, db = torch.empty(B, K, device=DEV), torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+            work = ops.linear_bwd_work(B, N, K, DEV)
+            fl = 2.0 * B * N * K
+            uf = timeit(lambda: ops.linear_fwd(X, W, b, Y, act))
+            ub = timeit(lambda: ops.linear_bwd(X, W, Y, dY, dX, dW, db, act, work))
+            tot_f += uf
+            tot_b += ub
+            print("linear %4d->%4d  fwd %7.1f us %6.1f TF   bwd %7.1f us %6.1f TF" % (K, N, uf, fl / uf / 1e6, ub, 2 * fl / ub / 1e6))
+        print("MLP total fwd %.1f us  bwd %.1f us" % (tot_f, tot_b))
+
+
+if __name__ == "__main__":
+    main()
