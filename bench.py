@@ -64,12 +64,13 @@ def parse():
 def cpu_baseline(cfg, ln_emb_full, seed):
     """The oracle (CPU restatement of the reference's path, kind "port") timed on this box's host cores, on a
     bounded sample of the same workload: same B, D, MLPs, ways and table count, tables capped at 200k rows and the
-    cache at 20k sets so the host state is ~2 GB; 1 refill (L=3) + 3 iterations."""
+    cache at 20k sets so the host state is ~2 GB; 1 refill + L iterations (L sized for 10-30 s of CPU work)."""
     from oracle import cdlrm_oracle as O
     threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     ln_emb = [min(n, 200000) for n in ln_emb_full]
-    B, D, L = cfg["B"], cfg["D"], 3
+    B, D = cfg["B"], cfg["D"]
+    L = max(2, min(48, (48 * 8192) // B))
     nf = len(ln_emb) + 1
     ln_top = np.array([D + nf * (nf - 1) // 2] + cfg["top"])
     rng = np.random.RandomState(seed)
@@ -197,6 +198,14 @@ def main():
         lookups = lbs * len(ln_emb)
         alg_bytes = lookups * (8 * D + 16)          # fp32 row read + fp32 row write + int64 index + int64 offset
         achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms == gather_ms and gather_ms > 0 else None
+        # HBM traffic of the gather kernel comes from separate rocprofv3 --pmc passes of this same command (PMC
+        # counters cannot be read from inside the process); the committed summary applies only to its own workload
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") == a.config and pmc.get("n_gpus") == world and a.alpha == 1.05:
+                traffic = pmc.get("hbm_bytes_per_launch")
         out = {
             "metric": "training samples/sec, Criteo-Terabyte-shape synthetic (cached data-parallel DLRM step, refills included)",
             "value": B * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -207,7 +216,8 @@ def main():
                        "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1)},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/r01_gather_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                          "bytes_per_launch": alg_bytes, "avg_launch_us": gather_ms * 1e3 if gather_ms == gather_ms else None,
                          "launches_timed": len(ev_pairs)},
         }

@@ -1,0 +1,87 @@
+"""Two trainer processes with the REAL HIP kernels (both on cuda:0, collectives over gloo because one GPU cannot
+host two RCCL ranks) against the reference's 2-process golden run: exercises the shared, registered host tables
+(rank 0 writes evictions back, rank 1 reads them over PCIe), replicated deterministic inserts, sync-to-rank-0,
+the touched-row merge and the flat weight-grad all-reduce."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, name, host_shared, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from test_distributed_gloo import _batches
+    import cdlrm_amd.engine as engine
+    import cdlrm_amd.model_no_ddp as M
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    ln_emb = np.array([int(x) for x in g["ln_emb"]])
+    m_spa, seed, B, L = int(g["m_spa"]), int(g["seed"]), int(g["B"]), int(g["L"])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2] + [int(x) for x in g["top"]])
+    eg = M.Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+    for k in range(len(ln_emb)):
+        eg.emb_l[k].weight.data = host_shared[k]
+    eg.register_shared()
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    cg = M.Embedding_Table_Cache_Group(m_spa, ln_emb, int(g["cache_size"]), B, int(g["ways"])).to(dev)
+    dl = M.DLRM_Net(np.array(g["ln_bot"]), ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
+    eng = engine.TrainEngine(cg, dl, eg, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), world_size=world, rank=rank,
+                             table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]))
+    pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
+    lbs = B // world
+    losses = []
+    batches = _batches(g)
+    for j, (X, lS_i, Tt) in enumerate(batches):
+        if j % L == 0:
+            eng.sync_touched_to_rank0()
+            torch.manual_seed(5000 + j)
+            pipe.plan_window(torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(dev))
+            pipe.commit()
+            pipe.wait_writeback()
+        sl = slice(rank * lbs, (rank + 1) * lbs)
+        loss = eng.step(X[sl].to(dev), lS_i[:, sl].contiguous().to(dev), Tt[sl].to(dev), j=j)
+        losses.append(float(loss[0]))
+    cg.ctx.check()
+    lin = M._linears(dl.top_l)
+    ret.put((rank, dict(losses=np.array(losses), occ=[o.cpu().numpy() for o in cg.occupancy_tables],
+                        top_w=[l.weight.data.cpu().numpy() for l in lin])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,port", [("train_w2_mean", 29821), ("train_w2_max", 29822)])
+def test_two_ranks_one_gpu_match_reference(golden, name, port):
+    from oracle import cdlrm_oracle as O
+    g = golden(name)
+    np.random.seed(int(g["seed"]))
+    host = [h.share_memory_() for h in O.init_host_tables([int(x) for x in g["ln_emb"]], int(g["m_spa"]))]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(2):
+        np.testing.assert_allclose(got[r]["losses"], g[f"r{r}_losses"], rtol=1e-5)
+        for k in range(len(g["ln_emb"])):
+            assert np.array_equal(got[r]["occ"][k], g[f"occ_{k}"]), (r, k)
+        for i in range(len(got[r]["top_w"])):
+            np.testing.assert_allclose(got[r]["top_w"][i], g[f"r{r}_top_w{i}"], rtol=1e-4, atol=1e-6)
+    for k in range(len(g["ln_emb"])):
+        np.testing.assert_allclose(float(host[k].double().sum()), float(g[f"host_sum_{k}"]), rtol=1e-6)
