@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-sample", type=int, default=8, help="time the gather kernel every k-th step")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--no-graph", action="store_true", help="never replay the step from a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="hipGraph replay also at 1 GPU (default: only when N > 1)")
     return ap.parse_args()
 
 
@@ -139,6 +141,11 @@ def main():
     dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
     eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
                       table_agg_freq=cfg["agg"], table_agg_op="mean")
+    # one GPU at B=8192 is GPU-bound: eager launches + cross-iteration pipelining of the probe; small local batches
+    # (N > 1) are launch-bound: replay the step from a hipGraph
+    use_graph = (not a.no_graph) and (world > 1 or a.graph)
+    if use_graph:
+        eng.enable_graph()
     pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world)
     syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=a.seed, alpha=a.alpha, device=dev)
     torch.cuda.synchronize()
@@ -153,10 +160,10 @@ def main():
         if state["next"] is None:           # very first window: plan it synchronously
             state["next"] = syn.window(w, L)
             pipe.plan_window(state["next"])
-        pipe.commit()
-        state["win"], state["next"], state["w"] = state["next"], None, w
         if world > 1:
             eng.sync_touched_to_rank0()
+        pipe.commit()
+        state["win"], state["next"], state["w"] = state["next"], None, w
 
     def run_step(j, timed):
         w, jj = divmod(j, L)
@@ -171,7 +178,11 @@ def main():
         X, T = syn.dense(j)
         X, T = X[rank * lbs:(rank + 1) * lbs], T[rank * lbs:(rank + 1) * lbs]
         sample = timed and a.gather_sample > 0 and (j % a.gather_sample == 0)
-        eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None)
+        # eager mode: hand the next batch's indices over so its tag probe / aux fill run behind this step's backward
+        nxt = None
+        if not use_graph and jj + 1 < L and jj + 1 != plan_at:
+            nxt = state["win"][:, col + B:col + B + lbs]
+        eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
 
     for j in range(a.warmup):
         run_step(j, False)
@@ -213,7 +224,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": a.config, "global_batch": B, "local_batch": lbs,
                        "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
-                       "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1)},
+                       "parallelism": "dp%d" % world, "hipgraph": use_graph, "final_loss": loss, "setup_s": round(setup_s, 1)},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_act_grad(const float* __restrict__ Y, i
 // Fused activation backward + bias-gradient partial sums: dZ = dY * act'(Y) written in place, and
 // part[chunk][n] = sum over the chunk's CS_ROWS rows of dZ[:, n].  One wave covers 64 consecutive
 // columns of a row (256-B coalesced), 4 row lanes per block, fixed summation order.
-#define CS_ROWS 64
+#define CS_ROWS 256
 __global__ void __launch_bounds__(256) k_actgrad_colsum(const float* __restrict__ Y, int64_t ld_y,
                                                         float* __restrict__ dY, int64_t ld_dy, int64_t M, int N,
                                                         int act, float* __restrict__ part) {
@@ -64,10 +64,20 @@ __global__ void __launch_bounds__(256) k_actgrad_colsum(const float* __restrict_
     if (rg == 0 && n < N && part) part[(int64_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
-__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ part, int64_t count, int splits,
-                                                      float* __restrict__ out) {
-    // fixed summation order (slab 0, 1, 2, ...): reproducible; 4 slabs in flight per step
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+// Two reductions in one launch (dW slabs and the bias-gradient partials of the same layer): blocks [0, gxa) work
+// on job A, the rest on job B.  Fixed summation order (slab 0, 1, 2, ...): reproducible; 4 slabs in flight.
+__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ partA, int64_t countA, int splitsA,
+                                                      float* __restrict__ outA, int gxa,
+                                                      const float* __restrict__ partB, int64_t countB, int splitsB,
+                                                      float* __restrict__ outB) {
+    const bool jobA = (int)blockIdx.x < gxa;
+    const float* part = jobA ? partA : partB;
+    const int64_t count = jobA ? countA : countB;
+    const int splits = jobA ? splitsA : splitsB;
+    float* out = jobA ? outA : outB;
+    const int64_t bid = jobA ? blockIdx.x : blockIdx.x - gxa;
+    const int64_t nblk = jobA ? gxa : gridDim.x - gxa;
+    for (int64_t e = bid * blockDim.x + threadIdx.x; e < count; e += nblk * blockDim.x) {
         float s = 0.f;
         int z = 0;
         for (; z + 4 <= splits; z += 4) {
@@ -109,7 +119,6 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
     if (act != 0 || db) {     // dZ = dY * act'(Y) in place, fused with the bias-gradient partial sums
         hipLaunchKernelGGL(k_actgrad_colsum, dim3((unsigned)cdiv(N, 64), (unsigned)ny), dim3(256), 0, s, Y, ld_y, dY,
                            ld_dy, M, N, act, db ? cs : nullptr);
-        if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, cs, (int64_t)N, ny, db);
     }
     if (dX) {   // dX[M,K] = dZ[M,N] W[N,K]
         GemmArgs g;
@@ -131,11 +140,16 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
         const int zs = (int)cdiv(M, g.kchunk);
         int rc = launch_gemm<false, false>(g, zs, s);
         if (rc) return rc;
+        // one launch sums the dW slabs (if the contraction was split) and the bias-gradient partials
+        int64_t gxa = 0;
         if (splits > 1) {
-            int64_t gx = cdiv((int64_t)N * K, 256);
-            if (gx > 2048) gx = 2048;
-            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)gx), dim3(256), 0, s, slabs, (int64_t)N * K, zs, dW);
+            gxa = cdiv((int64_t)N * K, 256);
+            if (gxa > 2048) gxa = 2048;
         }
+        const int64_t gxb = db ? cdiv(N, 256) : 0;
+        if (gxa + gxb > 0)
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)(gxa + gxb)), dim3(256), 0, s, slabs, (int64_t)N * K, zs, dW,
+                               (int)gxa, cs, (int64_t)N, ny, db);
     }
     CDLRM_LAUNCH_CHECK();
     return 0;

@@ -89,11 +89,26 @@ __global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ 
     if (m == 0) return;
     const TableDesc d = tab[t];
     const float4* src = reinterpret_cast<const float4*>(host_rows[t]);
+    // PCIe-bound: what matters is the number of host reads in flight (the link has a bounded tag pool), not the
+    // number of waves.  Each thread keeps FILL_U independent 16-B host reads in flight, so a SMALL grid saturates the
+    // link and leaves the memory pipelines of the other CUs to the kernels this fill runs beside.
+    constexpr int FILL_U = 8;
     const int64_t total = (int64_t)m * D4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(e / D4), c = (int)(e % D4);
-        const int64_t v = idx[(int64_t)t * ld_idx + miss_pos[(int64_t)t * n + r]];
-        weight[(d.row_base + d.P * ways + r) * D4 + c] = src[v * D4 + c];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * FILL_U) {
+        float4 v[FILL_U];
+        int64_t dst[FILL_U];
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) {
+            const int64_t e = min(e0 + u * stride, total - 1);
+            const int r = (int)(e / D4), c = (int)(e % D4);
+            const int64_t id = idx[(int64_t)t * ld_idx + miss_pos[(int64_t)t * n + r]];
+            dst[u] = (d.row_base + d.P * ways + r) * D4 + c;
+            v[u] = src[id * D4 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u)
+            if (e0 + u * stride < total) weight[dst[u]] = v[u];
     }
 }
 
@@ -129,6 +144,57 @@ __global__ void __launch_bounds__(256) k_embbag_fwd_arange(const TableDesc* __re
             for (int u = 0; u < FWD_UNROLL; ++u)
                 if (s[u] >= 0) *reinterpret_cast<float4*>(o + (b0 + u) * ld_bag + cc * 4) = v[u];
         }
+    }
+}
+
+// Persistent variant: a fixed grid walks (table, bag-chunk) work items; the slot ids of the NEXT item are loaded
+// before the current item's rows, so the slot -> row dependency costs one memory latency per item instead of two,
+// and there is no per-block launch ramp.  Loads are unpredicated (tail bags clamp to the last bag), only the
+// stores are masked.
+template <int LPR, int U>
+__global__ void __launch_bounds__(256) k_embbag_fwd_arange_p(const TableDesc* __restrict__ tab, int T, int D4,
+                                                             const float4* __restrict__ weight,
+                                                             const int32_t* __restrict__ slots, int64_t n,
+                                                             float* __restrict__ out, int64_t ld_bag, int64_t ld_table) {
+    const int c = threadIdx.x % LPR;
+    const int gpb = blockDim.x / LPR;
+    const int gid = threadIdx.x / LPR;
+    const int64_t chunks = cdiv_dev(n, (int64_t)gpb * U);
+    const int64_t total = chunks * T;
+    int64_t w = blockIdx.x;
+    if (w >= total) return;
+    int32_t s[U];
+    {
+        const int t = (int)(w / chunks);
+        const int64_t b0 = ((w % chunks) * gpb + gid) * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = slots[(int64_t)t * n + min(b0 + u, n - 1)];
+    }
+    while (true) {
+        const int t = (int)(w / chunks);
+        const int64_t b0 = ((w % chunks) * gpb + gid) * U;
+        const int64_t wn = w + gridDim.x;
+        int32_t sn[U];
+        if (wn < total) {
+            const int tn = (int)(wn / chunks);
+            const int64_t bn = ((wn % chunks) * gpb + gid) * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) sn[u] = slots[(int64_t)tn * n + min(bn + u, n - 1)];
+        }
+        const int64_t row_base = tab[t].row_base;
+        float* o = out + (int64_t)t * ld_table;
+        for (int cc = c; cc < D4; cc += LPR) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = weight[(row_base + s[u]) * D4 + cc];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (b0 + u < n) *reinterpret_cast<float4*>(o + (b0 + u) * ld_bag + cc * 4) = v[u];
+        }
+        if (wn >= total) break;
+        w = wn;
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = sn[u];
     }
 }
 
@@ -207,7 +273,9 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
         CDLRM_REQUIRE(ctx->h_host_rows[0] != nullptr, "cdlrm_ctx_bind_host_tables first");
         const int D4 = ctx->D / 4;
         int64_t fx = cdiv((int64_t)(n < ctx->aux ? n : ctx->aux) * D4, 256);
-        if (fx > 256) fx = 256;
+        // PCIe-bound (~50 GB/s): ~100 waves in flight saturate the link; a larger grid only steals memory-pipeline
+        // slots from the kernels this fill runs beside (measured: a concurrent GEMM slowed 4x under 256 blocks/table)
+        if (fx > 8) fx = 8;
         hipLaunchKernelGGL(k_fill_aux, dim3((unsigned)fx, (unsigned)ctx->T), dim3(256), 0, s, ctx->d_tab, ctx->ways, D4,
                            reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, n, ld_idx, miss_pos,
                            miss_count);
@@ -229,7 +297,26 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
     const int lpr = lanes_per_row(D4);
     const int gpb = 256 / lpr;
     const float4* w = reinterpret_cast<const float4*>(ctx->weight);
-    if (!offsets) {
+    static int variant = -1;
+    static int pgrid = 4096;     // measured on MI355X (c3 shape): persistent U=4, 4096 workgroups 33 us vs 45 us one-shot
+    if (variant < 0) {
+        const char* e = getenv("CDLRM_GATHER_VARIANT");     // development switch: 0 one-shot grid, 4/8 persistent
+        variant = e ? atoi(e) : 4;
+        const char* gsz = getenv("CDLRM_GATHER_GRID");
+        if (gsz) pgrid = atoi(gsz);
+    }
+    if (!offsets && (variant == 4 || variant == 8)) {
+        const int U = variant;
+        int64_t total = cdiv(n, (int64_t)gpb * U) * ctx->T;
+        int64_t gx = total < pgrid ? total : pgrid;
+#define PFWD_CALL(L)                                                                                                  \
+    if (U == 4) hipLaunchKernelGGL((k_embbag_fwd_arange_p<L, 4>), dim3((unsigned)gx), dim3(256), 0, s, ctx->d_tab,   \
+                                   ctx->T, D4, w, slots, n, out, ld_bag, ld_table);                                  \
+    else hipLaunchKernelGGL((k_embbag_fwd_arange_p<L, 8>), dim3((unsigned)gx), dim3(256), 0, s, ctx->d_tab, ctx->T,  \
+                            D4, w, slots, n, out, ld_bag, ld_table)
+        DISPATCH_LPR(lpr, PFWD_CALL)
+#undef PFWD_CALL
+    } else if (!offsets) {
         int64_t gx = cdiv(n, (int64_t)gpb * FWD_UNROLL);
         if (gx > 65535) gx = 65535;
         dim3 grid((unsigned)gx, (unsigned)ctx->T);

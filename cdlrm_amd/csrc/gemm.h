@@ -13,8 +13,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef GBK
 #define GBK 32
-#define LDS_KC (GBK + 4)   // pitch 36 floats: 16-B aligned rows, conflict-free ds_read_b128 / ds_write_b128
+#endif
+#define LDS_KC (GBK + 4)   // pitch = odd multiple of 16 B: aligned rows, conflict-free ds_read_b128 / ds_write_b128
 
 struct GemmArgs {
     const float* A; int64_t lda;
@@ -30,12 +32,12 @@ struct GemmArgs {
 // loads stay in flight across the MFMA loop.  Only the last, partial K tile zero-fills (at LDS-store time).
 template <bool KC, int ROWS, bool VEC, bool FULLK>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax,
-                                          int64_t k0, int64_t kmax, float4 (&v)[ROWS / 32]) {
+                                          int64_t k0, int64_t kmax, float4 (&v)[ROWS * GBK / 1024]) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
+    for (int i = 0; i < ROWS * GBK / 1024; ++i) {
         const int f = threadIdx.x + i * 256;
         if (KC) {       // ROWS rows of the non-contraction index, 32 contraction elements (8 float4) per row
-            const int64_t r = f >> 3, c = (f & 7) * 4;
+            const int64_t r = f / (GBK / 4), c = (f % (GBK / 4)) * 4;
             const int64_t rr = min(r0 + r, rmax - 1);
             if (VEC) {
                 const int64_t kk = FULLK ? k0 + c : min(k0 + c, kmax - 4);
@@ -63,7 +65,7 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t l
 
 template <bool KC, int ROWS>
 __device__ __forceinline__ void tile_load_any(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax,
-                                              int64_t k0, int64_t kmax, bool vec, float4 (&v)[ROWS / 32]) {
+                                              int64_t k0, int64_t kmax, bool vec, float4 (&v)[ROWS * GBK / 1024]) {
     const bool full = k0 + GBK <= kmax;      // all branches here are wave-uniform
     if (vec) {
         if (full) tile_load<KC, ROWS, true, true>(P, ld, r0, rmax, k0, kmax, v);
@@ -75,15 +77,15 @@ __device__ __forceinline__ void tile_load_any(const float* __restrict__ P, int64
 }
 
 template <bool KC, int ROWS>
-__device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&v)[ROWS / 32], int64_t k0,
+__device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&v)[ROWS * GBK / 1024], int64_t k0,
                                            int64_t kmax) {
     const bool full = k0 + GBK <= kmax;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
+    for (int i = 0; i < ROWS * GBK / 1024; ++i) {
         const int f = threadIdx.x + i * 256;
         float4 x = v[i];
         if (KC) {
-            const int r = f >> 3, c = (f & 7) * 4;
+            const int r = f / (GBK / 4), c = (f % (GBK / 4)) * 4;
             if (!full) {
                 if (k0 + c + 0 >= kmax) x.x = 0.f;
                 if (k0 + c + 1 >= kmax) x.y = 0.f;
@@ -125,12 +127,15 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[BM / 32], rb[BN / 32];
+    float4 ra[BM * GBK / 1024], rb[BN * GBK / 1024];
     tile_load_any<A_KC, BM>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
     tile_load_any<B_KC, BN>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0      // tools/gemm_ablate.hip only: 1 no global loads, 2 no LDS staging, 3 neither
 #endif
+    // (LDS double-buffering with one barrier per tile was tried and measured SLOWER on these shapes -- 73.6 vs
+    //  80 TF at 8192x512x512, 20 vs 26 TF at M=1024: the doubled LDS footprint costs more occupancy than the saved
+    //  barrier buys.)
     for (int64_t k0 = kbeg; k0 < kend; k0 += GBK) {
         if (!(GEMM_ABLATE & 2) || k0 == kbeg) {
             __syncthreads();

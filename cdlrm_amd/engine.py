@@ -125,6 +125,7 @@ class TrainEngine:
         self.comm = S.new_stream(self.dev) if self.world > 1 else None
         self.side = S.new_stream(self.dev)
         self.agg_rows = None
+        self._pref = None
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -209,11 +210,63 @@ class TrainEngine:
         self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.agg_count_host = S.pinned(torch.zeros(1, dtype=torch.int64), self.dev)
 
+    def enable_graph(self, on: bool = True):
+        """Replay the per-iteration launch sequence from a captured hipGraph (one graph per batch shape) instead of
+        issuing ~60 launches from Python: at small local batches the step is launch-bound otherwise.  The collective
+        and the dense SGD stay outside the graph."""
+        self.use_graph = bool(on) and S.is_hip(self.dev)
+        self._graphs = {}
+        self._eager_seen = {}
+
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
-             j: Optional[int] = None, gather_events: Optional[list] = None):
-        """One training iteration on this rank's slice.  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
+             j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None):
+        """One training iteration on this rank's slice (next_idx: the NEXT batch's indices, if it belongs to the same
+        window: its tag probe and aux fill are then issued behind this step's embedding backward).  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
         on the device; lS_o None = Criteo layout; j = batch number inside the epoch (table-agg schedule).
         Returns the device loss buffer (element 0 = BCE loss)."""
+        B, n = X.shape[0], lS_i.shape[1]
+        main = S.current_stream(self.dev)
+        if getattr(self, "use_graph", False) and gather_events is None and lS_o is None:
+            key = (B, n)
+            g = self._graphs.get(key)
+            if g is None:
+                seen = self._eager_seen.get(key, 0)
+                if seen < 3:            # warm-up: buffers, attributes and allocator state settle eagerly first
+                    self._eager_seen[key] = seen + 1
+                    self._fwd_bwd(X, lS_i, T, lS_o, None)
+                else:
+                    st = dict(X=torch.empty_like(X), idx=torch.empty((self.T, n), dtype=torch.int64, device=self.dev),
+                              T=torch.empty_like(T))
+                    st["X"].copy_(X); st["idx"].copy_(lS_i); st["T"].copy_(T)
+                    torch.cuda.synchronize(self.dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._fwd_bwd(st["X"], st["idx"], st["T"], None, None)
+                    g = (graph, st)
+                    self._graphs[key] = g
+                    graph.replay()
+            else:
+                graph, st = g
+                st["X"].copy_(X); st["idx"].copy_(lS_i); st["T"].copy_(T)
+                graph.replay()
+        else:
+            self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
+        # ---- dense gradient exchange + SGD ----
+        if self.world > 1:
+            gw = self.grad_flat[:self.n_weight]
+            ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
+            dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
+        ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
+        # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
+        if j is None:
+            j = self.iter
+        if j > 0 and j % self.agg_freq == 0:
+            self.table_aggregate()
+        self.iter += 1
+        return self._buffers(B)["loss"]
+
+    def _fwd_bwd(self, X, lS_i, T, lS_o, gather_events, next_idx=None):
+        """Forward + backward of one iteration up to: all dense gradients in grad_flat, cache rows updated."""
         ctx, cg = self.ctx, self.cg
         B = X.shape[0]
         n = lS_i.shape[1]
@@ -221,25 +274,19 @@ class TrainEngine:
         feat, dfeat, R, dR = buf["feat"], buf["dfeat"], buf["R"], buf["dR"]
         F, D = self.F, self.D
         # ---- forward ----
-        # embedding path (probe -> aux fill over PCIe -> gather) on the side stream, under the bottom MLP
+        # tag probe + aux-row fill (PCIe) on the side stream, under the bottom MLP -- or already done: the previous
+        # step issues them for this batch behind its embedding backward (software-pipelined across iterations)
         main = S.current_stream(self.dev)
         side = self.side
-        side.wait_stream(main)
-        with S.on_stream(side):
-            slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side)
-            if gather_events is not None:   # bench.py: HIP events around the roofline kernel, on ITS stream
-                e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
-                e0.record(side)
-                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B, stream=side)
-                e1.record(side)
-                gather_events.append((e0, e1))
-            else:
-                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B, stream=side)
-            gathered = S.new_event(self.dev)
-            gathered.record(side)
-            # the backward's sort of the slot ids needs nothing but the probe result: run it here, under the MLPs
-            emb_work = self._emb_work(n)
-            ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
+        pref, self._pref = self._pref, None
+        if pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape):
+            slots, miss_pos, miss_count, probed = pref["res"]
+        else:
+            side.wait_stream(main)
+            with S.on_stream(side):
+                slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side)
+                probed = S.new_event(self.dev)
+                probed.record(side)
         cur = X
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
@@ -247,7 +294,20 @@ class TrainEngine:
             ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
             bot_acts.append(y)
             cur = y
-        main.wait_event(gathered)
+        # the gather runs alone on the main stream (it is the HBM-roofline kernel: nothing competes for bandwidth)
+        main.wait_event(probed)
+        if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
+            e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
+            e0.record(main)
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+            e1.record(main)
+            gather_events.append((e0, e1))
+        else:
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+        # the backward's sort of the slot ids needs nothing but the probe result: run it on the side, under the MLPs
+        emb_work = self._emb_work(n)
+        with S.on_stream(side):
+            ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         ops.interact_fwd(feat, self.itself, R)
         cur = R
         top_acts = [R]
@@ -273,6 +333,13 @@ class TrainEngine:
         with S.on_stream(self.side):
             ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, emb_work, cg.touched,
                                  stream=self.side)
+            emb_done = S.new_event(self.dev)
+            emb_done.record(self.side)
+            if next_idx is not None:
+                res = ops.embbag_probe(ctx, next_idx, stream=self.side)
+                ev = S.new_event(self.dev)
+                ev.record(self.side)
+                self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), res=(res[0], res[1], res[2], ev))
         dY = dfeat[:, 0, :]
         for i in reversed(range(len(self.bot))):
             l, act = self.bot[i]
@@ -280,23 +347,10 @@ class TrainEngine:
             ops.linear_bwd(bot_acts[i], l.weight.data, bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
                            buf["lin_work"])
             dY = dX
-        # ---- dense gradient exchange + SGD ----
-        if self.world > 1:
-            gw = self.grad_flat[:self.n_weight]
-            ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
-            self.comm.wait_stream(main)
-            with S.on_stream(self.comm):
-                dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
-            main.wait_stream(self.comm)
-        ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
-        main.wait_stream(self.side)
-        # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
-        if j is None:
-            j = self.iter
-        if j > 0 and j % self.agg_freq == 0:
-            self.table_aggregate()
-        self.iter += 1
-        return buf["loss"]
+        if next_idx is None:
+            main.wait_stream(self.side)      # full join (also what a hipGraph capture needs)
+        else:
+            main.wait_event(emb_done)        # cache rows are updated; the prefetched probe keeps running
 
     def table_aggregate(self):
         """broadcast_and_aggregate (main_no_ddp.py:250-292): average the rows any rank touched since the last
