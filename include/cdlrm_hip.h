@@ -198,6 +198,22 @@ int cdlrm_scatter_rows(float* dst, const int64_t* index, const float* rows, int6
                        int32_t dim, int average, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Quotient-remainder embedding bag, stand-alone operator (QREmbeddingBag.forward,
+ * tricks/qr_embedding_bag.py:156-174; the reference never wires it into the cached path).
+ *   q = (idx / collisions).long() as a float32 true division + truncation (quirk kept), r = idx % collisions;
+ *   out[b] = sum_bag Wq[q] (op 0: * , 1: + , 2: concat) sum_bag Wr[r];  out is [n_bags, D] (2D for concat).
+ *   eq_out / er_out (optional, [n_bags, D]) keep the pooled operands for the mult backward.
+ *   err_word: device int32, set non-zero when a quotient falls outside Wq.
+ * bwd accumulates DENSE gradients gWq [rows_q, D], gWr [collisions, D] (caller zeroes them).
+ * ------------------------------------------------------------------------------------------- */
+int cdlrm_qr_embbag_fwd(const int64_t* idx, const int64_t* offsets, int64_t n, int64_t n_bags,
+                        const float* Wq, const float* Wr, int64_t rows_q, int32_t collisions, int32_t dim,
+                        int32_t op, float* out, float* eq_out, float* er_out, int32_t* err_word, void* stream);
+int cdlrm_qr_embbag_bwd(const int64_t* idx, const int64_t* offsets, int64_t n, int64_t n_bags,
+                        const float* eq, const float* er, const float* grad_out, int64_t rows_q,
+                        int32_t collisions, int32_t dim, int32_t op, float* gWq, float* gWr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Table aggregation (broadcast_and_aggregate, main_no_ddp.py:250-292)
  * ------------------------------------------------------------------------------------------- */
 

@@ -334,6 +334,39 @@ def test_linear_vs_torch_fp32(ops, M, N, K, act):
     np.testing.assert_allclose(db.cpu().numpy(), dZ.sum(0).float().numpy(), rtol=1e-4, atol=1e-4 * scale)
 
 
+def test_qr_embedding_bag_golden(ops, golden):
+    """QREmbeddingBag forward + gradients vs the reference's module, incl. the float32-division quirk."""
+    from cdlrm_amd.tricks.qr_embedding_bag import QREmbeddingBag
+    from cdlrm_amd import _lib
+    g = golden("qr")
+    c = int(g["c"])
+    for op in ("mult", "add", "concat"):
+        wq, wr = t(g[f"{op}_wq"]).to(DEV), t(g[f"{op}_wr"]).to(DEV)
+        E = QREmbeddingBag(103, wq.shape[1], c, operation=op, mode="sum", sparse=True, _weight=[wq.clone(), wr.clone()])
+        V = E(t(g[f"{op}_idx"]).to(DEV), t(g[f"{op}_offs"]).to(DEV))
+        np.testing.assert_allclose(V.detach().cpu().numpy(), g[f"{op}_V"], rtol=1e-6, atol=1e-7)
+        V.backward(t(g[f"{op}_G"]).to(DEV))
+        np.testing.assert_allclose(E.weight_q.grad.cpu().numpy(), g[f"{op}_gq"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(E.weight_r.grad.cpu().numpy(), g[f"{op}_gr"], rtol=1e-5, atol=1e-6)
+    # quotient arithmetic above 2**24: rows addressed = (idx / c).long() in float32
+    big = t(g["big_idx"]).to(DEV)
+    rows_q = int(g["big_q"].max()) + 1
+    Wq = torch.arange(rows_q, dtype=torch.float32, device=DEV).view(-1, 1).repeat(1, 4).contiguous()
+    Wr = torch.zeros(c, 4, device=DEV)
+    out = torch.empty(big.numel(), 4, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    off = torch.arange(big.numel(), device=DEV)
+    _lib.check(_lib.lib().cdlrm_qr_embbag_fwd(big.data_ptr(), off.data_ptr(), big.numel(), big.numel(), Wq.data_ptr(),
+                                              Wr.data_ptr(), rows_q, c, 4, 1, out.data_ptr(), None, None, err.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+    assert int(err) == 0
+    got = out[:, 0].cpu().double().numpy()
+    # float32 row ids are exact up to 2**24; compare where representable, and the quirk case explicitly
+    want = g["big_q"].astype(np.float64)
+    assert np.array_equal(np.float32(got), np.float32(want))
+    assert int(g["big_q"][4]) == 10_000_000
+
+
 def test_sgd_and_agg(ops):
     p = torch.randn(100003, device=DEV)
     gr = torch.randn(100003, device=DEV)
