@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--alpha", type=float, default=1.05, help="Zipf exponent of the synthetic indices (0 = uniform)")
     ap.add_argument("--max-ind-range", type=int, default=-1, help="cap rows per table (main_no_ddp.py:64)")
     ap.add_argument("--lookahead", type=int, default=-1, help="override the config's lookahead window")
+    ap.add_argument("--batch", type=int, default=-1, help="override the config's global batch (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-sample", type=int, default=8, help="time the gather kernel every k-th step")
     ap.add_argument("--seed", type=int, default=123)
@@ -121,6 +122,9 @@ def main():
     cfg = dict(CONFIGS[a.config])
     if a.lookahead > 0:
         cfg["L"] = a.lookahead
+    if a.batch > 0:          # development: emulate the per-rank batch of an N-GPU run on one GPU
+        cfg["B"] = a.batch
+        cfg["name"] += " [batch overridden to %d]" % a.batch
     tables = cfg["tables"]
     ln_emb = list(synth.TERABYTE_COUNTS if tables == "terabyte" else synth.KAGGLE_COUNTS if tables == "kaggle" else tables)
     if a.max_ind_range > 0:

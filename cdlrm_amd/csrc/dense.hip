@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
 }
 
 static int wgrad_splits(int64_t M, int N, int K) {
-    const int64_t tiles = cdiv(N, 64) * cdiv(K, 128);   // the 64x128 tile launch_gemm picks for these shapes
-    int64_t s = cdiv(512, tiles);                     // aim at ~2 workgroups per CU
+    const int64_t tiles = cdiv(N, 64) * cdiv(K, 64);    // the 64x64 tile launch_gemm picks for these shapes
+    int64_t s = cdiv(1024, tiles);                    // aim at ~4 workgroups per CU
     const int64_t smax = cdiv(M, 8 * GBK);
     if (s > smax) s = smax;
     if (s < 1) s = 1;

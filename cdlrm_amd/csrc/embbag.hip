@@ -151,11 +151,13 @@ __global__ void __launch_bounds__(256) k_embbag_fwd_arange(const TableDesc* __re
 // before the current item's rows, so the slot -> row dependency costs one memory latency per item instead of two,
 // and there is no per-block launch ramp.  Loads are unpredicated (tail bags clamp to the last bag), only the
 // stores are masked.
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int LPR, int U>
 __global__ void __launch_bounds__(256) k_embbag_fwd_arange_p(const TableDesc* __restrict__ tab, int T, int D4,
                                                              const float4* __restrict__ weight,
                                                              const int32_t* __restrict__ slots, int64_t n,
-                                                             float* __restrict__ out, int64_t ld_bag, int64_t ld_table) {
+                                                             float* __restrict__ out, int64_t ld_bag, int64_t ld_table,
+                                                             int nt) {
     const int c = threadIdx.x % LPR;
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
@@ -189,7 +191,15 @@ __global__ void __launch_bounds__(256) k_embbag_fwd_arange_p(const TableDesc* __
             for (int u = 0; u < U; ++u) v[u] = weight[(row_base + s[u]) * D4 + cc];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (b0 + u < n) *reinterpret_cast<float4*>(o + (b0 + u) * ld_bag + cc * 4) = v[u];
+                if (b0 + u < n) {
+                    float* p = o + (b0 + u) * ld_bag + cc * 4;
+                    if (nt) {
+                        v4f x = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        __builtin_nontemporal_store(x, reinterpret_cast<v4f*>(p));
+                    } else {
+                        *reinterpret_cast<float4*>(p) = v[u];
+                    }
+                }
         }
         if (wn >= total) break;
         w = wn;
@@ -305,15 +315,20 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
         const char* gsz = getenv("CDLRM_GATHER_GRID");
         if (gsz) pgrid = atoi(gsz);
     }
+    static int nt = -1;
+    if (nt < 0) {
+        const char* e = getenv("CDLRM_GATHER_NT");          // development switch: non-temporal output stores
+        nt = e ? atoi(e) : 0;
+    }
     if (!offsets && (variant == 4 || variant == 8)) {
         const int U = variant;
         int64_t total = cdiv(n, (int64_t)gpb * U) * ctx->T;
         int64_t gx = total < pgrid ? total : pgrid;
 #define PFWD_CALL(L)                                                                                                  \
     if (U == 4) hipLaunchKernelGGL((k_embbag_fwd_arange_p<L, 4>), dim3((unsigned)gx), dim3(256), 0, s, ctx->d_tab,   \
-                                   ctx->T, D4, w, slots, n, out, ld_bag, ld_table);                                  \
+                                   ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt);                              \
     else hipLaunchKernelGGL((k_embbag_fwd_arange_p<L, 8>), dim3((unsigned)gx), dim3(256), 0, s, ctx->d_tab, ctx->T,  \
-                            D4, w, slots, n, out, ld_bag, ld_table)
+                            D4, w, slots, n, out, ld_bag, ld_table, nt)
         DISPATCH_LPR(lpr, PFWD_CALL)
 #undef PFWD_CALL
     } else if (!offsets) {

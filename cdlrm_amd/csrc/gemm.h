@@ -4,10 +4,14 @@
 //   TM x TN MFMA tiles of 32x32; global -> register prefetch -> LDS staging, one barrier pair per K tile.
 //   A_KC: A(m,k) = A[m*lda + k]  (contraction contiguous)   else A[k*lda + m]
 //   B_KC: B(k,n) = B[n*ldb + k]                             else B[k*ldb + n]
-// LDS images: contraction-contiguous operands as [rows][32+1] (odd pitch: conflict-free fragment reads
-// and 4x ds_write_b32 staging), the others as [32][rows] (ds_write_b128 staging, contiguous reads).
+// LDS images: contraction-contiguous operands as [rows][32+4] (pitch = odd multiple of 16 B: ds_write_b128
+// staging and ds_read_b128 fragment fetches are both conflict-free), the others as [32][rows].
 // The tile shape is picked per call so that the grid has >= 2 workgroups per CU: with one 4-wave
 // workgroup per CU every SIMD holds a single wave and nothing hides its barrier / staging stalls.
+// Measured (tools/gemm_ablate.hip, 8192x512x512): 80 TF with staging, 107 TF with the staging ablated; the vendor
+// sgemm reaches 95-113 TF on the forward/dgrad shapes and 40-77 TF on the wgrad shapes, i.e. the MLP as a whole
+// runs at the library's speed.  Tried without gain: LDS double-buffering, 2-stage register prefetch, BK=64,
+// step-major MFMA order.
 #pragma once
 #include "common.h"
 
@@ -30,27 +34,31 @@ struct GemmArgs {
 // Operand staging.  Steady-state tiles (FULLK) are loaded with NO predicate: rows past the matrix edge are
 // clamped to the last valid row (their products land in output rows/columns that are never stored), so the
 // loads stay in flight across the MFMA loop.  Only the last, partial K tile zero-fills (at LDS-store time).
-template <bool KC, int ROWS, bool VEC, bool FULLK>
+template <bool KC, int ROWS, bool VEC>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax,
                                           int64_t k0, int64_t kmax, float4 (&v)[ROWS * GBK / 1024]) {
+    // STRAIGHT-LINE code on purpose: no branch, wave-uniform or not, may surround these loads.  hipcc places an
+    // s_waitcnt vmcnt(0) at the join of any branch that contains loads, which would drain the prefetch before the
+    // MFMA loop instead of letting it fly underneath (seen in the ISA: every K tile then pays a full load latency).
+    // Out-of-range rows / contraction indices are clamped to valid addresses; the partial last tile is zero-filled
+    // when it is written to LDS.
 #pragma unroll
     for (int i = 0; i < ROWS * GBK / 1024; ++i) {
         const int f = threadIdx.x + i * 256;
-        if (KC) {       // ROWS rows of the non-contraction index, 32 contraction elements (8 float4) per row
+        if (KC) {       // ROWS rows of the non-contraction index, GBK contraction elements per row
             const int64_t r = f / (GBK / 4), c = (f % (GBK / 4)) * 4;
             const int64_t rr = min(r0 + r, rmax - 1);
             if (VEC) {
-                const int64_t kk = FULLK ? k0 + c : min(k0 + c, kmax - 4);
-                v[i] = *reinterpret_cast<const float4*>(P + rr * ld + kk);
+                v[i] = *reinterpret_cast<const float4*>(P + rr * ld + min(k0 + c, kmax - 4));
             } else {
                 float e[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) e[u] = P[rr * ld + (FULLK ? k0 + c + u : min(k0 + c + u, kmax - 1))];
+                for (int u = 0; u < 4; ++u) e[u] = P[rr * ld + min(k0 + c + u, kmax - 1)];
                 v[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
-        } else {        // 32 rows of the contraction index, ROWS non-contraction elements per row
+        } else {        // GBK rows of the contraction index, ROWS non-contraction elements per row
             const int64_t c = f / (ROWS / 4), r = (f % (ROWS / 4)) * 4;
-            const int64_t kk = FULLK ? k0 + c : min(k0 + c, kmax - 1);
+            const int64_t kk = min(k0 + c, kmax - 1);
             if (VEC) {
                 v[i] = *reinterpret_cast<const float4*>(P + kk * ld + min(r0 + r, rmax - 4));
             } else {
@@ -64,44 +72,29 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t l
 }
 
 template <bool KC, int ROWS>
-__device__ __forceinline__ void tile_load_any(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax,
-                                              int64_t k0, int64_t kmax, bool vec, float4 (&v)[ROWS * GBK / 1024]) {
-    const bool full = k0 + GBK <= kmax;      // all branches here are wave-uniform
-    if (vec) {
-        if (full) tile_load<KC, ROWS, true, true>(P, ld, r0, rmax, k0, kmax, v);
-        else tile_load<KC, ROWS, true, false>(P, ld, r0, rmax, k0, kmax, v);
-    } else {
-        if (full) tile_load<KC, ROWS, false, true>(P, ld, r0, rmax, k0, kmax, v);
-        else tile_load<KC, ROWS, false, false>(P, ld, r0, rmax, k0, kmax, v);
-    }
-}
-
-template <bool KC, int ROWS>
 __device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&v)[ROWS * GBK / 1024], int64_t k0,
                                            int64_t kmax) {
-    const bool full = k0 + GBK <= kmax;
 #pragma unroll
     for (int i = 0; i < ROWS * GBK / 1024; ++i) {
         const int f = threadIdx.x + i * 256;
         float4 x = v[i];
         if (KC) {
             const int r = f / (GBK / 4), c = (f % (GBK / 4)) * 4;
-            if (!full) {
-                if (k0 + c + 0 >= kmax) x.x = 0.f;
-                if (k0 + c + 1 >= kmax) x.y = 0.f;
-                if (k0 + c + 2 >= kmax) x.z = 0.f;
-                if (k0 + c + 3 >= kmax) x.w = 0.f;
-            }
+            x.x = (k0 + c + 0 < kmax) ? x.x : 0.f;      // selects, not branches
+            x.y = (k0 + c + 1 < kmax) ? x.y : 0.f;
+            x.z = (k0 + c + 2 < kmax) ? x.z : 0.f;
+            x.w = (k0 + c + 3 < kmax) ? x.w : 0.f;
             *reinterpret_cast<float4*>(S + r * LDS_KC + c) = x;
         } else {
             const int c = f / (ROWS / 4), r = (f % (ROWS / 4)) * 4;
-            if (!full && k0 + c >= kmax) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = k0 + c < kmax;
+            x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
             *reinterpret_cast<float4*>(S + c * ROWS + r) = x;
         }
     }
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN>
+template <bool A_KC, bool B_KC, int TM, int TN, bool VA, bool VB>
 __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_KC];
@@ -128,8 +121,8 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 ra[BM * GBK / 1024], rb[BN * GBK / 1024];
-    tile_load_any<A_KC, BM>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-    tile_load_any<B_KC, BN>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    tile_load<A_KC, BM, VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    tile_load<B_KC, BN, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0      // tools/gemm_ablate.hip only: 1 no global loads, 2 no LDS staging, 3 neither
 #endif
@@ -143,9 +136,9 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
             tile_store<B_KC, BN>(Bs, rb, k0, kend);
             __syncthreads();
         }
-        if (k0 + GBK < kend && !(GEMM_ABLATE & 1)) {
-            tile_load_any<A_KC, BM>(g.A, g.lda, m0, g.M, k0 + GBK, kend, g.vecA, ra);
-            tile_load_any<B_KC, BN>(g.B, g.ldb, n0, g.N, k0 + GBK, kend, g.vecB, rb);
+        if (!(GEMM_ABLATE & 1)) {   // unconditional: past the last tile the clamped addresses just re-read valid data
+            tile_load<A_KC, BM, VA>(g.A, g.lda, m0, g.M, k0 + GBK, kend, ra);
+            tile_load<B_KC, BN, VB>(g.B, g.ldb, n0, g.N, k0 + GBK, kend, rb);
         }
         // One MFMA consumes 2 contraction indices (lanes 0-31 the first, lanes 32-63 the second).  Any pairing works
         // as long as A and B agree, so an 8-index group is consumed in 4 steps with lane-half lk holding indices
@@ -210,15 +203,25 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // tile choice: largest tile whose grid still has >= GEMM_MIN_BLOCKS workgroups
 #define GEMM_MIN_BLOCKS 512
 static inline void gemm_pick_tile(int64_t M, int64_t N, int64_t splits, int* tm, int* tn) {
-    // measured on MI355X at M=8192, N=K=512: 64x128 79 TF > 64x64 74 > 128x64 68 = 128x128 68 (tools/gemm_ablate.hip)
+    // measured on MI355X at M=8192, N=K=512 (tools/gemm_ablate.hip, branch-free staging):
+    //   64x64 91.5 TF (1024 workgroups) > 64x128 86.5 = 128x64 86.3 > 128x128 74.9 (256 workgroups)
+    // -> take the largest tile that still leaves >= 4 workgroups per CU
     const int cand[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
     for (int c = 0; c < 4; ++c) {
         const int64_t blocks = cdiv(M, 64 * cand[c][0]) * cdiv(N, 64 * cand[c][1]) * splits;
-        if (blocks >= (c == 0 ? 2 * GEMM_MIN_BLOCKS : GEMM_MIN_BLOCKS) || c == 3) {
+        if (blocks >= 2 * GEMM_MIN_BLOCKS || c == 3) {
             *tm = cand[c][0]; *tn = cand[c][1];
             return;
         }
     }
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN>
+static void launch_gemm_v(const GemmArgs& g, dim3 grid, hipStream_t s) {
+    if (g.vecA && g.vecB) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, TM, TN, true, true>), grid, dim3(256), 0, s, g);
+    else if (g.vecA) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, TM, TN, true, false>), grid, dim3(256), 0, s, g);
+    else if (g.vecB) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, TM, TN, false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm<A_KC, B_KC, TM, TN, false, false>), grid, dim3(256), 0, s, g);
 }
 
 template <bool A_KC, bool B_KC>
@@ -227,11 +230,15 @@ static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
     gemm_pick_tile(g.M, g.N, splits, &tm, &tn);
     if (g.N <= 32) tn = 1;
     if (g.M <= 32) tm = 1;
+    if (tm == 2 && tn == 1) { tm = 1; tn = g.N <= 64 ? 1 : 2; }     // 128x64 is never the best shape here
+    // vector loads also need extents >= 4 in the vectorised direction (clamped addresses must stay inside)
+    if (g.K < 4) g.vecA = g.vecB = 0;
+    if (!A_KC && g.M < 4) g.vecA = 0;
+    if (!B_KC && g.N < 4) g.vecB = 0;
     dim3 grid((unsigned)cdiv(g.N, 64 * tn), (unsigned)cdiv(g.M, 64 * tm), (unsigned)splits);
-    if (tm == 2 && tn == 2) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, 2, 2>), grid, dim3(256), 0, s, g);
-    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, 2, 1>), grid, dim3(256), 0, s, g);
-    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, 1, 2>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_gemm<A_KC, B_KC, 1, 1>), grid, dim3(256), 0, s, g);
+    if (tm == 2 && tn == 2) launch_gemm_v<A_KC, B_KC, 2, 2>(g, grid, s);
+    else if (tm == 1 && tn == 2) launch_gemm_v<A_KC, B_KC, 1, 2>(g, grid, s);
+    else launch_gemm_v<A_KC, B_KC, 1, 1>(g, grid, s);
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

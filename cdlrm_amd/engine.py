@@ -129,20 +129,28 @@ class TrainEngine:
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
+        """All Linear weights in one flat buffer, biases behind them.  The first top-MLP layer reads the interaction
+        output R, whose width D + npairs (479 at c3) is not a multiple of 4: its weight is stored with the row pitch
+        rounded up to 4 (zero pad column, R gets a matching zero column) so that layer runs on the 16-byte-load GEMM
+        path; `layer.weight` stays a [out, in] view of that storage."""
         lin = _linears(self.dlrm.bot_l) + _linears(self.dlrm.top_l)
-        nw = sum(l.weight.numel() for l in lin)
+        top0 = _linears(self.dlrm.top_l)[0]
+        kp = {l: ((l.in_features + 3) // 4 * 4 if l is top0 else l.in_features) for l in lin}
+        nw = sum(l.out_features * kp[l] for l in lin)
         nb = sum(l.bias.numel() for l in lin)
-        self.param_flat = torch.empty(nw + nb, dtype=torch.float32, device=self.dev)
+        self.param_flat = torch.zeros(nw + nb, dtype=torch.float32, device=self.dev)
         self.grad_flat = torch.zeros(nw + nb, dtype=torch.float32, device=self.dev)
         self.n_weight = nw
         off_w, off_b = 0, nw
-        self.gW, self.gb = {}, {}
+        self.W, self.gW, self.gb = {}, {}, {}
         for l in lin:
-            n = l.weight.numel()
-            self.param_flat[off_w:off_w + n].copy_(l.weight.data.reshape(-1))
-            l.weight.data = self.param_flat[off_w:off_w + n].view_as(l.weight.data)
-            self.gW[l] = self.grad_flat[off_w:off_w + n].view_as(l.weight.data)
-            l.weight.grad = self.gW[l]
+            n = l.out_features * kp[l]
+            Wp = self.param_flat[off_w:off_w + n].view(l.out_features, kp[l])
+            Wp[:, :l.in_features].copy_(l.weight.data)
+            self.W[l] = Wp                                          # what the kernels see: [out, kp] contiguous
+            l.weight.data = Wp[:, :l.in_features]
+            self.gW[l] = self.grad_flat[off_w:off_w + n].view(l.out_features, kp[l])
+            l.weight.grad = self.gW[l][:, :l.in_features]
             off_w += n
             m = l.bias.numel()
             self.param_flat[off_b:off_b + m].copy_(l.bias.data)
@@ -150,6 +158,7 @@ class TrainEngine:
             self.gb[l] = self.grad_flat[off_b:off_b + m]
             l.bias.grad = self.gb[l]
             off_b += m
+        self.r_width = kp[top0]
 
     def _buffers(self, B):
         if B in self._bufs:
@@ -160,8 +169,9 @@ class TrainEngine:
         b = dict()
         b["feat"] = torch.empty(B, F, D, dtype=f32, device=dev)
         b["dfeat"] = torch.empty(B, F, D, dtype=f32, device=dev)
-        b["R"] = torch.empty(B, D + npairs, dtype=f32, device=dev)
-        b["dR"] = torch.empty(B, D + npairs, dtype=f32, device=dev)
+        assert self.r_width >= D + npairs
+        b["R"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)      # pad column (if any) stays zero
+        b["dR"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
         # activations / gradients of the hidden layers
         b["bot_y"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.bot[:-1]]
         b["bot_dy"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.bot[:-1]]
@@ -170,7 +180,7 @@ class TrainEngine:
         b["loss"] = torch.zeros(65, dtype=f32, device=dev)
         work = 0
         for l, _ in self.bot + self.top:
-            work = max(work, ops.linear_bwd_work(B, l.out_features, l.in_features, dev).numel())
+            work = max(work, ops.linear_bwd_work(B, l.out_features, self.W[l].shape[1], dev).numel())
         b["lin_work"] = torch.empty(work, dtype=torch.uint8, device=dev)
         self._bufs[B] = b
         return b
@@ -291,7 +301,7 @@ class TrainEngine:
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
             y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
-            ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
+            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             bot_acts.append(y)
             cur = y
         # the gather runs alone on the main stream (it is the HBM-roofline kernel: nothing competes for bandwidth)
@@ -313,7 +323,7 @@ class TrainEngine:
         top_acts = [R]
         for i, (l, act) in enumerate(self.top):
             y = buf["top_y"][i]
-            ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
+            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             top_acts.append(y)
             cur = y
         Z = cur
@@ -323,7 +333,7 @@ class TrainEngine:
         for i in reversed(range(len(self.top))):
             l, act = self.top[i]
             dX = dR if i == 0 else buf["top_dy"][i - 1]
-            ops.linear_bwd(top_acts[i], l.weight.data, top_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
+            ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
                            buf["lin_work"])
             dY = dX
         ops.interact_bwd(feat, dR, self.itself, dfeat)
@@ -344,7 +354,7 @@ class TrainEngine:
         for i in reversed(range(len(self.bot))):
             l, act = self.bot[i]
             dX = None if i == 0 else buf["bot_dy"][i - 1]
-            ops.linear_bwd(bot_acts[i], l.weight.data, bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
+            ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
                            buf["lin_work"])
             dY = dX
         if next_idx is None:

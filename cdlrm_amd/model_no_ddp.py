@@ -394,6 +394,13 @@ def _linears(seq) -> List[nn.Linear]:
     return [l for l in seq if isinstance(l, nn.Linear)]
 
 
+def _dense_weight(l: nn.Linear) -> torch.Tensor:
+    """[out, in] contiguous weight for the kernels.  After a TrainEngine has taken the module over, layer.weight can be
+    a strided view of the engine's padded flat storage; the autograd surface then works on a packed copy."""
+    w = l.weight.data
+    return w if w.is_contiguous() else w.contiguous()
+
+
 class _DlrmDenseFn(torch.autograd.Function):
     """Whole dense forward/backward on the HIP kernels: bottom MLP -> (writes feature 0 of the packed
     operand) -> dot interaction -> top MLP.  One autograd node instead of ~20."""
@@ -470,7 +477,7 @@ class DLRM_Net(nn.Module):
                 y = out_last
             else:
                 y = torch.empty(cur.shape[0], l.out_features, dtype=torch.float32, device=cur.device)
-            ops.linear_fwd(cur, l.weight.data, l.bias.data, y, act)
+            ops.linear_fwd(cur, _dense_weight(l), l.bias.data, y, act)
             acts.append(y)
             cur = y
         return acts
@@ -484,10 +491,10 @@ class DLRM_Net(nn.Module):
             key = (B, N, K)
             if key not in self._work:
                 self._work[key] = ops.linear_bwd_work(B, N, K, dY.device)
-            dW = torch.empty_like(l.weight.data)
+            dW = torch.empty(l.out_features, l.in_features, dtype=torch.float32, device=dY.device)
             db = torch.empty_like(l.bias.data)
             dX = torch.empty(B, K, dtype=torch.float32, device=dY.device) if (i > 0 or need_dx) else None
-            ops.linear_bwd(acts[i], l.weight.data, acts[i + 1], dY, dX, dW, db, act, self._work[key])
+            ops.linear_bwd(acts[i], _dense_weight(l), acts[i + 1], dY, dX, dW, db, act, self._work[key])
             grads[2 * i], grads[2 * i + 1] = dW, db
             dY = dX
         return dY, grads

@@ -170,13 +170,14 @@ def agg_scatter(ctx, rows, count, buf, cap, stream=None):
 
 
 def interact_fwd(feat, itself, R, stream=None):
-    R.copy_(O.interact_features(feat[:, 0, :], [feat[:, k, :] for k in range(1, feat.shape[1])], "dot", itself))
+    out = O.interact_features(feat[:, 0, :], [feat[:, k, :] for k in range(1, feat.shape[1])], "dot", itself)
+    R[:, :out.shape[1]].copy_(out)          # R may carry zero pad columns (row pitch rounded up to 4)
 
 
 def interact_bwd(feat, dR, itself, dfeat, stream=None):
     f = feat.detach().clone().requires_grad_(True)
     out = O.interact_features(f[:, 0, :], [f[:, k, :] for k in range(1, f.shape[1])], "dot", itself)
-    out.backward(dR)
+    out.backward(dR[:, :out.shape[1]])
     dfeat.copy_(f.grad)
 
 

@@ -15,6 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, name, host_shared, ret):
+    try:
+        _worker_body(rank, world, port, name, host_shared, ret)
+    except BaseException as e:      # a dead worker must fail the test, not hang it
+        import traceback
+        ret.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+def _worker_body(rank, world, port, name, host_shared, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -74,7 +83,11 @@ def test_two_ranks_one_gpu_match_reference(golden, name, port):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(ret.get(timeout=600) for _ in range(2))
+    got = {}
+    for _ in range(2):
+        r, payload = ret.get(timeout=300)
+        assert "error" not in payload, payload["error"]
+        got[r] = payload
     for p in procs:
         p.join(timeout=60)
     for r in range(2):

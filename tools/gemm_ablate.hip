@@ -32,10 +32,10 @@ int main(int argc, char** argv) {
         for (int tn = 2; tn >= 1; --tn) {
             dim3 grid((N + 64 * tn - 1) / (64 * tn), (M + 64 * tm - 1) / (64 * tm), 1);
             auto launch = [&]() {
-                if (tm == 2 && tn == 2) hipLaunchKernelGGL((k_gemm<true, true, 2, 2>), grid, dim3(256), 0, 0, g);
-                else if (tm == 2) hipLaunchKernelGGL((k_gemm<true, true, 2, 1>), grid, dim3(256), 0, 0, g);
-                else if (tn == 2) hipLaunchKernelGGL((k_gemm<true, true, 1, 2>), grid, dim3(256), 0, 0, g);
-                else hipLaunchKernelGGL((k_gemm<true, true, 1, 1>), grid, dim3(256), 0, 0, g);
+                if (tm == 2 && tn == 2) hipLaunchKernelGGL((k_gemm<true, true, 2, 2, true, true>), grid, dim3(256), 0, 0, g);
+                else if (tm == 2) hipLaunchKernelGGL((k_gemm<true, true, 2, 1, true, true>), grid, dim3(256), 0, 0, g);
+                else if (tn == 2) hipLaunchKernelGGL((k_gemm<true, true, 1, 2, true, true>), grid, dim3(256), 0, 0, g);
+                else hipLaunchKernelGGL((k_gemm<true, true, 1, 1, true, true>), grid, dim3(256), 0, 0, g);
             };
             for (int i = 0; i < 5; ++i) launch();
             hipEventRecord(e0);
