@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_act_grad(const float* __restrict__ Y, i
 // Fused activation backward + bias-gradient partial sums: dZ = dY * act'(Y) written in place, and
 // part[chunk][n] = sum over the chunk's CS_ROWS rows of dZ[:, n].  One wave covers 64 consecutive
 // columns of a row (256-B coalesced), 4 row lanes per block, fixed summation order.
-#define CS_ROWS 256
+#define CS_ROWS 64
 __global__ void __launch_bounds__(256) k_actgrad_colsum(const float* __restrict__ Y, int64_t ld_y,
                                                         float* __restrict__ dY, int64_t ld_dy, int64_t M, int N,
                                                         int act, float* __restrict__ part) {
@@ -71,12 +71,26 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
                                                       const float* __restrict__ partB, int64_t countB, int splitsB,
                                                       float* __restrict__ outB) {
     const bool jobA = (int)blockIdx.x < gxa;
-    const float* part = jobA ? partA : partB;
-    const int64_t count = jobA ? countA : countB;
-    const int splits = jobA ? splitsA : splitsB;
-    float* out = jobA ? outA : outB;
-    const int64_t bid = jobA ? blockIdx.x : blockIdx.x - gxa;
-    const int64_t nblk = jobA ? gxa : gridDim.x - gxa;
+    if (!jobA) {
+        // job B (bias gradient): few elements, many partials -> 4 lanes per element, each summing every 4th
+        // partial, combined in a fixed order through LDS
+        __shared__ float red[4][64];
+        const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
+        const int64_t e = (int64_t)(blockIdx.x - gxa) * 64 + c;
+        float s = 0.f;
+        if (e < countB)
+            for (int z = sub; z < splitsB; z += 4) s += partB[(int64_t)z * countB + e];
+        red[sub][c] = s;
+        __syncthreads();
+        if (sub == 0 && e < countB) outB[e] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        return;
+    }
+    const float* part = partA;
+    const int64_t count = countA;
+    const int splits = splitsA;
+    float* out = outA;
+    const int64_t bid = blockIdx.x;
+    const int64_t nblk = gxa;
     for (int64_t e = bid * blockDim.x + threadIdx.x; e < count; e += nblk * blockDim.x) {
         float s = 0.f;
         int z = 0;
@@ -146,7 +160,7 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
             gxa = cdiv((int64_t)N * K, 256);
             if (gxa > 2048) gxa = 2048;
         }
-        const int64_t gxb = db ? cdiv(N, 256) : 0;
+        const int64_t gxb = db ? cdiv(N, 64) : 0;
         if (gxa + gxb > 0)
             hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)(gxa + gxb)), dim3(256), 0, s, slabs, (int64_t)N * K, zs, dW,
                                (int)gxa, cs, (int64_t)N, ny, db);

@@ -285,7 +285,12 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
         int64_t fx = cdiv((int64_t)(n < ctx->aux ? n : ctx->aux) * D4, 256);
         // PCIe-bound (~50 GB/s): ~100 waves in flight saturate the link; a larger grid only steals memory-pipeline
         // slots from the kernels this fill runs beside (measured: a concurrent GEMM slowed 4x under 256 blocks/table)
-        if (fx > 8) fx = 8;
+        static int fill_cap = -1;
+        if (fill_cap < 0) {
+            const char* e = getenv("CDLRM_FILL_BLOCKS");     // development switch
+            fill_cap = e ? atoi(e) : 8;
+        }
+        if (fx > fill_cap) fx = fill_cap;
         hipLaunchKernelGGL(k_fill_aux, dim3((unsigned)fx, (unsigned)ctx->T), dim3(256), 0, s, ctx->d_tab, ctx->ways, D4,
                            reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, n, ld_idx, miss_pos,
                            miss_count);
