@@ -11,7 +11,7 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
                                 int64_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     CDLRM_REQUIRE(X && W && Y && M >= 0 && N >= 1 && K >= 1 && ld_x >= K && ld_y >= N, "bad argument");
     if (M == 0) return 0;
-    GemmArgs g;
+    GemmArgs g = gemm_args();
     g.A = X; g.lda = ld_x; g.B = W; g.ldb = K; g.C = Y; g.ldc = ld_y; g.slab = 0;
     g.M = M; g.N = N; g.K = K; g.kchunk = K; g.bias = bias; g.act = act;
     g.vecA = aligned16(X) && ld_x % 4 == 0 && K % 4 == 0;
@@ -20,6 +20,9 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
 }
 
 // ---- backward helpers -----------------------------------------------------------------------------
+// Stand-alone activation backward (dZ = dY * act'(Y) in place).  The training step does not need it: there the
+// activation backward of layer l-1 rides in the epilogue of layer l's dgrad GEMM (x_act) and the loss kernel
+// applies the final sigmoid's; this kernel serves callers that hand over post-activation gradients.
 __global__ void __launch_bounds__(256) k_act_grad(const float* __restrict__ Y, int64_t ld_y, float* __restrict__ dY,
                                                   int64_t ld_dy, int64_t M, int N, int act) {
     const int64_t total = M * N;
@@ -32,36 +35,6 @@ __global__ void __launch_bounds__(256) k_act_grad(const float* __restrict__ Y, i
         else if (act == 2) d = d * ((1.0f - y) * y);      // sigmoid_backward
         dY[m * ld_dy + n] = d;
     }
-}
-
-// Fused activation backward + bias-gradient partial sums: dZ = dY * act'(Y) written in place, and
-// part[chunk][n] = sum over the chunk's CS_ROWS rows of dZ[:, n].  One wave covers 64 consecutive
-// columns of a row (256-B coalesced), 4 row lanes per block, fixed summation order.
-#define CS_ROWS 64
-__global__ void __launch_bounds__(256) k_actgrad_colsum(const float* __restrict__ Y, int64_t ld_y,
-                                                        float* __restrict__ dY, int64_t ld_dy, int64_t M, int N,
-                                                        int act, float* __restrict__ part) {
-    __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + c;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
-    float s = 0.f;
-    if (n < N) {
-#pragma unroll 4
-        for (int64_t m = r0 + rg; m < r1; m += 4) {
-            float d = dY[m * ld_dy + n];
-            if (act != 0) {
-                const float y = Y[m * ld_y + n];
-                if (act == 1) d = y > 0.f ? d : 0.f;              // threshold_backward
-                else d = d * ((1.0f - y) * y);                    // sigmoid_backward
-                dY[m * ld_dy + n] = d;
-            }
-            s += d;
-        }
-    }
-    red[rg][c] = s;
-    __syncthreads();
-    if (rg == 0 && n < N && part) part[(int64_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
 // Two reductions in one launch (dW slabs and the bias-gradient partials of the same layer): blocks [0, gxa) work
@@ -104,7 +77,11 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
+// Weight-gradient contraction (over the batch) is cut into slabs when the batch is long: small batches go to the
+// LDS-free kernel un-split (no reduction launch at all), long ones to the tiled kernel with ~1024 workgroups.
+#define WGRAD_DIRECT_MAX_M 2048
 static int wgrad_splits(int64_t M, int N, int K) {
+    if (M <= WGRAD_DIRECT_MAX_M) return 1;
     const int64_t tiles = cdiv(N, 64) * cdiv(K, 64);    // the 64x64 tile launch_gemm picks for these shapes
     int64_t s = cdiv(1024, tiles);                    // aim at ~4 workgroups per CU
     const int64_t smax = cdiv(M, 8 * GBK);
@@ -114,56 +91,58 @@ static int wgrad_splits(int64_t M, int N, int K) {
 }
 
 extern "C" uint64_t cdlrm_linear_bwd_work_bytes(int64_t M, int32_t N, int32_t K) {
-    const uint64_t slabs = (uint64_t)wgrad_splits(M, N, K) * N * K * 4;
-    const uint64_t cs = (uint64_t)cdiv(M, CS_ROWS) * N * 4;
+    const uint64_t splits = (uint64_t)wgrad_splits(M, N, K);
+    const uint64_t slabs = splits * N * K * 4;
+    const uint64_t cs = splits * N * 4;
     return ((slabs + 255) & ~(uint64_t)255) + ((cs + 255) & ~(uint64_t)255) + 256;
 }
 
 extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y, float* dY,
                                 int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db, int64_t M, int32_t N,
-                                int32_t K, int32_t act, void* work, void* stream) {
+                                int32_t K, int32_t act, int32_t x_act, void* work, void* stream) {
     CDLRM_REQUIRE(X && W && dY && dW && work && M >= 1 && N >= 1 && K >= 1, "bad argument");
     CDLRM_REQUIRE(act == 0 || Y, "activation backward needs Y");
+    CDLRM_REQUIRE(act >= 0 && act <= 2 && x_act >= 0 && x_act <= 2, "bad activation code");
     CDLRM_REQUIRE(((uintptr_t)work & 255) == 0, "work must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int splits = wgrad_splits(M, N, K);
     float* slabs = (float*)work;
     float* cs = (float*)((char*)work + ((((uint64_t)splits * N * K * 4) + 255) & ~(uint64_t)255));
-    const int ny = (int)cdiv(M, CS_ROWS);
-    if (act != 0 || db) {     // dZ = dY * act'(Y) in place, fused with the bias-gradient partial sums
-        hipLaunchKernelGGL(k_actgrad_colsum, dim3((unsigned)cdiv(N, 64), (unsigned)ny), dim3(256), 0, s, Y, ld_y, dY,
-                           ld_dy, M, N, act, db ? cs : nullptr);
+    if (act != 0) {     // dZ = dY * act'(Y) in place
+        const int64_t nb = cdiv(M * N, 256), blocks = nb < 2048 ? nb : 2048;
+        hipLaunchKernelGGL(k_act_grad, dim3((unsigned)blocks), dim3(256), 0, s, Y, ld_y, dY, ld_dy, M, N, act);
     }
-    if (dX) {   // dX[M,K] = dZ[M,N] W[N,K]
-        GemmArgs g;
+    if (dX) {   // dX[M,K] = dZ[M,N] W[N,K]  (* act'(X) when X is the activation output of the layer below)
+        GemmArgs g = gemm_args();
         g.A = dY; g.lda = ld_dy; g.B = W; g.ldb = K; g.C = dX; g.ldc = ld_dx; g.slab = 0;
         g.M = M; g.N = K; g.K = N; g.kchunk = N; g.bias = nullptr; g.act = 0;
         g.vecA = aligned16(dY) && ld_dy % 4 == 0 && N % 4 == 0;
         g.vecB = aligned16(W) && K % 4 == 0;
+        g.mask = X; g.ldmask = ld_x; g.mask_act = x_act;
         int rc = launch_gemm<true, false>(g, 1, s);
         if (rc) return rc;
     }
-    // dW[N,K] = dZ[M,N]^T X[M,K], split over M into slabs summed in slab order
+    // dW[N,K] = dZ[M,N]^T X[M,K], split over M into slabs summed in slab order; the first column panel of the
+    // same GEMM sums dZ over the batch (bias gradient)
     {
-        GemmArgs g;
-        g.A = dY; g.lda = ld_dy; g.B = X; g.ldb = ld_x; g.C = splits > 1 ? slabs : dW; g.ldc = K;
+        GemmArgs g = gemm_args();
+        g.A = dY; g.lda = ld_dy; g.B = X; g.ldb = ld_x; g.ldc = K;
         g.slab = (int64_t)N * K;
         g.M = N; g.N = K; g.K = M; g.kchunk = cdiv(cdiv(M, splits), GBK) * GBK; g.bias = nullptr; g.act = 0;
         g.vecA = aligned16(dY) && ld_dy % 4 == 0 && N % 4 == 0;
         g.vecB = aligned16(X) && ld_x % 4 == 0 && K % 4 == 0;
-        const int zs = (int)cdiv(M, g.kchunk);
+        const int zs = (int)cdiv(M, g.kchunk);      // <= splits
+        g.C = zs > 1 ? slabs : dW;
+        g.colsum = db ? (zs > 1 ? cs : db) : nullptr;
         int rc = launch_gemm<false, false>(g, zs, s);
         if (rc) return rc;
-        // one launch sums the dW slabs (if the contraction was split) and the bias-gradient partials
-        int64_t gxa = 0;
-        if (splits > 1) {
-            gxa = cdiv((int64_t)N * K, 256);
+        if (zs > 1) {   // one launch sums the dW slabs and the bias-gradient partials
+            int64_t gxa = cdiv((int64_t)N * K, 256);
             if (gxa > 2048) gxa = 2048;
-        }
-        const int64_t gxb = db ? cdiv(N, 64) : 0;
-        if (gxa + gxb > 0)
+            const int64_t gxb = db ? cdiv(N, 64) : 0;
             hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)(gxa + gxb)), dim3(256), 0, s, slabs, (int64_t)N * K, zs, dW,
-                               (int)gxa, cs, (int64_t)N, ny, db);
+                               (int)gxa, cs, (int64_t)N, zs, db);
+        }
     }
     CDLRM_LAUNCH_CHECK();
     return 0;
@@ -219,7 +198,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd(const float* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ feat, const float* __restrict__ dR,
-                                                      int64_t ld_r, int64_t B, int F, int D, int itself,
+                                                      int64_t ld_r, int64_t B, int F, int D, int itself, int x_act,
                                                       float* __restrict__ dfeat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -278,7 +257,16 @@ __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (i < F) out[i * D + col] = acc[r] + (i == 0 ? gx[col] : 0.f);
+                    if (i < F) {
+                        float v = acc[r];
+                        if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
+                            v += gx[col];
+                            const float y = Ts[col];
+                            if (x_act == 1) v = y > 0.f ? v : 0.f;
+                            else if (x_act == 2) v = v * ((1.0f - y) * y);
+                        }
+                        out[i * D + col] = v;
+                    }
                 }
             }
         }
@@ -304,7 +292,7 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
 }
 
 extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
-                                  int32_t itself, float* dfeat, void* stream) {
+                                  int32_t itself, int32_t x_act, float* dfeat, void* stream) {
     CDLRM_REQUIRE(feat && dR && dfeat && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape");
     CDLRM_REQUIRE(aligned16(feat), "alignment");
     if (B == 0) return 0;
@@ -319,7 +307,7 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     int64_t gx = cdiv(B, 4);
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(k_interact_bwd, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, feat, dR, ld_r, B, F, D,
-                       itself, dfeat);
+                       itself, x_act, dfeat);
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -328,7 +316,8 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
 // K11 BCELoss(mean) on the sigmoid output + its gradient; K12 dense SGD
 // =================================================================================================
 __global__ void __launch_bounds__(256) k_bce_partial(const float* __restrict__ Z, const float* __restrict__ T, int64_t n,
-                                                     float* __restrict__ part, float* __restrict__ dZ) {
+                                                     float* __restrict__ part, float* __restrict__ dZ,
+                                                     int sigmoid_bwd) {
     __shared__ float red[4];
     float s = 0.f;
     const float inv_n = 1.0f / (float)n;
@@ -338,13 +327,45 @@ __global__ void __launch_bounds__(256) k_bce_partial(const float* __restrict__ Z
         const float l1 = fmaxf(logf(z), -100.f), l0 = fmaxf(log1pf(-z), -100.f);
         s += (t - 1.0f) * l0 - t * l1;
         // binary_cross_entropy_backward: (z - t) / max((1 - z) z, 1e-12) * grad, grad = 1/n
-        if (dZ) dZ[i] = (z - t) / fmaxf((1.0f - z) * z, 1e-12f) * inv_n;
+        if (dZ) {
+            float d = (z - t) / fmaxf((1.0f - z) * z, 1e-12f) * inv_n;
+            if (sigmoid_bwd) d = d * ((1.0f - z) * z);      // sigmoid_backward of the layer that produced z
+            dZ[i] = d;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// the whole loss in ONE workgroup (n up to a few 10k: a training batch) -- one launch instead of two
+__global__ void __launch_bounds__(1024) k_bce_one(const float* __restrict__ Z, const float* __restrict__ T, int64_t n,
+                                                  float* __restrict__ loss, float* __restrict__ dZ, int sigmoid_bwd) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float z = Z[i], t = T[i];
+        const float l1 = fmaxf(logf(z), -100.f), l0 = fmaxf(log1pf(-z), -100.f);
+        s += (t - 1.0f) * l0 - t * l1;
+        if (dZ) {
+            float d = (z - t) / fmaxf((1.0f - z) * z, 1e-12f) * inv_n;
+            if (sigmoid_bwd) d = d * ((1.0f - z) * z);
+            dZ[i] = d;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        loss[0] = tot / (float)n;
+    }
 }
 
 __global__ void __launch_bounds__(64) k_bce_final(const float* __restrict__ part, int nparts, int64_t n,
@@ -357,11 +378,17 @@ __global__ void __launch_bounds__(64) k_bce_final(const float* __restrict__ part
 }
 
 #define BCE_PARTS 64
-extern "C" int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* loss_out, float* dZ, void* stream) {
+extern "C" int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* loss_out, float* dZ,
+                                 int32_t sigmoid_bwd, void* stream) {
     CDLRM_REQUIRE(Z && target && loss_out && n >= 1, "bad argument");
     // partial sums live behind the loss word: loss_out must have room for 1 + 64 floats
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bce_partial, dim3(BCE_PARTS), dim3(256), 0, s, Z, target, n, loss_out + 1, dZ);
+    if (n <= 32768) {
+        hipLaunchKernelGGL(k_bce_one, dim3(1), dim3(1024), 0, s, Z, target, n, loss_out, dZ, (int)sigmoid_bwd);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(k_bce_partial, dim3(BCE_PARTS), dim3(256), 0, s, Z, target, n, loss_out + 1, dZ, (int)sigmoid_bwd);
     hipLaunchKernelGGL(k_bce_final, dim3(1), dim3(64), 0, s, loss_out + 1, BCE_PARTS, n, loss_out);
     CDLRM_LAUNCH_CHECK();
     return 0;

@@ -29,7 +29,17 @@ struct GemmArgs {
     int64_t M; int N; int64_t K; int64_t kchunk;
     const float* bias; int act;               // epilogue: + bias[n], 1 ReLU, 2 sigmoid
     int vecA, vecB;                           // 16-byte loads legal
+    // fused backward pieces
+    const float* mask; int64_t ldmask; int mask_act;   // epilogue: C *= act'(mask[m,n]) (1 ReLU output, 2 sigmoid output)
+    float* colsum;                            // !A_KC only: colsum[z*M + m] = sum over this split's k of A(m,k)
+    int vecC;                                 // 16-byte stores legal (k_gemm_direct)
 };
+
+static inline GemmArgs gemm_args() {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    return g;
+}
 
 // Operand staging.  Steady-state tiles (FULLK) are loaded with NO predicate: rows past the matrix edge are
 // clamped to the last valid row (their products land in output rows/columns that are never stored), so the
@@ -121,6 +131,10 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 ra[BM * GBK / 1024], rb[BN * GBK / 1024];
+    // bias gradient fused into the weight-gradient GEMM: the first column panel also sums its A tiles (= dZ^T) over
+    // the contraction (VALU only, under the MFMAs)
+    const bool do_colsum = !A_KC && g.colsum != nullptr && bx == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     tile_load<A_KC, BM, VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
     tile_load<B_KC, BN, VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
 #ifndef GEMM_ABLATE
@@ -135,6 +149,15 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
             tile_store<A_KC, BM>(As, ra, k0, kend);
             tile_store<B_KC, BN>(Bs, rb, k0, kend);
             __syncthreads();
+        }
+        if (!A_KC && do_colsum) {       // wave-uniform; no loads inside
+#pragma unroll
+            for (int i = 0; i < BM * GBK / 1024; ++i) {
+                const int c = (threadIdx.x + i * 256) / (BM / 4);
+                const bool ok = k0 + c < kend;
+                csum.x += ok ? ra[i].x : 0.f; csum.y += ok ? ra[i].y : 0.f;
+                csum.z += ok ? ra[i].z : 0.f; csum.w += ok ? ra[i].w : 0.f;
+            }
         }
         if (!(GEMM_ABLATE & 1)) {   // unconditional: past the last tile the clamped addresses just re-read valid data
             tile_load<A_KC, BM, VA>(g.A, g.lda, m0, g.M, k0 + GBK, kend, ra);
@@ -178,6 +201,20 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
                 }
         }
     }
+    if (!A_KC && do_colsum) {
+        // the BM/4 threads with equal (tid % (BM/4)) hold the same 4 rows for different contraction indices:
+        // combine them through LDS in a fixed order
+        __syncthreads();                        // every wave is done reading As
+        const int q = threadIdx.x / (BM / 4), r4 = (threadIdx.x % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(As + q * BM + r4) = csum;
+        __syncthreads();
+        if (threadIdx.x < BM && m0 + threadIdx.x < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 1024 / BM; ++qq) s += As[qq * BM + threadIdx.x];
+            g.colsum[(int64_t)bz * g.M + m0 + threadIdx.x] = s;
+        }
+    }
     float* C = g.C + (int64_t)bz * g.slab;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -193,9 +230,146 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
                 float v = acc[i][j][r] + bv;
                 if (g.act == 1) v = v > 0.f ? v : 0.f;
                 else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+                if (g.mask_act) {               // activation backward of the layer below, fused into the dgrad
+                    const float x = g.mask[row * g.ldmask + col];
+                    v = g.mask_act == 1 ? (x > 0.f ? v : 0.f) : v * ((1.0f - x) * x);
+                }
                 C[row * g.ldc + col] = v;
             }
         }
+}
+
+// ---- small problems: LDS-free GEMM -------------------------------------------------------------------
+// When the tiled kernel's grid cannot fill the chip (M <= ~2048 with these layer widths: 128 workgroups, one wave per
+// SIMD, every K tile paying a full load latency -- 20 us for 0.5 GFLOP) the work is re-cut finer: one workgroup per
+// 32x32 output tile, its 4 waves splitting the CONTRACTION four ways, operands loaded from global/L2 straight into
+// the MFMA operand layout (lane = row, 4 consecutive contraction indices per lane half), 64 contraction indices per
+// batch of loads, two batches in flight.  The 4 partial tiles meet in LDS and are summed in wave order (fixed
+// order: reproducible), then bias / activation / mask and a row-contiguous store.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void direct_load(const float* __restrict__ p, int64_t ld, int64_t k, int64_t kmax, int lk,
+                                            float4 (&v)[8]) {
+    // straight-line, clamped addresses (see tile_load)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int64_t kk = k + 8 * s + 4 * lk;
+        if (KC) {
+            if (VEC) {
+                v[s] = *reinterpret_cast<const float4*>(p + min(kk, kmax - 4));
+            } else {
+                v[s] = make_float4(p[min(kk, kmax - 1)], p[min(kk + 1, kmax - 1)], p[min(kk + 2, kmax - 1)],
+                                   p[min(kk + 3, kmax - 1)]);
+            }
+        } else {
+            v[s] = make_float4(p[min(kk, kmax - 1) * ld], p[min(kk + 1, kmax - 1) * ld], p[min(kk + 2, kmax - 1) * ld],
+                               p[min(kk + 3, kmax - 1) * ld]);
+        }
+    }
+}
+
+__device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&b)[8], int64_t k, int64_t kw1, int lk,
+                                           f32x16& acc, float& cs) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int64_t kk = k + 8 * s + 4 * lk;
+        // zeroing ONE operand past the end of this wave's contraction range is enough
+        const float ax = kk + 0 < kw1 ? a[s].x : 0.f, ay = kk + 1 < kw1 ? a[s].y : 0.f;
+        const float az = kk + 2 < kw1 ? a[s].z : 0.f, aw = kk + 3 < kw1 ? a[s].w : 0.f;
+        cs += (ax + ay) + (az + aw);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, b[s].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, b[s].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(az, b[s].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, b[s].w, acc, 0, 0, 0);
+    }
+}
+
+// LOOP = false: each wave's share of the contraction is <= 64 (one batch of loads, no loop)
+template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
+__global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
+    __shared__ float red[4][32][33];
+    __shared__ float csr[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
+    const unsigned bx = wgid % gridDim.x, by = (wgid / gridDim.x) % gridDim.y, bz = wgid / (gridDim.x * gridDim.y);
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const int64_t kbeg = (int64_t)bz * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+    const int64_t kq = ((kend - kbeg + 31) / 32) * 8;        // a quarter of the range, rounded up to 8
+    const int64_t kw0 = kbeg + wave * kq, kw1 = min(kend, kw0 + kq);
+    const int64_t am = min(m0 + lr, g.M - 1), bn = min(n0 + lr, (int64_t)g.N - 1);
+    const float* pa = A_KC ? g.A + am * g.lda : g.A + am;
+    const float* pb = B_KC ? g.B + bn * g.ldb : g.B + bn;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float cs = 0.f;
+    float4 a0[8], b0[8];
+    direct_load<A_KC, VA>(pa, g.lda, kw0, g.K, lk, a0);
+    direct_load<B_KC, VB>(pb, g.ldb, kw0, g.K, lk, b0);
+    if (LOOP) {
+        // Both MFMA batches of an iteration are UNCONDITIONAL (indices past kw1 are zeroed in direct_mma): with a
+        // condition on the second batch the compiler sinks its loads into the conditional block, right in front
+        // of their use, and the double buffering is gone (seen in the ISA).
+        float4 a1[8], b1[8];
+        // sched_barrier: the machine scheduler otherwise drags each load down to just before its use (fewer
+        // live registers, 2-4 loads in flight, one exposed latency per step -- seen in the ISA)
+        for (int64_t k = kw0; k < kw1; k += 128) {
+            direct_load<A_KC, VA>(pa, g.lda, k + 64, g.K, lk, a1);
+            direct_load<B_KC, VB>(pb, g.ldb, k + 64, g.K, lk, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            direct_mma(a0, b0, k, kw1, lk, acc, cs);
+            __builtin_amdgcn_sched_barrier(0);
+            direct_load<A_KC, VA>(pa, g.lda, k + 128, g.K, lk, a0);
+            direct_load<B_KC, VB>(pb, g.ldb, k + 128, g.K, lk, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            direct_mma(a1, b1, k + 64, kw1, lk, acc, cs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        direct_mma(a0, b0, kw0, kw1, lk, acc, cs);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[r];
+    if (!A_KC && g.colsum != nullptr && bx == 0) {
+        cs += __shfl_xor(cs, 32);
+        if (lk == 0) csr[wave][lr] = cs;
+    }
+    __syncthreads();
+    if (!A_KC && g.colsum != nullptr && bx == 0 && threadIdx.x < 32 && m0 + threadIdx.x < g.M)
+        g.colsum[(int64_t)bz * g.M + m0 + threadIdx.x] =
+            ((csr[0][threadIdx.x] + csr[1][threadIdx.x]) + csr[2][threadIdx.x]) + csr[3][threadIdx.x];
+    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const int64_t gm = m0 + row;
+    if (gm >= g.M) return;
+    float* C = g.C + (int64_t)bz * g.slab + gm * g.ldc;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t gn = n0 + c4 + u;
+        float x = ((red[0][row][c4 + u] + red[1][row][c4 + u]) + red[2][row][c4 + u]) + red[3][row][c4 + u];
+        if (gn < g.N) {
+            if (g.bias) x += g.bias[gn];
+            if (g.act == 1) x = x > 0.f ? x : 0.f;
+            else if (g.act == 2) x = 1.0f / (1.0f + expf(-x));
+            if (g.mask_act) {
+                const float y = g.mask[gm * g.ldmask + gn];
+                x = g.mask_act == 1 ? (y > 0.f ? x : 0.f) : x * ((1.0f - y) * y);
+            }
+        }
+        v[u] = x;
+    }
+    if (g.vecC && n0 + c4 + 3 < g.N) {
+        *reinterpret_cast<float4*>(C + n0 + c4) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (n0 + c4 + u < g.N) C[n0 + c4 + u] = v[u];
+    }
 }
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -224,8 +398,45 @@ static void launch_gemm_v(const GemmArgs& g, dim3 grid, hipStream_t s) {
     else hipLaunchKernelGGL((k_gemm<A_KC, B_KC, TM, TN, false, false>), grid, dim3(256), 0, s, g);
 }
 
+// the tiled kernel needs this many 64x64 workgroups to be the better choice (2 per CU); below it the
+// LDS-free kernel's 4x finer cut wins.  CDLRM_GEMM_DIRECT=0 / 1 forces one or the other (experiments).
+static inline bool gemm_use_direct(int64_t M, int64_t N, int64_t splits) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("CDLRM_GEMM_DIRECT");
+        forced = e ? atoi(e) : -1;
+    }
+    if (forced >= 0) return forced != 0;
+    return cdiv(M, 64) * cdiv(N, 64) * splits < 512;
+}
+
+template <bool A_KC, bool B_KC>
+static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
+    g.vecC = aligned16(g.C) && g.ldc % 4 == 0 && g.slab % 4 == 0;
+    const bool va = A_KC && g.vecA, vb = B_KC && g.vecB;     // only contraction-contiguous operands use 16-B loads
+    dim3 grid((unsigned)cdiv(g.N, 32), (unsigned)cdiv(g.M, 32), (unsigned)splits);
+    const int64_t klen = g.kchunk < g.K ? g.kchunk : g.K;
+    const bool loop = cdiv(klen, 32) * 8 > 64;                // per-wave share of the contraction > one batch
+#define CDLRM_DIRECT(VA_, VB_)                                                                              \
+    do {                                                                                                    \
+        if (loop) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, true>), grid, dim3(256), 0, s, g);   \
+        else hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, false>), grid, dim3(256), 0, s, g);       \
+    } while (0)
+    if (va && vb) CDLRM_DIRECT(A_KC, B_KC);
+    else if (va) CDLRM_DIRECT(A_KC, false);
+    else if (vb) CDLRM_DIRECT(false, B_KC);
+    else CDLRM_DIRECT(false, false);
+#undef CDLRM_DIRECT
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
+    if (g.K < 4) g.vecA = g.vecB = 0;
+    if (gemm_use_direct(g.M, g.N, splits)) {
+        launch_gemm_direct<A_KC, B_KC>(g, splits, s);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     int tm, tn;
     gemm_pick_tile(g.M, g.N, splits, &tm, &tn);
     if (g.N <= 32) tn = 1;

@@ -327,16 +327,25 @@ class TrainEngine:
             top_acts.append(y)
             cur = y
         Z = cur
-        ops.bce_fwd_bwd(Z, T, buf["loss"], buf["top_dy"][-1])
         # ---- backward ----
+        # No stand-alone activation-backward pass: every gradient buffer holds the PRE-activation gradient of its
+        # layer.  The loss kernel applies the last sigmoid's derivative, each dgrad GEMM applies the derivative of
+        # the activation that produced its input (x_act) in its epilogue, the interaction backward does the same
+        # for the bottom MLP's output, and the bias gradients are column sums taken inside the wgrad GEMMs.
+        last_act = self.top[-1][1]
+        ops.bce_fwd_bwd(Z, T, buf["loss"], buf["top_dy"][-1], sigmoid_bwd=(last_act == 2))
         dY = buf["top_dy"][-1]
         for i in reversed(range(len(self.top))):
             l, act = self.top[i]
+            if i == len(self.top) - 1 and act == 2:
+                act = 0                                      # already applied by the loss kernel
+            elif i < len(self.top) - 1:
+                act = 0                                      # applied by the dgrad epilogue of layer i+1
             dX = dR if i == 0 else buf["top_dy"][i - 1]
             ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
-                           buf["lin_work"])
+                           buf["lin_work"], x_act=(self.top[i - 1][1] if i > 0 else 0))
             dY = dX
-        ops.interact_bwd(feat, dR, self.itself, dfeat)
+        ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
         self.side.wait_stream(main)
@@ -354,8 +363,8 @@ class TrainEngine:
         for i in reversed(range(len(self.bot))):
             l, act = self.bot[i]
             dX = None if i == 0 else buf["bot_dy"][i - 1]
-            ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
-                           buf["lin_work"])
+            ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], 0,
+                           buf["lin_work"], x_act=(self.bot[i - 1][1] if i > 0 else 0))
             dY = dX
         if next_idx is None:
             main.wait_stream(self.side)      # full join (also what a hipGraph capture needs)

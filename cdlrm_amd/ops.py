@@ -259,10 +259,12 @@ def interact_fwd(feat: torch.Tensor, itself: bool, R: torch.Tensor, stream=None)
                                         stream_ptr(stream)))
 
 
-def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None):
+def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None, x_act: int = 0):
+    """x_act: activation that produced feature 0 (the bottom MLP's output); its gradient row then leaves as the
+    pre-activation gradient."""
     B, F, D = feat.shape
     check(_lib.lib().cdlrm_interact_bwd(feat.data_ptr(), dR.data_ptr(), dR.stride(0), B, F, D, int(bool(itself)),
-                                        dfeat.data_ptr(), stream_ptr(stream)))
+                                        int(x_act), dfeat.data_ptr(), stream_ptr(stream)))
 
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
@@ -281,18 +283,22 @@ def linear_bwd_work(M: int, N: int, K: int, device) -> torch.Tensor:
     return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
 
 
-def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=None):
+def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=None, x_act: int = 0):
+    """act: this layer's activation, applied backward to dY in place (0: dY already is the pre-activation
+    gradient).  x_act: the activation that produced X; dX then leaves as the layer below's pre-activation gradient."""
     M, K = X.shape
     N = W.shape[0]
     check(_lib.lib().cdlrm_linear_bwd(X.data_ptr(), X.stride(0), W.data_ptr(), ptr(Y), 0 if Y is None else Y.stride(0),
                                       dY.data_ptr(), dY.stride(0), ptr(dX), 0 if dX is None else dX.stride(0),
-                                      dW.data_ptr(), ptr(db), M, N, K, act, work.data_ptr(), stream_ptr(stream)))
+                                      dW.data_ptr(), ptr(db), M, N, K, act, int(x_act), work.data_ptr(),
+                                      stream_ptr(stream)))
 
 
-def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, dZ: Optional[torch.Tensor], stream=None):
+def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, dZ: Optional[torch.Tensor], stream=None,
+                sigmoid_bwd: bool = False):
     assert loss_buf.numel() >= 65
     check(_lib.lib().cdlrm_bce_fwd_bwd(Z.data_ptr(), target.data_ptr(), Z.numel(), loss_buf.data_ptr(), ptr(dZ),
-                                       stream_ptr(stream)))
+                                       1 if sigmoid_bwd else 0, stream_ptr(stream)))
 
 
 def scale_div(x: torch.Tensor, divisor: float, stream=None):

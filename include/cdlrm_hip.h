@@ -240,28 +240,37 @@ int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count,
 int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32_t itself,
                        float* R, int64_t ld_r, void* stream);
 /* dfeat[b] = (G + G^T) feat_b with G the strictly-lower (or lower) triangle filled from dR, plus dR's
- * first D columns added to feature 0. */
+ * first D columns added to feature 0.  x_act != 0: feature 0 is the output of an activation (1 ReLU,
+ * 2 sigmoid; the bottom MLP's last layer, model_no_ddp.py:262-266) and its gradient row is multiplied by
+ * act'(feat[b,0,:]) here, so the bottom MLP's backward starts from the pre-activation gradient. */
 int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F,
-                       int32_t D, int32_t itself, float* dfeat, void* stream);
+                       int32_t D, int32_t itself, int32_t x_act, float* dfeat, void* stream);
 
 /* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
  * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */
 int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y,
                      int64_t ld_y, int64_t M, int32_t N, int32_t K, int32_t act, void* stream);
-/* Backward of the same layer.  dY is overwritten in place by dZ = dY * act'(Y).
- * dX [M, K] ld_dx (may be NULL for the first layer), dW [N, K], db [N].
- * work: device scratch of cdlrm_linear_bwd_work_bytes(M, N, K) bytes (split-M partial slabs of dW,
- * summed in a fixed order: bitwise reproducible). */
+/* Backward of the same layer.  act != 0: dY is the gradient w.r.t. the layer's OUTPUT and is overwritten
+ * in place by dZ = dY * act'(Y); act == 0: dY already is dZ (Y may be NULL).
+ * dX [M, K] ld_dx (may be NULL for the first layer), dW [N, K], db [N] (may be NULL).
+ * x_act != 0: X is itself the output of an activation (1 ReLU, 2 sigmoid) and dX is multiplied by act'(X)
+ * in the GEMM epilogue, i.e. dX is then the dZ of the layer below (pass act = 0 there): the training
+ * step chains the layers this way so no stand-alone activation-backward pass touches HBM.
+ * work: device scratch of cdlrm_linear_bwd_work_bytes(M, N, K) bytes (split-M partial slabs of dW and of
+ * db, summed in a fixed order: bitwise reproducible). */
 uint64_t cdlrm_linear_bwd_work_bytes(int64_t M, int32_t N, int32_t K);
 int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y,
                      float* dY, int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db,
-                     int64_t M, int32_t N, int32_t K, int32_t act, void* work, void* stream);
+                     int64_t M, int32_t N, int32_t K, int32_t act, int32_t x_act, void* work,
+                     void* stream);
 
 /* BCELoss(mean) forward + backward on the sigmoid output (torch clamps log at -100):
  * loss_out device fp32 [65]: [0] = loss, [1..64] = partial sums (fixed-order, reproducible);
- * dZ[i] = (z - t) / (max((1 - z) z, 1e-12) * n), may be NULL. */
+ * dZ[i] = (z - t) / (max((1 - z) z, 1e-12) * n), may be NULL.  sigmoid_bwd != 0: Z came out of a
+ * sigmoid (sigmoid_top, main_no_ddp.py:358) and dZ is additionally multiplied by (1 - z) z, i.e. it is
+ * the gradient w.r.t. the last layer's pre-activation. */
 int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* loss_out, float* dZ,
-                      void* stream);
+                      int32_t sigmoid_bwd, void* stream);
 
 /* p -= lr * g over a flat fp32 buffer (optim.SGD without momentum, main_no_ddp.py:375, 415). */
 int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float lr, void* stream);

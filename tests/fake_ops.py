@@ -174,11 +174,16 @@ def interact_fwd(feat, itself, R, stream=None):
     R[:, :out.shape[1]].copy_(out)          # R may carry zero pad columns (row pitch rounded up to 4)
 
 
-def interact_bwd(feat, dR, itself, dfeat, stream=None):
+def _act_bwd(d, y, act):
+    return d * (y > 0) if act == 1 else d * ((1 - y) * y) if act == 2 else d
+
+
+def interact_bwd(feat, dR, itself, dfeat, stream=None, x_act=0):
     f = feat.detach().clone().requires_grad_(True)
     out = O.interact_features(f[:, 0, :], [f[:, k, :] for k in range(1, f.shape[1])], "dot", itself)
     out.backward(dR[:, :out.shape[1]])
     dfeat.copy_(f.grad)
+    dfeat[:, 0, :] = _act_bwd(dfeat[:, 0, :], feat[:, 0, :], x_act)
 
 
 def linear_fwd(X, W, b, Y, act, stream=None):
@@ -190,25 +195,25 @@ def linear_bwd_work(M, N, K, device):
     return torch.empty(1)
 
 
-def linear_bwd(X, W, Y, dY, dX, dW, db, act, work, stream=None):
+def linear_bwd(X, W, Y, dY, dX, dW, db, act, work, stream=None, x_act=0):
     if act == 1:
         dY.copy_(dY * (Y > 0))
     elif act == 2:
         dY.copy_(dY * ((1 - Y) * Y))
     if dX is not None:
-        dX.copy_(dY @ W)
+        dX.copy_(_act_bwd(dY @ W, X, x_act))
     dW.copy_(dY.t() @ X)
     if db is not None:
         db.copy_(dY.sum(0))
 
 
-def bce_fwd_bwd(Z, target, loss_buf, dZ, stream=None):
+def bce_fwd_bwd(Z, target, loss_buf, dZ, stream=None, sigmoid_bwd=False):
     z = Z.detach().clone().requires_grad_(True)
     l = torch.nn.functional.binary_cross_entropy(z, target, reduction="mean")
     l.backward()
     loss_buf[0] = l.detach()
     if dZ is not None:
-        dZ.copy_(z.grad)
+        dZ.copy_(_act_bwd(z.grad, Z, 2) if sigmoid_bwd else z.grad)
 
 
 def sgd_step(param, grad, lr, stream=None):

@@ -307,7 +307,8 @@ def test_dense_golden(ops, golden, itself):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(8192, 512, 13, 1), (1000, 256, 512, 1), (777, 1, 256, 2), (4096, 512, 479, 1),
-                                       (130, 70, 33, 0)])
+                                       (130, 70, 33, 0), (1024, 512, 480, 1), (2048, 128, 256, 1), (8192, 1, 256, 2),
+                                       (5000, 512, 512, 1), (3, 5, 2, 0), (1024, 512, 13, 1)])
 def test_linear_vs_torch_fp32(ops, M, N, K, act):
     """FP32-MFMA Linear fwd/bwd against a plain torch fp32 reference (CPU, float64 accumulate for the bound)."""
     rng = np.random.RandomState(M + N + K)
@@ -332,6 +333,65 @@ def test_linear_vs_torch_fp32(ops, M, N, K, act):
     np.testing.assert_allclose(dX.cpu().numpy(), (dZ @ W.double()).float().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dW.cpu().numpy(), (dZ.t() @ X.double()).float().numpy(), rtol=1e-4, atol=1e-4 * scale)
     np.testing.assert_allclose(db.cpu().numpy(), dZ.sum(0).float().numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize("M", [96, 1024, 8192])
+def test_fused_activation_backward_chain(ops, M):
+    """The training step's backward never runs a stand-alone activation-backward pass: loss kernel (sigmoid_bwd),
+    dgrad epilogue (x_act) and interaction backward (x_act) each apply the derivative of the activation BELOW
+    them.  Compare the chained result with torch autograd on the same two-layer head + interaction."""
+    rng = np.random.RandomState(M)
+    F, D, H = 5, 16, 40
+    npairs = F * (F - 1) // 2
+    feat = torch.from_numpy(rng.randn(M, F, D).astype(np.float32))
+    feat[:, 0, :] = torch.relu(feat[:, 0, :])                  # feature 0 = a ReLU output
+    W1 = torch.from_numpy((rng.randn(H, D + npairs) / 5).astype(np.float32))
+    b1 = torch.from_numpy(rng.randn(H).astype(np.float32))
+    W2 = torch.from_numpy((rng.randn(1, H) / 5).astype(np.float32))
+    b2 = torch.from_numpy(rng.randn(1).astype(np.float32))
+    T = torch.from_numpy((rng.rand(M, 1) > 0.5).astype(np.float32))
+    # torch reference: pre-activation gradient of the layer that produced feature 0
+    pre0 = feat[:, 0, :].clone().double().requires_grad_(True)     # stands for the pre-activation (positive part)
+    f = torch.cat([torch.relu(pre0).unsqueeze(1), feat[:, 1:, :].double()], dim=1)
+    f_rest = feat[:, 1:, :].clone().double().requires_grad_(True)
+    f = torch.cat([torch.relu(pre0).unsqueeze(1), f_rest], dim=1)
+    Zm = torch.bmm(f, f.transpose(1, 2))
+    li = [i for i in range(F) for j in range(i)]
+    lj = [j for i in range(F) for j in range(i)]
+    R = torch.cat([f[:, 0, :], Zm[:, li, lj]], dim=1)
+    W1d, b1d, W2d, b2d = [x.double().requires_grad_(True) for x in (W1, b1, W2, b2)]
+    h = torch.relu(R @ W1d.t() + b1d)
+    z = torch.sigmoid(h @ W2d.t() + b2d)
+    loss = torch.nn.functional.binary_cross_entropy(z, T.double())
+    loss.backward()
+    # HIP chain
+    fd = feat.to(DEV)
+    Rd = torch.empty(M, D + npairs, device=DEV)
+    ops.interact_fwd(fd, False, Rd)
+    hd = torch.empty(M, H, device=DEV)
+    zd = torch.empty(M, 1, device=DEV)
+    ops.linear_fwd(Rd, W1.to(DEV), b1.to(DEV), hd, 1)
+    ops.linear_fwd(hd, W2.to(DEV), b2.to(DEV), zd, 2)
+    lossb = torch.zeros(65, device=DEV)
+    dz = torch.empty(M, 1, device=DEV)
+    ops.bce_fwd_bwd(zd, T.to(DEV), lossb, dz, sigmoid_bwd=True)
+    dh = torch.empty(M, H, device=DEV)
+    gW2, gb2 = torch.empty(1, H, device=DEV), torch.empty(1, device=DEV)
+    ops.linear_bwd(hd, W2.to(DEV), None, dz, dh, gW2, gb2, 0, ops.linear_bwd_work(M, 1, H, DEV), x_act=1)
+    dR = torch.empty(M, D + npairs, device=DEV)
+    gW1, gb1 = torch.empty(H, D + npairs, device=DEV), torch.empty(H, device=DEV)
+    ops.linear_bwd(Rd, W1.to(DEV), None, dh, dR, gW1, gb1, 0, ops.linear_bwd_work(M, H, D + npairs, DEV), x_act=0)
+    dfeat = torch.empty_like(fd)
+    ops.interact_bwd(fd, dR, False, dfeat, x_act=1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(lossb[0]), float(loss), rtol=1e-5)
+    tol = dict(rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(gW2.cpu().numpy(), W2d.grad.float().numpy(), **tol)
+    np.testing.assert_allclose(gb2.cpu().numpy(), b2d.grad.float().numpy(), **tol)
+    np.testing.assert_allclose(gW1.cpu().numpy(), W1d.grad.float().numpy(), **tol)
+    np.testing.assert_allclose(gb1.cpu().numpy(), b1d.grad.float().numpy(), **tol)
+    np.testing.assert_allclose(dfeat[:, 1:].cpu().numpy(), f_rest.grad.float().numpy(), **tol)
+    np.testing.assert_allclose(dfeat[:, 0].cpu().numpy(), pre0.grad.float().numpy(), **tol)
 
 
 def test_qr_embedding_bag_golden(ops, golden):
