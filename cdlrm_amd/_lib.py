@@ -76,6 +76,7 @@ PROTOTYPES = {
     "cdlrm_linear_bwd_work_bytes": (c_u64, [c_i64, c_i32, c_i32]),
     "cdlrm_linear_bwd": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i32, c_i32,
                                    c_i32, c_i32, vp, vp]),
+    "cdlrm_mlp_wgrad": (C.c_int, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp]),
     "cdlrm_bce_fwd_bwd": (C.c_int, [vp, vp, c_i64, vp, vp, c_i32, vp]),
     "cdlrm_sgd_step": (C.c_int, [vp, vp, c_i64, c_f32, vp]),
     "cdlrm_scale_div": (C.c_int, [vp, c_i64, c_f32, vp]),

@@ -100,7 +100,8 @@ extern "C" uint64_t cdlrm_linear_bwd_work_bytes(int64_t M, int32_t N, int32_t K)
 extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y, float* dY,
                                 int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db, int64_t M, int32_t N,
                                 int32_t K, int32_t act, int32_t x_act, void* work, void* stream) {
-    CDLRM_REQUIRE(X && W && dY && dW && work && M >= 1 && N >= 1 && K >= 1, "bad argument");
+    CDLRM_REQUIRE(X && W && dY && work && M >= 1 && N >= 1 && K >= 1, "bad argument");
+    CDLRM_REQUIRE(dW || !db, "db without dW (the bias gradient is a by-product of the weight-gradient GEMM)");
     CDLRM_REQUIRE(act == 0 || Y, "activation backward needs Y");
     CDLRM_REQUIRE(act >= 0 && act <= 2 && x_act >= 0 && x_act <= 2, "bad activation code");
     CDLRM_REQUIRE(((uintptr_t)work & 255) == 0, "work must be 256-byte aligned");
@@ -124,7 +125,7 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
     }
     // dW[N,K] = dZ[M,N]^T X[M,K], split over M into slabs summed in slab order; the first column panel of the
     // same GEMM sums dZ over the batch (bias gradient)
-    {
+    if (dW) {
         GemmArgs g = gemm_args();
         g.A = dY; g.lda = ld_dy; g.B = X; g.ldb = ld_x; g.ldc = K;
         g.slab = (int64_t)N * K;
@@ -145,6 +146,37 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
         }
     }
     CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight (and bias) gradients of SEVERAL layers at once, from the pre-activation gradients dZ[i] that the dgrad chain
+// left behind (cdlrm_linear_bwd with dW = NULL): dW[i] = dZ[i]^T X[i], db[i] = column sums of dZ[i].
+// Small batches: all layers in one grouped launch of the LDS-free kernel (no slabs, no reduction); long batches: the
+// tiled split-M path, layer after layer.
+extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
+                               const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
+                               const int32_t* K, void* work, void* stream) {
+    CDLRM_REQUIRE(n_layers >= 0 && (n_layers == 0 || (X && ld_x && dZ && ld_dz && dW && db && N && K)) && M >= 1,
+                  "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= WGRAD_DIRECT_MAX_M) {
+        std::vector<GemmArgs> probs((size_t)n_layers);
+        for (int i = 0; i < n_layers; ++i) {
+            CDLRM_REQUIRE(X[i] && dZ[i] && dW[i] && N[i] >= 1 && K[i] >= 1 && ld_x[i] >= K[i] && ld_dz[i] >= N[i],
+                          "bad layer argument");
+            GemmArgs g = gemm_args();
+            g.A = dZ[i]; g.lda = ld_dz[i]; g.B = X[i]; g.ldb = ld_x[i]; g.C = dW[i]; g.ldc = K[i];
+            g.M = N[i]; g.N = K[i]; g.K = M; g.kchunk = M; g.colsum = db[i];
+            probs[(size_t)i] = g;
+        }
+        return launch_wgrad_group(probs.data(), n_layers, s);
+    }
+    for (int i = 0; i < n_layers; ++i) {
+        // dY = dZ with act 0, no dX: only the weight-gradient part of cdlrm_linear_bwd runs
+        int rc = cdlrm_linear_bwd(X[i], ld_x[i], /*W (unused without dX)*/ X[i], nullptr, 0, const_cast<float*>(dZ[i]),
+                                  ld_dz[i], nullptr, 0, dW[i], db[i], M, N[i], K[i], 0, 0, work, stream);
+        if (rc) return rc;
+    }
     return 0;
 }
 

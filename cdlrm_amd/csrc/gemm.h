@@ -267,8 +267,17 @@ __device__ __forceinline__ void direct_load(const float* __restrict__ p, int64_t
     }
 }
 
+#ifndef DIRECT_ABLATE
+#define DIRECT_ABLATE 0     // tools/gemm_direct_ablate.hip only: 1 no loads inside the loop, 2 no MFMAs
+#endif
 __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&b)[8], int64_t k, int64_t kw1, int lk,
                                            f32x16& acc, float& cs) {
+#if DIRECT_ABLATE & 2
+#pragma unroll
+    for (int s = 0; s < 8; ++s) cs += (a[s].x + a[s].y) + (a[s].z + a[s].w) + (b[s].x + b[s].y) + (b[s].z + b[s].w);
+    acc[0] = cs;
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int64_t kk = k + 8 * s + 4 * lk;
@@ -284,17 +293,17 @@ __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&
 }
 
 // LOOP = false: each wave's share of the contraction is <= 64 (one batch of loads, no loop)
+// XCD-aware bijective renumbering of a 1-D grid (see k_gemm)
+__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
+    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
+    return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
+}
+
 template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
-__global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
-    __shared__ float red[4][32][33];
-    __shared__ float csr[4][32];
+__device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsigned by, unsigned bz,
+                                            float (*red)[32][33], float (*csr)[32]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 31, lk = lane >> 5;
-    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
-    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
-    const unsigned bx = wgid % gridDim.x, by = (wgid / gridDim.x) % gridDim.y, bz = wgid / (gridDim.x * gridDim.y);
     const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
     const int64_t kbeg = (int64_t)bz * g.kchunk;
     const int64_t kend = min(g.K, kbeg + g.kchunk);
@@ -318,13 +327,17 @@ __global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
         // sched_barrier: the machine scheduler otherwise drags each load down to just before its use (fewer
         // live registers, 2-4 loads in flight, one exposed latency per step -- seen in the ISA)
         for (int64_t k = kw0; k < kw1; k += 128) {
-            direct_load<A_KC, VA>(pa, g.lda, k + 64, g.K, lk, a1);
-            direct_load<B_KC, VB>(pb, g.ldb, k + 64, g.K, lk, b1);
+            if (!(DIRECT_ABLATE & 1) || k == kw0) {
+                direct_load<A_KC, VA>(pa, g.lda, k + 64, g.K, lk, a1);
+                direct_load<B_KC, VB>(pb, g.ldb, k + 64, g.K, lk, b1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             direct_mma(a0, b0, k, kw1, lk, acc, cs);
             __builtin_amdgcn_sched_barrier(0);
-            direct_load<A_KC, VA>(pa, g.lda, k + 128, g.K, lk, a0);
-            direct_load<B_KC, VB>(pb, g.ldb, k + 128, g.K, lk, b0);
+            if (!(DIRECT_ABLATE & 1)) {
+                direct_load<A_KC, VA>(pa, g.lda, k + 128, g.K, lk, a0);
+                direct_load<B_KC, VB>(pb, g.ldb, k + 128, g.K, lk, b0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             direct_mma(a1, b1, k + 64, kw1, lk, acc, cs);
             __builtin_amdgcn_sched_barrier(0);
@@ -370,6 +383,41 @@ __global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
         for (int u = 0; u < 4; ++u)
             if (n0 + c4 + u < g.N) C[n0 + c4 + u] = v[u];
     }
+}
+
+template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
+__global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
+    __shared__ float red[4][32][33];
+    __shared__ float csr[4][32];
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nwg);
+    direct_body<A_KC, B_KC, VA, VB, LOOP>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y,
+                                          wgid / (gridDim.x * gridDim.y), red, csr);
+}
+
+// Several independent small GEMMs of one operand layout in ONE launch (the weight gradients of all layers of the
+// MLPs: at small batches every launch costs ~10 us of fixed latency against ~3 us of MFMA work, and one problem
+// alone cannot fill the chip).  Workgroup -> problem by the running workgroup count.
+#define GEMM_GROUP_MAX 8
+struct GemmGroup {
+    int n;
+    unsigned first[GEMM_GROUP_MAX + 1];      // first[p] .. first[p+1]: workgroups of problem p (x fastest, then y)
+    GemmArgs g[GEMM_GROUP_MAX];
+};
+
+template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
+__global__ void __launch_bounds__(256) k_gemm_direct_group(GemmGroup grp) {
+    __shared__ float red[4][32][33];
+    __shared__ float csr[4][32];
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+        if (q < grp.n && wgid >= grp.first[q]) p = q;
+    const GemmArgs& g = grp.g[p];
+    const unsigned local = wgid - grp.first[p];
+    const unsigned gx = (unsigned)((g.N + 31) / 32);
+    direct_body<A_KC, B_KC, VA, VB, LOOP>(g, local % gx, local / gx, 0, red, csr);
 }
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -427,6 +475,39 @@ static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
     else if (vb) CDLRM_DIRECT(false, B_KC);
     else CDLRM_DIRECT(false, false);
 #undef CDLRM_DIRECT
+}
+
+// up to GEMM_GROUP_MAX un-split problems of the weight-gradient layout (both operands contraction-strided) per launch
+static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s) {
+    for (int want_loop = 0; want_loop < 2; ++want_loop) {
+        GemmGroup grp;
+        memset(&grp, 0, sizeof(grp));
+        unsigned blocks = 0;
+        auto flush = [&]() {
+            if (grp.n == 0) return;
+            grp.first[grp.n] = blocks;
+            if (want_loop)
+                hipLaunchKernelGGL((k_gemm_direct_group<false, false, false, false, true>), dim3(blocks), dim3(256), 0, s, grp);
+            else
+                hipLaunchKernelGGL((k_gemm_direct_group<false, false, false, false, false>), dim3(blocks), dim3(256), 0, s, grp);
+            grp.n = 0;
+            blocks = 0;
+        };
+        for (int i = 0; i < n; ++i) {
+            const bool loop = cdiv(probs[i].K, 32) * 8 > 64;
+            if ((int)loop != want_loop) continue;
+            if (grp.n == GEMM_GROUP_MAX) flush();
+            grp.first[grp.n] = blocks;
+            grp.g[grp.n] = probs[i];
+            grp.g[grp.n].kchunk = probs[i].K;
+            grp.g[grp.n].vecC = aligned16(probs[i].C) && probs[i].ldc % 4 == 0;
+            blocks += (unsigned)(cdiv(probs[i].M, 32) * cdiv(probs[i].N, 32));
+            grp.n++;
+        }
+        flush();
+    }
+    CDLRM_LAUNCH_CHECK();
+    return 0;
 }
 
 template <bool A_KC, bool B_KC>

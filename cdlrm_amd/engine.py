@@ -182,6 +182,13 @@ class TrainEngine:
         for l, _ in self.bot + self.top:
             work = max(work, ops.linear_bwd_work(B, l.out_features, self.W[l].shape[1], dev).numel())
         b["lin_work"] = torch.empty(work, dtype=torch.uint8, device=dev)
+        # weight/bias gradients of all layers are taken at the end of the backward, from the pre-activation
+        # gradients the dgrad chain leaves in these buffers (one grouped launch at small batches)
+        layers = [l for l, _ in self.bot + self.top]
+        x0 = torch.empty(B, self.W[layers[0]].shape[1], dtype=f32, device=dev)   # stand-in: re-pointed at X every step
+        xs = [x0] + b["bot_y"] + [b["R"]] + b["top_y"][:-1]
+        dzs = b["bot_dy"] + [b["dfeat"][:, 0, :]] + b["top_dy"]
+        b["wgrad"] = ops.WgradPlan(xs, dzs, [self.gW[l] for l in layers], [self.gb[l] for l in layers], b["lin_work"])
         self._bufs[B] = b
         return b
 
@@ -342,7 +349,7 @@ class TrainEngine:
             elif i < len(self.top) - 1:
                 act = 0                                      # applied by the dgrad epilogue of layer i+1
             dX = dR if i == 0 else buf["top_dy"][i - 1]
-            ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, self.gW[l], self.gb[l], act,
+            ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, None, None, act,
                            buf["lin_work"], x_act=(self.top[i - 1][1] if i > 0 else 0))
             dY = dX
         ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
@@ -360,12 +367,15 @@ class TrainEngine:
                 ev.record(self.side)
                 self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), res=(res[0], res[1], res[2], ev))
         dY = dfeat[:, 0, :]
-        for i in reversed(range(len(self.bot))):
+        for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
-            dX = None if i == 0 else buf["bot_dy"][i - 1]
-            ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, self.gW[l], self.gb[l], 0,
-                           buf["lin_work"], x_act=(self.bot[i - 1][1] if i > 0 else 0))
+            dX = buf["bot_dy"][i - 1]
+            ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, None, None, 0,
+                           buf["lin_work"], x_act=self.bot[i - 1][1])
             dY = dX
+        plan = buf["wgrad"]
+        plan.set_x(0, X)
+        ops.mlp_wgrad(plan)
         if next_idx is None:
             main.wait_stream(self.side)      # full join (also what a hipGraph capture needs)
         else:

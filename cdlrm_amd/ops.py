@@ -290,8 +290,46 @@ def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=Non
     N = W.shape[0]
     check(_lib.lib().cdlrm_linear_bwd(X.data_ptr(), X.stride(0), W.data_ptr(), ptr(Y), 0 if Y is None else Y.stride(0),
                                       dY.data_ptr(), dY.stride(0), ptr(dX), 0 if dX is None else dX.stride(0),
-                                      dW.data_ptr(), ptr(db), M, N, K, act, int(x_act), work.data_ptr(),
+                                      ptr(dW), ptr(db), M, N, K, act, int(x_act), work.data_ptr(),
                                       stream_ptr(stream)))
+
+
+class WgradPlan:
+    """Host-side argument block of cdlrm_mlp_wgrad for a fixed set of layers and buffers (built once per batch shape;
+    `set_x` re-points one layer's input, e.g. the dense features of the current batch)."""
+
+    def __init__(self, Xs, dZs, dWs, dbs, work: torch.Tensor):
+        import ctypes as C
+        n = len(Xs)
+        assert len(dZs) == n and len(dWs) == n and len(dbs) == n
+        self.n = n
+        self.M = int(dZs[0].shape[0])
+        self._keep = (list(Xs), list(dZs), list(dWs), list(dbs), work)
+        PA, IA, NA = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+        self.X = PA(*[x.data_ptr() for x in Xs])
+        self.ld_x = IA(*[x.stride(0) for x in Xs])
+        self.dZ = PA(*[d.data_ptr() for d in dZs])
+        self.ld_dz = IA(*[d.stride(0) for d in dZs])
+        self.dW = PA(*[w.data_ptr() for w in dWs])
+        self.db = PA(*[ptr(b) for b in dbs])
+        self.N = NA(*[int(w.shape[0]) for w in dWs])
+        self.K = NA(*[int(w.shape[1]) for w in dWs])
+        for x, d, w in zip(Xs, dZs, dWs):
+            assert x.shape[0] == self.M and d.shape[0] == self.M and x.stride(1) == 1 and d.stride(1) == 1
+            assert w.is_contiguous() and d.shape[1] == w.shape[0] and x.shape[1] <= w.shape[1] <= x.stride(0)
+        self.work = work
+
+    def set_x(self, i: int, x: torch.Tensor):
+        assert x.shape[0] == self.M and x.stride(1) == 1
+        self.X[i] = x.data_ptr()
+        self.ld_x[i] = x.stride(0)
+        self._keep[0][i] = x
+
+
+def mlp_wgrad(plan: WgradPlan, stream=None):
+    """dW[i] = dZ[i]^T X[i], db[i] = column sums of dZ[i] for every layer of the plan (one grouped launch at small M)."""
+    check(_lib.lib().cdlrm_mlp_wgrad(plan.n, plan.X, plan.ld_x, plan.dZ, plan.ld_dz, plan.dW, plan.db, plan.M, plan.N,
+                                     plan.K, plan.work.data_ptr(), stream_ptr(stream)))
 
 
 def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, dZ: Optional[torch.Tensor], stream=None,

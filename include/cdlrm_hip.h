@@ -252,7 +252,8 @@ int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* 
                      int64_t ld_y, int64_t M, int32_t N, int32_t K, int32_t act, void* stream);
 /* Backward of the same layer.  act != 0: dY is the gradient w.r.t. the layer's OUTPUT and is overwritten
  * in place by dZ = dY * act'(Y); act == 0: dY already is dZ (Y may be NULL).
- * dX [M, K] ld_dx (may be NULL for the first layer), dW [N, K], db [N] (may be NULL).
+ * dX [M, K] ld_dx (may be NULL for the first layer), dW [N, K] (NULL: the weight gradient is taken later
+ * by cdlrm_mlp_wgrad from the dZ left in dY), db [N] (may be NULL).
  * x_act != 0: X is itself the output of an activation (1 ReLU, 2 sigmoid) and dX is multiplied by act'(X)
  * in the GEMM epilogue, i.e. dX is then the dZ of the layer below (pass act = 0 there): the training
  * step chains the layers this way so no stand-alone activation-backward pass touches HBM.
@@ -263,6 +264,15 @@ int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* 
                      float* dY, int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db,
                      int64_t M, int32_t N, int32_t K, int32_t act, int32_t x_act, void* work,
                      void* stream);
+
+/* Weight and bias gradients of n_layers Linear layers from the pre-activation gradients dZ[i] [M, N[i]] that
+ * cdlrm_linear_bwd(dW = NULL) left behind: dW[i] [N[i], K[i]] = dZ[i]^T X[i], db[i] [N[i]] (entries may be NULL)
+ * = column sums of dZ[i].  The arrays are HOST arrays of device pointers / sizes.  Replaces the per-parameter
+ * autograd accumulation of the reference's loss.backward() (main_no_ddp.py:409) for the MLP weights: at small
+ * per-GPU batches all layers run as one grouped launch.  work: as for cdlrm_linear_bwd, sized for the largest layer. */
+int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
+                    const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
+                    const int32_t* K, void* work, void* stream);
 
 /* BCELoss(mean) forward + backward on the sigmoid output (torch clamps log at -100):
  * loss_out device fp32 [65]: [0] = loss, [1..64] = partial sums (fixed-order, reproducible);

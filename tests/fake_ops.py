@@ -202,9 +202,27 @@ def linear_bwd(X, W, Y, dY, dX, dW, db, act, work, stream=None, x_act=0):
         dY.copy_(dY * ((1 - Y) * Y))
     if dX is not None:
         dX.copy_(_act_bwd(dY @ W, X, x_act))
-    dW.copy_(dY.t() @ X)
+    if dW is not None:
+        dW.copy_(dY.t() @ X)
     if db is not None:
         db.copy_(dY.sum(0))
+
+
+class WgradPlan:
+    def __init__(self, Xs, dZs, dWs, dbs, work):
+        self.Xs, self.dZs, self.dWs, self.dbs = list(Xs), list(dZs), list(dWs), list(dbs)
+
+    def set_x(self, i, x):
+        self.Xs[i] = x
+
+
+def mlp_wgrad(plan, stream=None):
+    for x, dz, dw, db in zip(plan.Xs, plan.dZs, plan.dWs, plan.dbs):
+        dw[:, :x.shape[1]].copy_(dz.t() @ x)
+        if dw.shape[1] > x.shape[1]:
+            dw[:, x.shape[1]:].zero_()
+        if db is not None:
+            db.copy_(dz.sum(0))
 
 
 def bce_fwd_bwd(Z, target, loss_buf, dZ, stream=None, sigmoid_bwd=False):

@@ -394,6 +394,36 @@ def test_fused_activation_backward_chain(ops, M):
     np.testing.assert_allclose(dfeat[:, 0].cpu().numpy(), pre0.grad.float().numpy(), **tol)
 
 
+@pytest.mark.parametrize("M", [64, 1000, 2048, 4100])
+def test_mlp_wgrad_group(ops, M):
+    """All layers' weight + bias gradients in one call (grouped LDS-free launch up to M = 2048, tiled split-M path
+    above) against fp64 torch."""
+    rng = np.random.RandomState(M)
+    shapes = [(512, 13), (256, 512), (128, 256), (512, 480), (512, 512), (256, 512), (1, 256), (70, 33), (5, 3)]
+    Xs, dZs, dWs, dbs = [], [], [], []
+    for n, (N, K) in enumerate(shapes):
+        ld = K + (4 if n == 3 else 0)                   # one input with a row pitch wider than K
+        xb = torch.from_numpy(rng.randn(M, ld).astype(np.float32)).to(DEV)
+        Xs.append(xb[:, :K])
+        dZs.append(torch.from_numpy(rng.randn(M, N).astype(np.float32)).to(DEV))
+        dWs.append(torch.empty(N, K, device=DEV))
+        dbs.append(None if n == 2 else torch.empty(N, device=DEV))
+    work = 0
+    for N, K in shapes:
+        work = max(work, ops.linear_bwd_work(M, N, K, DEV).numel())
+    plan = ops.WgradPlan(Xs, dZs, dWs, dbs, torch.empty(work, dtype=torch.uint8, device=DEV))
+    ops.mlp_wgrad(plan)
+    ops.mlp_wgrad(plan)          # idempotent: no accumulation into the outputs
+    torch.cuda.synchronize()
+    scale = float(np.sqrt(M))
+    for X, dZ, dW, db in zip(Xs, dZs, dWs, dbs):
+        ref = dZ.cpu().double().t() @ X.cpu().double()
+        np.testing.assert_allclose(dW.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        if db is not None:
+            np.testing.assert_allclose(db.cpu().numpy(), dZ.cpu().double().sum(0).float().numpy(), rtol=1e-4,
+                                       atol=1e-5 * scale)
+
+
 def test_qr_embedding_bag_golden(ops, golden):
     """QREmbeddingBag forward + gradients vs the reference's module, incl. the float32-division quirk."""
     from cdlrm_amd.tricks.qr_embedding_bag import QREmbeddingBag
