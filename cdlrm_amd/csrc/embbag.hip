@@ -79,36 +79,74 @@ __global__ void __launch_bounds__(1024) k_resolve(const TableDesc* __restrict__ 
 // K6c: aux-row fill: cache.weight[aux_i] = W_host[idx_miss_i]  (model_no_ddp.py:179), zero-copy reads
 // of the pinned host table over PCIe, 16 bytes per lane.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ tab, int ways, int D4,
+template <int FILL_U>
+__global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ tab, int T, int ways, int D4,
                                                   float4* __restrict__ weight, float* const* __restrict__ host_rows,
                                                   const int64_t* __restrict__ idx, int64_t n, int64_t ld_idx,
                                                   const int32_t* __restrict__ miss_pos,
                                                   const int32_t* __restrict__ miss_count) {
-    const int t = blockIdx.y;
-    const int m = miss_count[t];
-    if (m == 0) return;
-    const TableDesc d = tab[t];
-    const float4* src = reinterpret_cast<const float4*>(host_rows[t]);
     // PCIe-bound: what matters is the number of host reads in flight (the link has a bounded tag pool), not the
-    // number of waves.  Each thread keeps FILL_U independent 16-B host reads in flight, so a SMALL grid saturates the
-    // link and leaves the memory pipelines of the other CUs to the kernels this fill runs beside.
-    constexpr int FILL_U = 8;
-    const int64_t total = (int64_t)m * D4;
+    // number of waves -- and every read beyond what the link can carry sits in the L2/fabric request queues in
+    // front of the HBM traffic of whatever runs beside this kernel (measured: concurrent GEMMs 2-3x slower under a
+    // 200-workgroup fill).  So: ONE small grid over the misses of all tables (most tables have none), FILL_U
+    // independent 16-B reads per lane.
+    __shared__ int64_t first[65];           // first[t] = 16-B elements of the tables before t
+    __shared__ int64_t aux_base[64];        // first aux row of table t
+    __shared__ uint64_t hrow[64];           // host table of t (address)
+    if (threadIdx.x == 0) {
+        int64_t acc = 0;
+        for (int t = 0; t < T; ++t) {
+            first[t] = acc;
+            acc += (int64_t)miss_count[t] * D4;
+        }
+        first[T] = acc;
+    }
+    if (threadIdx.x < T) {
+        const TableDesc d = tab[threadIdx.x];
+        aux_base[threadIdx.x] = d.row_base + d.P * ways;
+        hrow[threadIdx.x] = (uint64_t)(uintptr_t)host_rows[threadIdx.x];
+    }
+    __syncthreads();
+    const int64_t total = first[T];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * FILL_U) {
-        float4 v[FILL_U];
-        int64_t dst[FILL_U];
+        // PHASED on purpose: vmcnt is an in-order counter, so a dependent miss_pos -> idx -> host-row chain written
+        // per u would make chain u+1 wait for the slow host read of chain u (one PCIe round trip per read,
+        // measured: 5 GB/s).  All positions first, then all ids, then all host reads back to back.
+        int t[FILL_U], r[FILL_U], c[FILL_U], pos[FILL_U];
+        int64_t id[FILL_U];
 #pragma unroll
         for (int u = 0; u < FILL_U; ++u) {
             const int64_t e = min(e0 + u * stride, total - 1);
-            const int r = (int)(e / D4), c = (int)(e % D4);
-            const int64_t id = idx[(int64_t)t * ld_idx + miss_pos[(int64_t)t * n + r]];
-            dst[u] = (d.row_base + d.P * ways + r) * D4 + c;
-            v[u] = src[id * D4 + c];
+            int tt = 0;
+            while (e >= first[tt + 1]) ++tt;            // LDS only
+            const int64_t el = e - first[tt];
+            t[u] = tt; r[u] = (int)(el / D4); c[u] = (int)(el % D4);
         }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) f32x4* host_ptr;      // global, not flat, loads
+        host_ptr src[FILL_U];
+        f32x4 v[FILL_U];
+        int64_t dst[FILL_U];
 #pragma unroll
-        for (int u = 0; u < FILL_U; ++u)
-            if (e0 + u * stride < total) weight[dst[u]] = v[u];
+        for (int u = 0; u < FILL_U; ++u) {
+            src[u] = (host_ptr)hrow[t[u]];
+            dst[u] = (aux_base[t[u]] + r[u]) * D4 + c[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) pos[u] = miss_pos[(int64_t)t[u] * n + r[u]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) id[u] = idx[(int64_t)t[u] * ld_idx + pos[u]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) v[u] = src[u][id[u] * D4 + c[u]];
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional stores (elements past the end were clamped to the last one: same value, same address) --
+        // a condition here lets the compiler sink each host read into its store's block, serialising them again
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) *reinterpret_cast<f32x4*>(weight + dst[u]) = v[u];
     }
 }
 
@@ -282,18 +320,27 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
     if (ctx->aux > 0) {
         CDLRM_REQUIRE(ctx->h_host_rows[0] != nullptr, "cdlrm_ctx_bind_host_tables first");
         const int D4 = ctx->D / 4;
-        int64_t fx = cdiv((int64_t)(n < ctx->aux ? n : ctx->aux) * D4, 256);
-        // PCIe-bound (~50 GB/s): ~100 waves in flight saturate the link; a larger grid only steals memory-pipeline
-        // slots from the kernels this fill runs beside (measured: a concurrent GEMM slowed 4x under 256 blocks/table)
-        static int fill_cap = -1;
-        if (fill_cap < 0) {
-            const char* e = getenv("CDLRM_FILL_BLOCKS");     // development switch
-            fill_cap = e ? atoi(e) : 8;
+        CDLRM_REQUIRE(ctx->T <= 64, "more than 64 tables");
+        // grid x reads-per-lane x 4 KB per workgroup-read = bytes in flight.  Measured on the MI355X box (random 512-B
+        // rows of a 96 GB pinned table): a host read takes ~17 us round trip, so the ~50 GB/s link needs ~0.5-1 MB in
+        // flight; 32 workgroups x 4 reads is the knee (16x8: 1.04 ms/step, 32x4: 0.96, 64x4: 0.98)
+        static int fill_grid = -1, fill_u = -1;
+        if (fill_grid < 0) {
+            const char* e = getenv("CDLRM_FILL_GRID");       // development switches
+            fill_grid = e ? atoi(e) : 32;
+            e = getenv("CDLRM_FILL_U");
+            fill_u = e ? atoi(e) : 4;
         }
-        if (fx > fill_cap) fx = fill_cap;
-        hipLaunchKernelGGL(k_fill_aux, dim3((unsigned)fx, (unsigned)ctx->T), dim3(256), 0, s, ctx->d_tab, ctx->ways, D4,
-                           reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, n, ld_idx, miss_pos,
-                           miss_count);
+        int64_t fx = cdiv((int64_t)(n < ctx->aux ? n : ctx->aux) * D4 * ctx->T, 256);
+        if (fx > fill_grid) fx = fill_grid;
+#define FILL_CALL(U)                                                                                                   \
+    hipLaunchKernelGGL(k_fill_aux<U>, dim3((unsigned)fx), dim3(256), 0, s, ctx->d_tab, ctx->T, ctx->ways, D4,          \
+                       reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, n, ld_idx, miss_pos, miss_count)
+        if (fill_u >= 8) FILL_CALL(8);
+        else if (fill_u >= 4) FILL_CALL(4);
+        else if (fill_u >= 2) FILL_CALL(2);
+        else FILL_CALL(1);
+#undef FILL_CALL
     }
     CDLRM_LAUNCH_CHECK();
     return 0;
