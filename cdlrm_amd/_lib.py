@@ -30,7 +30,7 @@ class CdlrmError(RuntimeError):
 class Geometry(C.Structure):
     _fields_ = [("num_tables", c_i32), ("dim", c_i32), ("num_ways", c_i32), ("aux_rows", c_i32),
                 ("table_rows", C.POINTER(c_i64)), ("cache_sets", C.POINTER(c_i64)),
-                ("device", c_i32), ("reserved", c_i32)]
+                ("device", c_i32), ("aux_phases", c_i32)]
 
 
 class Plan(C.Structure):
@@ -38,6 +38,10 @@ class Plan(C.Structure):
                 ("prot", vp), ("hit", vp), ("kept", vp), ("kept_off", vp), ("way", vp), ("flags", vp),
                 ("winner", vp), ("win_claim", vp), ("win_idx", vp), ("win_row", vp), ("win_tag", vp),
                 ("win_off", vp), ("cap_win", c_i64), ("stage", vp), ("ev_tag", vp)]
+
+
+class Victims(C.Structure):
+    _fields_ = [("pos", vp), ("idx", vp), ("off", vp), ("rows", vp), ("cap", c_i64)]
 
 
 # name -> (restype, argtypes); every symbol include/cdlrm_hip.h declares
@@ -51,7 +55,7 @@ PROTOTYPES = {
     "cdlrm_host_register": (C.c_int, [vp, c_u64, C.POINTER(vp)]),
     "cdlrm_host_unregister": (C.c_int, [vp]),
     "cdlrm_ctx_check_sync": (C.c_int, [vp, vp]),
-    "cdlrm_embbag_probe": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, vp, vp]),
+    "cdlrm_embbag_probe": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, vp, c_i32, vp]),
     "cdlrm_embbag_fwd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, vp]),
     "cdlrm_embbag_bwd_work_bytes": (c_u64, [c_i32, c_i64, c_i32]),
     "cdlrm_embbag_bwd_sgd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),
@@ -66,6 +70,8 @@ PROTOTYPES = {
     "cdlrm_plan_fetch": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(vp), C.c_int, vp]),
     "cdlrm_plan_commit": (C.c_int, [vp, C.POINTER(Plan), vp]),
     "cdlrm_plan_writeback": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(vp), C.c_int, vp]),
+    "cdlrm_plan_victims": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(Victims), vp]),
+    "cdlrm_ctx_bind_victims": (C.c_int, [vp, C.POINTER(Victims)]),
     "cdlrm_gather_rows": (C.c_int, [vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_agg_compact": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, vp]),
     "cdlrm_agg_gather": (C.c_int, [vp, vp, vp, c_f32, vp, c_i64, vp]),

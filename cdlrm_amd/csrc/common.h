@@ -26,7 +26,7 @@ struct TableDesc {
 };
 
 struct cdlrm_ctx {
-    int T = 0, D = 0, ways = 0, aux = 0, device = 0;
+    int T = 0, D = 0, ways = 0, aux = 0, aux_phases = 1, device = 0;
     std::vector<TableDesc> h_tab;
     TableDesc* d_tab = nullptr;
     int64_t total_rows = 0, total_tags = 0, total_sets = 0, total_bm_words = 0;
@@ -36,6 +36,10 @@ struct cdlrm_ctx {
     std::vector<float*> h_host_rows;
     float** d_ptr_fetch = nullptr;       // device arrays [T] for per-call pointer tables
     float** d_ptr_wb = nullptr;
+    // window-resident rows of the non-cached window indices (cdlrm_ctx_bind_victims); null = read the host tables
+    const int64_t* vict_idx = nullptr;
+    const int64_t* vict_off = nullptr;
+    const float* vict_rows = nullptr;
     int* d_err = nullptr;                // device error word
     int64_t* d_scan = nullptr;           // block sums for the scans
     int64_t scan_cap = 0;

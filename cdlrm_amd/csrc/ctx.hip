@@ -21,17 +21,19 @@ extern "C" int cdlrm_ctx_create(const cdlrm_geometry* geo, cdlrm_ctx** out) {
     CDLRM_REQUIRE(geo->dim >= 4 && geo->dim % 4 == 0, "dim must be a positive multiple of 4");
     CDLRM_REQUIRE(geo->num_ways >= 1 && geo->num_ways <= 64, "1..64 ways");
     CDLRM_REQUIRE(geo->aux_rows >= 0, "aux_rows >= 0");
+    CDLRM_REQUIRE(geo->aux_phases >= 0 && geo->aux_phases <= 2, "aux_phases 0..2");
     CDLRM_HIP_CHECK(hipSetDevice(geo->device));
     cdlrm_ctx* c = new cdlrm_ctx();
     c->T = geo->num_tables; c->D = geo->dim; c->ways = geo->num_ways; c->aux = geo->aux_rows;
     c->device = geo->device;
+    c->aux_phases = geo->aux_phases < 1 ? 1 : geo->aux_phases;
     int64_t tag = 0, row = 0, set = 0, bm = 0;
     for (int k = 0; k < c->T; ++k) {
         TableDesc d;
         d.n_rows = geo->table_rows[k];
         d.P = geo->cache_sets[k];
         if (d.n_rows < 1 || d.P < 1 || d.P > d.n_rows ||
-            d.P * (int64_t)c->ways + c->aux >= ((int64_t)1 << 31)) {
+            d.P * (int64_t)c->ways + (int64_t)c->aux * c->aux_phases >= ((int64_t)1 << 31)) {
             delete c;
             cdlrm_set_error("cdlrm_ctx_create: table %d has unsupported geometry (n=%lld P=%lld)", k,
                             (long long)geo->table_rows[k], (long long)geo->cache_sets[k]);
@@ -39,7 +41,7 @@ extern "C" int cdlrm_ctx_create(const cdlrm_geometry* geo, cdlrm_ctx** out) {
         }
         d.tag_base = tag; d.row_base = row; d.set_base = set; d.bm_base = bm;
         d.bm_words = ((d.n_rows + 63) / 64 + BM_WPB - 1) / BM_WPB * BM_WPB;
-        d.rows = d.P * c->ways + c->aux;
+        d.rows = d.P * c->ways + (int64_t)c->aux * c->aux_phases;
         tag += d.P * c->ways; row += d.rows; set += d.P; bm += d.bm_words;
         c->h_tab.push_back(d);
     }

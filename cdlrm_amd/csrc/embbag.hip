@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_probe(const TableDesc* __restrict__ tab
 // K6b: ordered miss resolution, one workgroup per table: the i-th miss (in position order) gets aux
 // slot P*ways + i (model_no_ddp.py:176-177).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_resolve(const TableDesc* __restrict__ tab, int ways, int aux,
+__global__ void __launch_bounds__(1024) k_resolve(const TableDesc* __restrict__ tab, int ways, int aux, int aux_first,
                                                   int32_t* __restrict__ slots, int64_t n,
                                                   int32_t* __restrict__ miss_pos, int32_t* __restrict__ miss_count,
                                                   int* err) {
@@ -63,10 +63,10 @@ __global__ void __launch_bounds__(1024) k_resolve(const TableDesc* __restrict__ 
         if (miss) {
             const int r = running + ex;
             if (r < aux) {
-                row[i] = (int32_t)(d.P * ways + r);
+                row[i] = (int32_t)(d.P * ways + aux_first + r);
                 mp[r] = (int32_t)i;
             } else {
-                row[i] = (int32_t)(d.P * ways);   // keep addresses legal; the call reports the error
+                row[i] = (int32_t)(d.P * ways + aux_first);   // keep addresses legal; the call reports the error
                 atomicOr(err, 2);
             }
         }
@@ -76,16 +76,20 @@ __global__ void __launch_bounds__(1024) k_resolve(const TableDesc* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6c: aux-row fill: cache.weight[aux_i] = W_host[idx_miss_i]  (model_no_ddp.py:179), zero-copy reads
-// of the pinned host table over PCIe, 16 bytes per lane.
+// K6c: aux-row fill: cache.weight[aux_i] = W_host[idx_miss_i]  (model_no_ddp.py:179): from the window's
+// HBM-resident victim rows when bound (VICT: binary search of the index in the table's sorted victim list), else
+// zero-copy reads of the pinned host table over PCIe; 16 bytes per lane.
 // ---------------------------------------------------------------------------------------------
-template <int FILL_U>
-__global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ tab, int T, int ways, int D4,
+template <int FILL_U, bool VICT>
+__global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ tab, int T, int ways, int aux_first,
+                                                  int D4,
                                                   float4* __restrict__ weight, float* const* __restrict__ host_rows,
                                                   const int64_t* __restrict__ idx, int64_t n, int64_t ld_idx,
                                                   const int32_t* __restrict__ miss_pos,
-                                                  const int32_t* __restrict__ miss_count) {
-    // PCIe-bound: what matters is the number of host reads in flight (the link has a bounded tag pool), not the
+                                                  const int32_t* __restrict__ miss_count,
+                                                  const int64_t* __restrict__ v_idx, const int64_t* __restrict__ v_off,
+                                                  const float* __restrict__ v_rows) {
+    // PCIe-bound (without victims): what matters is the number of host reads in flight (the link has a bounded tag pool), not the
     // number of waves -- and every read beyond what the link can carry sits in the L2/fabric request queues in
     // front of the HBM traffic of whatever runs beside this kernel (measured: concurrent GEMMs 2-3x slower under a
     // 200-workgroup fill).  So: ONE small grid over the misses of all tables (most tables have none), FILL_U
@@ -93,6 +97,19 @@ __global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ 
     __shared__ int64_t first[65];           // first[t] = 16-B elements of the tables before t
     __shared__ int64_t aux_base[64];        // first aux row of table t
     __shared__ uint64_t hrow[64];           // host table of t (address)
+    __shared__ int64_t voff[65];            // victim list of table t: v_idx[voff[t] .. voff[t+1])
+    __shared__ int search_steps;
+    if (VICT) {
+        if (threadIdx.x <= T) voff[threadIdx.x] = v_off[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t longest = 0;
+            for (int t = 0; t < T; ++t) longest = max(longest, voff[t + 1] - voff[t]);
+            int steps = 0;
+            while (((int64_t)1 << steps) <= longest) ++steps;       // lower_bound over `longest` entries
+            search_steps = steps;
+        }
+    }
     if (threadIdx.x == 0) {
         int64_t acc = 0;
         for (int t = 0; t < T; ++t) {
@@ -103,7 +120,7 @@ __global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ 
     }
     if (threadIdx.x < T) {
         const TableDesc d = tab[threadIdx.x];
-        aux_base[threadIdx.x] = d.row_base + d.P * ways;
+        aux_base[threadIdx.x] = d.row_base + d.P * ways + aux_first;
         hrow[threadIdx.x] = (uint64_t)(uintptr_t)host_rows[threadIdx.x];
     }
     __syncthreads();
@@ -140,8 +157,42 @@ __global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ 
 #pragma unroll
         for (int u = 0; u < FILL_U; ++u) id[u] = idx[(int64_t)t[u] * ld_idx + pos[u]];
         __builtin_amdgcn_sched_barrier(0);
+        int64_t at[FILL_U];
 #pragma unroll
-        for (int u = 0; u < FILL_U; ++u) v[u] = src[u][id[u] * D4 + c[u]];
+        for (int u = 0; u < FILL_U; ++u) at[u] = id[u] * D4 + c[u];
+        if (VICT) {
+            // lower_bound of id in the table's victim list, all FILL_U searches in lock step (loads of one step in
+            // flight together); lanes of one row search redundantly (same addresses: one request per wave)
+            int64_t lo[FILL_U], hi[FILL_U];
+#pragma unroll
+            for (int u = 0; u < FILL_U; ++u) { lo[u] = voff[t[u]]; hi[u] = voff[t[u] + 1]; }
+            const int steps = search_steps;
+            for (int it = 0; it < steps; ++it) {
+                int64_t probe[FILL_U];
+#pragma unroll
+                for (int u = 0; u < FILL_U; ++u) probe[u] = v_idx[lo[u] < hi[u] ? (lo[u] + hi[u]) >> 1 : lo[u] - (lo[u] > 0)];
+#pragma unroll
+                for (int u = 0; u < FILL_U; ++u) {
+                    const int64_t mid = (lo[u] + hi[u]) >> 1;
+                    if (lo[u] < hi[u]) {
+                        if (probe[u] < id[u]) lo[u] = mid + 1; else hi[u] = mid;
+                    }
+                }
+            }
+            int64_t found[FILL_U];
+#pragma unroll
+            for (int u = 0; u < FILL_U; ++u) found[u] = v_idx[lo[u] < voff[t[u] + 1] ? lo[u] : voff[0]];
+#pragma unroll
+            for (int u = 0; u < FILL_U; ++u) {
+                if (lo[u] < voff[t[u] + 1] && found[u] == id[u]) {
+                    src[u] = (host_ptr)(uintptr_t)v_rows;
+                    at[u] = lo[u] * D4 + c[u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) v[u] = src[u][at[u]];
         __builtin_amdgcn_sched_barrier(0);
         // unconditional stores (elements past the end were clamped to the last one: same value, same address) --
         // a condition here lets the compiler sink each host read into its store's block, serialising them again
@@ -291,8 +342,11 @@ static int lanes_per_row(int D4) { int l = pow2ceil(D4); return l > 64 ? 64 : (l
     }
 
 extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx,
-                                  int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, void* stream) {
+                                  int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, int32_t aux_phase,
+                                  void* stream) {
     CDLRM_REQUIRE(ctx && idx && slots_out && miss_pos && miss_count, "null argument");
+    CDLRM_REQUIRE(aux_phase >= 0 && aux_phase < ctx->aux_phases, "aux_phase outside the geometry's aux_phases");
+    const int aux_first = aux_phase * ctx->aux;
     CDLRM_REQUIRE(ctx->tags && ctx->weight, "cdlrm_ctx_bind_cache first");
     CDLRM_REQUIRE(n >= 0 && ld_idx >= n && n < ((int64_t)1 << 31), "bad n / ld_idx");
     hipStream_t s = (hipStream_t)stream;
@@ -315,7 +369,7 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
         default: PROBE_CALL(16); break;
     }
 #undef PROBE_CALL
-    hipLaunchKernelGGL(k_resolve, dim3(ctx->T), dim3(1024), 0, s, ctx->d_tab, ctx->ways, ctx->aux, slots_out, n,
+    hipLaunchKernelGGL(k_resolve, dim3(ctx->T), dim3(1024), 0, s, ctx->d_tab, ctx->ways, ctx->aux, aux_first, slots_out, n,
                        miss_pos, miss_count, ctx->d_err);
     if (ctx->aux > 0) {
         CDLRM_REQUIRE(ctx->h_host_rows[0] != nullptr, "cdlrm_ctx_bind_host_tables first");
@@ -332,14 +386,19 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
             fill_u = e ? atoi(e) : 4;
         }
         int64_t fx = cdiv((int64_t)(n < ctx->aux ? n : ctx->aux) * D4 * ctx->T, 256);
-        if (fx > fill_grid) fx = fill_grid;
-#define FILL_CALL(U)                                                                                                   \
-    hipLaunchKernelGGL(k_fill_aux<U>, dim3((unsigned)fx), dim3(256), 0, s, ctx->d_tab, ctx->T, ctx->ways, D4,          \
-                       reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, n, ld_idx, miss_pos, miss_count)
-        if (fill_u >= 8) FILL_CALL(8);
-        else if (fill_u >= 4) FILL_CALL(4);
-        else if (fill_u >= 2) FILL_CALL(2);
-        else FILL_CALL(1);
+        const bool vict = ctx->vict_idx != nullptr;
+        // with the window's victim rows resident in HBM the fill is a latency-bound search + HBM copy: wide grid
+        const int64_t cap_grid = vict ? 512 : fill_grid;
+        if (fx > cap_grid) fx = cap_grid;
+#define FILL_CALL(U, V)                                                                                                \
+    hipLaunchKernelGGL((k_fill_aux<U, V>), dim3((unsigned)fx), dim3(256), 0, s, ctx->d_tab, ctx->T, ctx->ways,         \
+                       aux_first, D4, reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, n, ld_idx,        \
+                       miss_pos, miss_count, ctx->vict_idx, ctx->vict_off, ctx->vict_rows)
+        if (vict) FILL_CALL(4, true);
+        else if (fill_u >= 8) FILL_CALL(8, false);
+        else if (fill_u >= 4) FILL_CALL(4, false);
+        else if (fill_u >= 2) FILL_CALL(2, false);
+        else FILL_CALL(1, false);
 #undef FILL_CALL
     }
     CDLRM_LAUNCH_CHECK();

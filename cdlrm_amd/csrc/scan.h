@@ -5,7 +5,7 @@
 // out[j] = position of the j-th non-zero flag (ascending); *d_count = number of non-zero flags.
 // n is read from d_n[0] when d_n != nullptr (then n_max bounds the launch), else n = n_max.
 // Entries beyond `cap` are dropped and the device error word gets bit 4.
-// clear != 0 zeroes the flags it has consumed.
+// clear bit 0: zero the flags it has consumed; bit 1: entries beyond `cap` are dropped silently (no error bit).
 int cdlrm_compact_flags(cdlrm_ctx* ctx, uint8_t* flags, const int64_t* d_n, int64_t n_max,
                         int32_t* out32, int64_t* out64, int64_t cap, int64_t* d_count, int clear,
                         hipStream_t s);

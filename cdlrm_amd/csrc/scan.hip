@@ -95,13 +95,13 @@ __global__ void __launch_bounds__(CF_THREADS) k_cf_emit(uint8_t* flags, const in
                 if (pos < cap) {
                     if (out32) out32[pos] = (int32_t)(base + i);
                     if (out64) out64[pos] = base + i;
-                } else {
+                } else if (!(clear & 2)) {
                     atomicOr(err, 4);
                 }
                 ++pos;
             }
         }
-        if (clear) {
+        if (clear & 1) {
             if (base + CF_PER_THREAD <= n) {
                 *reinterpret_cast<uint4*>(flags + base) = make_uint4(0, 0, 0, 0);
             } else {

@@ -511,6 +511,91 @@ extern "C" int cdlrm_plan_writeback(cdlrm_ctx* ctx, const cdlrm_plan* plan, floa
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window victims: the window's unique indices that are neither cached already nor inserted by this plan (no free
+// way in their set).  Every lookup of such an index is a miss (model_no_ddp.py:176-179 reads its HOST row into an
+// aux slot each time).  Their host rows do not change while the window trains, so they are fetched ONCE per window
+// into HBM (on the plan stream, during the previous window) and the per-iteration aux fill becomes an HBM copy.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WIN_THREADS) k_victim_flags(const int64_t* __restrict__ uniq_off, int T, int64_t cap,
+                                                              const uint8_t* __restrict__ hit, uint8_t* __restrict__ flags) {
+    const int64_t U = min(uniq_off[T], cap);
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x)
+        flags[u] = hit[u] ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(WIN_THREADS) k_victim_unflag(const int64_t* __restrict__ win_off, int T, int64_t cap,
+                                                               const int32_t* __restrict__ win_claim,
+                                                               const int32_t* __restrict__ kept, uint8_t* __restrict__ flags) {
+    const int64_t Wn = min(win_off[T], cap);
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < Wn; w += (int64_t)gridDim.x * blockDim.x)
+        flags[kept[win_claim[w]]] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_victim_fetch(int T, int D4, int lpr, const int64_t* __restrict__ v_off, int64_t cap,
+                                                      const int32_t* __restrict__ v_pos, const int64_t* __restrict__ uniq,
+                                                      float* const* __restrict__ src, int64_t* __restrict__ v_idx,
+                                                      float4* __restrict__ v_rows) {
+    const int64_t Vn = min(v_off[T], cap);
+    const int c = threadIdx.x % lpr;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+    const int64_t ng = (int64_t)gridDim.x * blockDim.x / lpr;
+    for (int64_t j = g0; j < Vn; j += ng) {
+        const int t = table_of(v_off, T, j);
+        const int64_t id = uniq[v_pos[j]];
+        if (c == 0) v_idx[j] = id;
+        const float4* sp = reinterpret_cast<const float4*>(src[t]) + id * D4;
+        for (int cc = c; cc < D4; cc += lpr) v_rows[j * D4 + cc] = sp[cc];
+    }
+}
+
+extern "C" int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* v, void* stream) {
+    CDLRM_REQUIRE(ctx && plan && v, "null argument");
+    CDLRM_REQUIRE(v->pos && v->idx && v->off && v->rows && v->cap >= 1 && ((uintptr_t)v->rows & 15) == 0, "victim buffers");
+    CDLRM_REQUIRE(plan->uniq && plan->uniq_off && plan->hit && plan->kept && plan->win_claim && plan->win_off && plan->flags,
+                  "plan buffers missing");
+    CDLRM_REQUIRE(ctx->h_host_rows[0] != nullptr, "cdlrm_ctx_bind_host_tables first");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t gx = cdiv(plan->cap_uniq, WIN_THREADS);
+    if (gx > WIN_BLOCKS) gx = WIN_BLOCKS;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_victim_flags, dim3((unsigned)gx), dim3(WIN_THREADS), 0, s, plan->uniq_off, ctx->T, plan->cap_uniq,
+                       plan->hit, plan->flags);
+    int64_t gw = cdiv(plan->cap_win, WIN_THREADS);
+    if (gw > WIN_BLOCKS) gw = WIN_BLOCKS;
+    if (gw < 1) gw = 1;
+    hipLaunchKernelGGL(k_victim_unflag, dim3((unsigned)gw), dim3(WIN_THREADS), 0, s, plan->win_off, ctx->T, plan->cap_win,
+                       plan->win_claim, plan->kept, plan->flags);
+    CDLRM_LAUNCH_CHECK();
+    int rc = cdlrm_scan_reserve(ctx, cdiv(plan->cap_uniq, 4096) + 1);
+    if (rc) return rc;
+    // beyond v->cap the list is cut (those indices keep reading the host table): clear | soft cap
+    rc = cdlrm_compact_flags(ctx, plan->flags, plan->uniq_off + ctx->T, plan->cap_uniq, v->pos, nullptr, v->cap,
+                             ctx->d_small + 2, 1 | 2, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_offsets_from_sorted, dim3(cdiv(ctx->T + 1, 64)), dim3(64), 0, s, v->pos, ctx->d_small + 2, v->cap,
+                       plan->uniq_off, ctx->T, v->off);
+    const int D4 = ctx->D / 4, lpr = lanes_per_row_w(D4);
+    int64_t gf = cdiv(v->cap * lpr, 256);
+    if (gf > WIN_BLOCKS) gf = WIN_BLOCKS;
+    if (gf < 1) gf = 1;
+    hipLaunchKernelGGL(k_victim_fetch, dim3((unsigned)gf), dim3(256), 0, s, ctx->T, D4, lpr, v->off, v->cap, v->pos,
+                       plan->uniq, ctx->d_host_rows, v->idx, reinterpret_cast<float4*>(v->rows));
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdlrm_ctx_bind_victims(cdlrm_ctx* ctx, const cdlrm_victims* v) {
+    CDLRM_REQUIRE(ctx, "null argument");
+    if (!v) {
+        ctx->vict_idx = nullptr; ctx->vict_off = nullptr; ctx->vict_rows = nullptr;
+        return 0;
+    }
+    CDLRM_REQUIRE(v->idx && v->off && v->rows && ((uintptr_t)v->rows & 15) == 0, "victim buffers");
+    ctx->vict_idx = v->idx; ctx->vict_off = v->off; ctx->vict_rows = v->rows;
+    return 0;
+}
+
 __global__ void __launch_bounds__(256) k_gather_rows(const float4* __restrict__ src, const int64_t* __restrict__ index,
                                                      int64_t count, int D4, float4* __restrict__ out) {
     const int64_t total = count * D4;

@@ -27,10 +27,18 @@ from .model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table
 class WindowPipeline:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, host_tables: Embedding_Table_Group, max_window: int,
                  *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
-                 world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None):
+                 world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None,
+                 victim_rows: Optional[int] = None):
+        """victim_rows: capacity (rows) of each of the two HBM buffers that hold the host rows of a window's
+        non-cached indices (None: every unique index of a window, at most 8 GiB per buffer; 0: off -- every miss
+        reads the host table over PCIe as the reference does)."""
         self.cg, self.host = cache_group, host_tables
         self.ctx = cache_group.ctx
         self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
+        if victim_rows is None:
+            victim_rows = min(self.plan.cap_uniq, (8 << 30) // (4 * self.ctx.D))
+        self.victims = [ops.Victims(self.ctx, victim_rows) for _ in range(2)] if victim_rows > 0 else None
+        self._vnext = 0
         self.dev = cache_group.weight.device
         self.side = S.new_stream(self.dev)
         self.parity_rng, self.seed, self.avg = parity_rng, int(seed), average_on_writeback
@@ -61,6 +69,8 @@ class WindowPipeline:
             else:
                 plan.assign(None, seed=self.seed * 1000003 + self.window_no, stream=side)
             plan.fetch(self.host_ptrs, False, stream=side)
+            if self.victims is not None:
+                plan.victims(self.victims[self._vnext], stream=side)
             if window_idx.is_cuda:
                 window_idx.record_stream(side)
             self.planned = S.new_event(self.dev)
@@ -73,6 +83,11 @@ class WindowPipeline:
         assert self.planned is not None, "plan_window() first"
         main.wait_event(self.planned)
         self.plan.commit(stream=main)
+        if self.victims is not None:
+            # from here on the per-iteration probe serves misses from this window's resident victim rows (the buffer
+            # of the previous window is free for the next plan: every probe that read it is ordered before this point)
+            self.ctx.bind_victims(self.victims[self._vnext])
+            self._vnext ^= 1
         done = S.new_event(self.dev)
         done.record(main)
         with S.on_stream(self.side):
@@ -124,8 +139,11 @@ class TrainEngine:
         self.iter = 0
         self.comm = S.new_stream(self.dev) if self.world > 1 else None
         self.side = S.new_stream(self.dev)
+        self.pref = S.new_stream(self.dev)          # next batch's tag probe + aux-row fill
         self.agg_rows = None
         self._pref = None
+        self._phase = 0                             # aux region of the batch being trained
+        self._emb_done = None
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -191,6 +209,17 @@ class TrainEngine:
         b["wgrad"] = ops.WgradPlan(xs, dzs, [self.gW[l] for l in layers], [self.gb[l] for l in layers], b["lin_work"])
         self._bufs[B] = b
         return b
+
+    def _probe_bufs(self, n, which):
+        """(slots, miss_pos, miss_count) of one pipeline stage, allocated once: they are written and read on side
+        streams, where the caching allocator's per-stream reuse rules would not protect per-call temporaries."""
+        key = ("probe", n, which)
+        if key not in self._bufs:
+            i32 = torch.int32
+            self._bufs[key] = (torch.empty(self.T, n, dtype=i32, device=self.dev),
+                               torch.empty(self.T, n, dtype=i32, device=self.dev),
+                               torch.empty(self.T, dtype=i32, device=self.dev))
+        return self._bufs[key]
 
     def _emb_work(self, n):
         key = ("emb", n)
@@ -267,6 +296,10 @@ class TrainEngine:
                 st["X"].copy_(X); st["idx"].copy_(lS_i); st["T"].copy_(T)
                 graph.replay()
         else:
+            if j is None:
+                j = self.iter
+            if self.world > 1 and j > 0 and j % self.agg_freq == 0:
+                next_idx = None      # the row merge below rewrites touched aux rows: no fill may be in flight
             self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
         # ---- dense gradient exchange + SGD ----
         if self.world > 1:
@@ -295,13 +328,16 @@ class TrainEngine:
         # step issues them for this batch behind its embedding backward (software-pipelined across iterations)
         main = S.current_stream(self.dev)
         side = self.side
+        two_phase = ctx.aux_phases >= 2
         pref, self._pref = self._pref, None
         if pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape):
             slots, miss_pos, miss_count, probed = pref["res"]
+            self._phase = pref["phase"]
         else:
             side.wait_stream(main)
             with S.on_stream(side):
-                slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side)
+                slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side, aux_phase=self._phase,
+                                                               out=self._probe_bufs(n, self._phase))
                 probed = S.new_event(self.dev)
                 probed.record(side)
         cur = X
@@ -321,6 +357,24 @@ class TrainEngine:
             gather_events.append((e0, e1))
         else:
             ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+        if next_idx is not None and two_phase:
+            # Software pipelining across iterations: the NEXT batch's tag probe and aux-row fill (~0.25 ms of PCIe
+            # reads at c3) start right behind this batch's gather, on their own stream, into the OTHER aux region
+            # (this batch still reads and updates its own aux rows).  The other region was last used by the previous
+            # batch: its embedding update must have landed (emb_done).
+            ev_g = S.new_event(self.dev)
+            ev_g.record(main)
+            pst = self.pref
+            pst.wait_event(ev_g)
+            if self._emb_done is not None:
+                pst.wait_event(self._emb_done)
+            with S.on_stream(pst):
+                ph = 1 - self._phase
+                res = ops.embbag_probe(ctx, next_idx, stream=pst, aux_phase=ph, out=self._probe_bufs(n, ph))
+                ev = S.new_event(self.dev)
+                ev.record(pst)
+            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=ph,
+                              res=(res[0], res[1], res[2], ev))
         # the backward's sort of the slot ids needs nothing but the probe result: run it on the side, under the MLPs
         emb_work = self._emb_work(n)
         with S.on_stream(side):
@@ -361,11 +415,14 @@ class TrainEngine:
                                  stream=self.side)
             emb_done = S.new_event(self.dev)
             emb_done.record(self.side)
-            if next_idx is not None:
-                res = ops.embbag_probe(ctx, next_idx, stream=self.side)
+            self._emb_done = emb_done
+            if next_idx is not None and not two_phase:
+                # single aux region: the next batch's fill can only follow this batch's embedding update
+                res = ops.embbag_probe(ctx, next_idx, stream=self.side, out=self._probe_bufs(n, 2 + (self.iter & 1)))
                 ev = S.new_event(self.dev)
                 ev.record(self.side)
-                self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), res=(res[0], res[1], res[2], ev))
+                self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
+                                  res=(res[0], res[1], res[2], ev))
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]

@@ -162,8 +162,8 @@ class _CacheTable:
 
     @property
     def weight(self):
-        g, k = self._g, self._k
-        return g.weight.data[g.row_base[k]:g.row_base[k + 1]]
+        g, k = self._g, self._k       # the reference's [ways*P + aux, m] table (a second aux region may follow it)
+        return g.weight.data[g.row_base[k]:g.row_base[k] + g.num_ways * g.cache_sizes[k] + g.aux_table_size]
 
 
 class LookupList(list):
@@ -222,15 +222,19 @@ class Embedding_Table_Cache_Group(nn.Module):
     Here both are views of two flat device buffers (`tags`, `weight`).
     """
 
-    def __init__(self, m_spa, ln_emb, max_cache_size, aux_table_size, num_ways, cache_init="normal"):
+    def __init__(self, m_spa, ln_emb, max_cache_size, aux_table_size, num_ways, cache_init="normal", aux_phases=2):
+        """aux_phases = 2 (default) appends a second aux region to every table so that the fused engine can fill the
+        NEXT batch's miss rows while the current batch still trains on its own (engine.py); callers that never pass
+        aux_phase see exactly the reference's tables."""
         super().__init__()
+        self.aux_phases = max(1, int(aux_phases))
         self.ln_emb = np.asarray(ln_emb)
         self.num_ways = int(num_ways)
         self.m_spa = int(m_spa)
         self.aux_table_size = int(aux_table_size)
         self.max_cache_size = self.find_next_prime(max_cache_size)
         self.cache_sizes = [int(n) if int(n) < self.max_cache_size else self.max_cache_size for n in self.ln_emb]
-        rows = [self.num_ways * p + self.aux_table_size for p in self.cache_sizes]
+        rows = [self.num_ways * p + self.aux_table_size * self.aux_phases for p in self.cache_sizes]
         self.row_base = [0]
         self.tag_base = [0]
         for k, r in enumerate(rows):
@@ -239,8 +243,12 @@ class Embedding_Table_Cache_Group(nn.Module):
         w = torch.empty(self.row_base[-1], self.m_spa, dtype=torch.float32)
         if cache_init == "normal":
             # nn.EmbeddingBag default init, table by table, from the torch CPU generator (:138)
+            # (only the reference's rows draw from the generator -- the insert's Exp(1) draws come from the same
+            #  stream later; the second aux region is scratch)
+            w.zero_()
             for k in range(len(rows)):
-                w[self.row_base[k]:self.row_base[k + 1]].normal_()
+                ref_rows = self.num_ways * self.cache_sizes[k] + self.aux_table_size
+                w[self.row_base[k]:self.row_base[k] + ref_rows].normal_()
         elif cache_init == "zeros":
             w.zero_()
         elif cache_init != "empty":
@@ -282,7 +290,7 @@ class Embedding_Table_Cache_Group(nn.Module):
         if self._ctx is None:
             # ops.CacheCtx refuses any non-HIP device: the module must be moved to the MI355X first (.to(rank))
             self._ctx = ops.CacheCtx([int(n) for n in self.ln_emb], self.cache_sizes, self.m_spa, self.num_ways,
-                                     self.aux_table_size, self.weight.device)
+                                     self.aux_table_size, self.weight.device, aux_phases=self.aux_phases)
             self._ctx.bind_cache(self.tags, self.weight.data)
         return self._ctx
 

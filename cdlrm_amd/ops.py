@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import Geometry, Plan, check, ptr, stream_ptr
+from ._lib import Victims as _VictimsStruct
 
 
 def _require_cuda(t: torch.Tensor, name: str):
@@ -22,15 +23,16 @@ class CacheCtx:
     """Opaque library context of one cache group (geometry + bound cache state)."""
 
     def __init__(self, table_rows: Sequence[int], cache_sets: Sequence[int], dim: int, num_ways: int,
-                 aux_rows: int, device: torch.device):
+                 aux_rows: int, device: torch.device, aux_phases: int = 1):
         self.T = len(table_rows)
         self.D, self.ways, self.aux = int(dim), int(num_ways), int(aux_rows)
+        self.aux_phases = max(1, int(aux_phases))
         self.table_rows = [int(x) for x in table_rows]
         self.cache_sets = [int(x) for x in cache_sets]
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("cdlrm_amd: a HIP device is required (no CPU fallback)")
-        self.rows = [self.ways * p + self.aux for p in self.cache_sets]
+        self.rows = [self.ways * p + self.aux * self.aux_phases for p in self.cache_sets]
         self.row_base, self.tag_base, self.set_base = [0], [0], [0]
         for k in range(self.T):
             self.row_base.append(self.row_base[-1] + self.rows[k])
@@ -41,7 +43,7 @@ class CacheCtx:
         self.total_bm_words = sum(self.bm_words)
         tr = (C.c_int64 * self.T)(*self.table_rows)
         cs = (C.c_int64 * self.T)(*self.cache_sets)
-        geo = Geometry(self.T, self.D, self.ways, self.aux, tr, cs, self.device.index or 0, 0)
+        geo = Geometry(self.T, self.D, self.ways, self.aux, tr, cs, self.device.index or 0, self.aux_phases)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(_lib.lib().cdlrm_ctx_create(C.byref(geo), C.byref(h)))
@@ -72,6 +74,12 @@ class CacheCtx:
         check(_lib.lib().cdlrm_ctx_bind_host_tables(self.handle, arr))
         self._host_ptrs = ptrs
 
+    def bind_victims(self, victims: Optional["Victims"]):
+        """Serve the aux-row fill of the per-iteration probe from the window's HBM-resident victim rows (None:
+        from the host tables again)."""
+        check(_lib.lib().cdlrm_ctx_bind_victims(self.handle, C.byref(victims.c) if victims is not None else None))
+        self._victims = victims
+
     def check(self, stream=None):
         """Raise if a kernel flagged out-of-range input (synchronises the stream)."""
         check(_lib.lib().cdlrm_ctx_check_sync(self.handle, stream_ptr(stream)))
@@ -79,16 +87,24 @@ class CacheCtx:
 
 # ---- per-iteration path --------------------------------------------------------------------------
 
-def embbag_probe(ctx: CacheCtx, idx: torch.Tensor, stream=None):
-    """idx int64 [T, n] on device -> (slots int32 [T, n], miss_pos int32 [T, n], miss_count int32 [T])."""
+def embbag_probe(ctx: CacheCtx, idx: torch.Tensor, stream=None, aux_phase: int = 0, out=None):
+    """idx int64 [T, n] on device -> (slots int32 [T, n], miss_pos int32 [T, n], miss_count int32 [T]).
+    aux_phase: which of the ctx's aux regions receives the misses' rows (double-buffered aux, see engine.py)."""
     _require_cuda(idx, "idx")
     assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.shape[0] == ctx.T and idx.stride(1) == 1
     n = idx.shape[1]
-    slots = torch.empty((ctx.T, n), dtype=torch.int32, device=idx.device)
-    miss_pos = torch.empty((ctx.T, n), dtype=torch.int32, device=idx.device)
-    miss_count = torch.empty((ctx.T,), dtype=torch.int32, device=idx.device)
+    if out is not None:
+        slots, miss_pos, miss_count = out
+        assert slots.shape == (ctx.T, n) and slots.dtype == torch.int32 and slots.is_contiguous()
+        assert miss_pos.shape == (ctx.T, n) and miss_pos.dtype == torch.int32 and miss_pos.is_contiguous()
+        assert miss_count.numel() == ctx.T and miss_count.dtype == torch.int32
+    else:
+        slots = torch.empty((ctx.T, n), dtype=torch.int32, device=idx.device)
+        miss_pos = torch.empty((ctx.T, n), dtype=torch.int32, device=idx.device)
+        miss_count = torch.empty((ctx.T,), dtype=torch.int32, device=idx.device)
     check(_lib.lib().cdlrm_embbag_probe(ctx.handle, idx.data_ptr(), n, idx.stride(0) if n else 0, slots.data_ptr(),
-                                        miss_pos.data_ptr(), miss_count.data_ptr(), stream_ptr(stream)))
+                                        miss_pos.data_ptr(), miss_count.data_ptr(), int(aux_phase),
+                                        stream_ptr(stream)))
     return slots, miss_pos, miss_count
 
 
@@ -214,6 +230,10 @@ class WindowPlan:
         check(_lib.lib().cdlrm_plan_fetch(self.ctx.handle, C.byref(self.c), arr, 1 if by_position else 0,
                                           stream_ptr(stream)))
 
+    def victims(self, victims: "Victims", stream=None):
+        """After assign(): list the window's indices that stay outside the cache and fetch their host rows."""
+        check(_lib.lib().cdlrm_plan_victims(self.ctx.handle, C.byref(self.c), C.byref(victims.c), stream_ptr(stream)))
+
     # K4 + K5b
     def commit(self, stream=None):
         check(_lib.lib().cdlrm_plan_commit(self.ctx.handle, C.byref(self.c), stream_ptr(stream)))
@@ -223,6 +243,20 @@ class WindowPlan:
         arr = (C.c_void_p * self.ctx.T)(*[int(p) for p in dst_ptrs])
         check(_lib.lib().cdlrm_plan_writeback(self.ctx.handle, C.byref(self.c), arr, 1 if average else 0,
                                               stream_ptr(stream)))
+
+
+class Victims:
+    """Caller-owned buffers of one window's victim rows (cdlrm_victims in the header)."""
+
+    def __init__(self, ctx: CacheCtx, cap: int):
+        dev = ctx.device
+        self.cap = max(1, int(cap))
+        self.pos = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.idx = torch.zeros(self.cap, dtype=torch.int64, device=dev)
+        self.off = torch.zeros(ctx.T + 1, dtype=torch.int64, device=dev)
+        self.rows = torch.empty((self.cap, ctx.D), dtype=torch.float32, device=dev)
+        self.c = _VictimsStruct(self.pos.data_ptr(), self.idx.data_ptr(), self.off.data_ptr(), self.rows.data_ptr(),
+                                self.cap)
 
 
 def gather_rows(src_ptr: int, index: torch.Tensor, dim: int, stream=None) -> torch.Tensor:

@@ -45,7 +45,9 @@ typedef struct {
     const int64_t* table_rows;   /* [T] n_k  rows of the host master table                 */
     const int64_t* cache_sets;   /* [T] P_k = min(n_k, find_next_prime(cache_size))        */
     int32_t device;              /* HIP device ordinal                                     */
-    int32_t reserved;
+    int32_t aux_phases;          /* 0/1: one aux region per table; 2: two (aux rows double-  */
+                                 /* buffered: the NEXT batch's misses are filled while the    */
+                                 /* current batch still trains on its own aux rows)           */
 } cdlrm_geometry;
 
 int cdlrm_abi_version(void);
@@ -55,7 +57,8 @@ int cdlrm_ctx_create(const cdlrm_geometry* geo, cdlrm_ctx** out);
 int cdlrm_ctx_destroy(cdlrm_ctx* ctx);
 
 /* Bind the caller-owned cache state.  tags: int64 [sum_k P_k*ways] (table k at element offset
- * sum_{j<k} P_j*ways); weight: fp32 [sum_k (ways*P_k+aux), D] (table k at row sum_{j<k} rows_j).
+ * sum_{j<k} P_j*ways); weight: fp32 [sum_k rows_k, D], rows_k = ways*P_k + aux*max(1, aux_phases) (table k at row
+ * sum_{j<k} rows_j; its first ways*P_k + aux rows are the reference's cache table).
  * Replaces the per-table nn.EmbeddingBag weights + CPU occupancy tables of model_no_ddp.py:130-147. */
 int cdlrm_ctx_bind_cache(cdlrm_ctx* ctx, int64_t* tags, float* weight);
 
@@ -81,9 +84,12 @@ int cdlrm_ctx_check_sync(cdlrm_ctx* ctx, void* stream);
  *              row (:176-179).
  *   miss_pos   device int32 [T, n]: positions of table k's misses in order, first miss_count[k]
  *              entries of row k valid (victim_cache_entries, model_no_ddp.py:187)
- *   miss_count device int32 [T]: number of misses per table.                                     */
+ *   miss_count device int32 [T]: number of misses per table.
+ *   aux_phase  which aux region receives the misses (0 unless the geometry has aux_phases = 2): aux slots are
+ *              then P_k*ways + aux_phase*aux + i.                                                  */
 int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx,
-                       int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, void* stream);
+                       int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, int32_t aux_phase,
+                       void* stream);
 
 /* Fused multi-table sum-pool gather: nn.EmbeddingBag(mode="sum") forward on the cache rows for all
  * T tables in one launch (model_no_ddp.py:200-203).
@@ -186,6 +192,22 @@ int cdlrm_plan_commit(cdlrm_ctx* ctx, const cdlrm_plan* plan, void* stream);
  * host[k][ev_tag] = row, or (host + row) / 2 with average != 0.  dst_rows as src_rows above. */
 int cdlrm_plan_writeback(cdlrm_ctx* ctx, const cdlrm_plan* plan, float* const* dst_rows,
                          int average, void* stream);
+
+/* Window victims: the window's unique indices that stay OUTSIDE the cache after this plan commits (not cached
+ * before, no way won).  The reference serves each of their lookups from the host table (aux rows,
+ * model_no_ddp.py:176-179) -- the same host row every time while the window trains.  cdlrm_plan_victims (after
+ * cdlrm_plan_assign, same stream) lists them and fetches their rows once into caller-owned HBM;
+ * cdlrm_ctx_bind_victims (at the commit of that window) makes cdlrm_embbag_probe fill aux rows from there, falling
+ * back to the host table for any index not in the list (beyond cap, or not from this window).  NULL unbinds. */
+typedef struct {
+    int32_t* pos;            /* [cap] positions into plan->uniq, ascending                                   */
+    int64_t* idx;            /* [cap] the indices, ascending per table                                       */
+    int64_t* off;            /* [T+1] start of table k                                                       */
+    float*   rows;           /* [cap, D] their host rows                                                     */
+    int64_t  cap;
+} cdlrm_victims;
+int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* victims, void* stream);
+int cdlrm_ctx_bind_victims(cdlrm_ctx* ctx, const cdlrm_victims* victims);
 
 /* Generic row gather used by the drop-in process_batch_slice (rows = W_host[uniq],
  * model_no_ddp.py:84): out[i, :] = src[index[i], :]. */

@@ -27,13 +27,14 @@ def register_host(tables):
 
 
 class CacheCtx:
-    def __init__(self, table_rows, cache_sets, dim, num_ways, aux_rows, device):
+    def __init__(self, table_rows, cache_sets, dim, num_ways, aux_rows, device, aux_phases=1):
         self.T = len(table_rows)
         self.D, self.ways, self.aux = int(dim), int(num_ways), int(aux_rows)
+        self.aux_phases = max(1, int(aux_phases))
         self.table_rows = [int(x) for x in table_rows]
         self.cache_sets = [int(x) for x in cache_sets]
         self.device = torch.device(device)
-        self.rows = [self.ways * p + self.aux for p in self.cache_sets]
+        self.rows = [self.ways * p + self.aux * self.aux_phases for p in self.cache_sets]
         self.row_base, self.tag_base = [0], [0]
         for k in range(self.T):
             self.row_base.append(self.row_base[-1] + self.rows[k])
@@ -53,18 +54,33 @@ class CacheCtx:
     def w(self, k):
         return self.weight[self.row_base[k]:self.row_base[k + 1]]
 
+    def bind_victims(self, victims):
+        pass                       # the test double always reads the host tables: same values
+
     def check(self, stream=None):
         pass
 
 
-def embbag_probe(ctx, idx, stream=None):
+class Victims:
+    def __init__(self, ctx, cap):
+        self.cap = cap
+
+
+def embbag_probe(ctx, idx, stream=None, aux_phase=0, out=None):
     T, n = idx.shape
-    slots = torch.empty(T, n, dtype=torch.int32)
-    miss_pos = torch.zeros(T, n, dtype=torch.int32)
-    miss_count = torch.zeros(T, dtype=torch.int32)
+    assert 0 <= aux_phase < ctx.aux_phases
+    if out is not None:
+        slots, miss_pos, miss_count = out
+        miss_pos.zero_()
+        miss_count.zero_()
+    else:
+        slots = torch.empty(T, n, dtype=torch.int32)
+        miss_pos = torch.zeros(T, n, dtype=torch.int32)
+        miss_count = torch.zeros(T, dtype=torch.int32)
     for k in range(T):
         s, mp, mi = O.probe_table(ctx.occ(k), idx[k], ctx.cache_sets[k])
         if mp.numel():
+            s[mp] += aux_phase * ctx.aux
             ctx.w(k)[s[mp]] = ctx.host[k][mi]
         slots[k] = s.to(torch.int32)
         miss_pos[k, :mp.numel()] = mp.to(torch.int32)
@@ -99,12 +115,16 @@ class WindowPlan:
     def __init__(self, ctx, max_window, cap_uniq=None, cap_win=None):
         self.ctx = ctx
         self.uniqs = None
+        self.cap_uniq = cap_uniq if cap_uniq is not None else sum(min(int(max_window), n) for n in ctx.table_rows)
 
     def unique(self, idx, stream=None):
         self.uniqs = [torch.from_numpy(np.unique(idx[k].numpy())) for k in range(self.ctx.T)]
 
     def set_unique(self, uniqs):
         self.uniqs = [u.clone() for u in uniqs]
+
+    def victims(self, victims, stream=None):
+        pass
 
     def probe(self, stream=None):
         self.kept_counts = []

@@ -28,7 +28,7 @@ def make_batches(g):
     return out
 
 
-def build(g, world=1, rank=0, host=None):
+def build(g, world=1, rank=0, host=None, aux_phases=2):
     from cdlrm_amd.engine import TrainEngine, WindowPipeline
     from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group
     ln_emb = np.array([int(x) for x in g["ln_emb"]])
@@ -41,7 +41,7 @@ def build(g, world=1, rank=0, host=None):
         host = Embedding_Table_Group(m_spa, ln_emb).pin()
     np.random.seed(seed)
     torch.manual_seed(seed)
-    cg = Embedding_Table_Cache_Group(m_spa, ln_emb, int(g["cache_size"]), B, int(g["ways"])).to(DEV)
+    cg = Embedding_Table_Cache_Group(m_spa, ln_emb, int(g["cache_size"]), B, int(g["ways"]), aux_phases=aux_phases).to(DEV)
     dl = DLRM_Net(np.array(g["ln_bot"]), ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(DEV)
     eng = TrainEngine(cg, dl, host, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), world_size=world, rank=rank,
                       table_agg_freq=int(g["agg_freq"]) if "agg_freq" in g.files else 10 ** 9,
@@ -50,12 +50,18 @@ def build(g, world=1, rank=0, host=None):
     return host, cg, dl, eng, pipe
 
 
-@pytest.mark.parametrize("name", ["train_small", "train_c1"])
-def test_loss_trajectory_and_tag_state(golden, name):
+@pytest.mark.parametrize("name,pipelined,aux_phases", [("train_small", False, 2), ("train_c1", False, 2),
+                                                        ("train_small", True, 2), ("train_c1", True, 2),
+                                                        ("train_small", True, 1)])
+def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases):
+    """pipelined: the next batch's indices are handed to step() (as bench.py does inside a window), so its tag probe
+    and aux-row fill run during the current step, into the other aux region (aux_phases = 2) or behind the current
+    embedding update (aux_phases = 1).  Same trajectory either way."""
     g = golden(name)
-    host, cg, dl, eng, pipe = build(g)
+    host, cg, dl, eng, pipe = build(g, aux_phases=aux_phases)
     L = int(g["L"])
     batches = make_batches(g)
+    dev_idx = [b[1].to(DEV) for b in batches]
     losses = []
     for j, (X, lS_i, Tt) in enumerate(batches):
         if j % L == 0:
@@ -64,8 +70,10 @@ def test_loss_trajectory_and_tag_state(golden, name):
             pipe.plan_window(win)
             pipe.commit()
             pipe.wait_writeback()
-        loss = eng.step(X.to(DEV), lS_i.to(DEV), Tt.to(DEV), j=j)
-        losses.append(float(loss[0]))
+        nxt = dev_idx[j + 1] if pipelined and j + 1 < len(batches) and (j + 1) % L != 0 else None
+        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt)
+        losses.append(loss[0:1].clone())
+    losses = [float(x) for x in losses]
     cg.ctx.check()
     np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-5)
     occ = cg.occupancy_tables

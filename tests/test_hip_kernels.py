@@ -189,6 +189,71 @@ def test_device_rng_mode_is_valid_insert(ops, golden):
             assert torch.equal(slots_rows[new], st.host[k][res[new]])
 
 
+@pytest.mark.parametrize("cap_mode", ["full", "cut"])
+def test_window_victims_serve_misses_from_hbm(ops, golden, cap_mode):
+    """cdlrm_plan_victims lists exactly the window's indices that stay outside the cache (unique - hits - winners)
+    with their host rows; with the list bound, the per-iteration probe fills aux rows with the same values the host
+    tables hold -- also for indices outside the list (not from the window / list cut at cap): host fallback."""
+    g = golden("cache_windows_small")
+    ln_emb, T, ways, B, cache_sizes, D = load_windows(g)
+    occ = O.new_occupancy_tables(cache_sizes, ways)
+    st = DevState(ops, ln_emb, cache_sizes, D, ways, 4 * B, occ, [torch.zeros(ways * cache_sizes[k] + 4 * B, D) for k in range(T)],
+                  [t(g[f"host0_{k}"]) for k in range(T)])
+    plan = ops.WindowPlan(st.ctx, int(g["L"]) * B)
+    rng = np.random.RandomState(5)
+    saw_victims = 0
+    for w in range(int(g["nwin"])):
+        win = t(g[f"w{w}_win"]).to(DEV)
+        pre = [st.occ(k).clone() for k in range(T)]
+        plan.unique(win); plan.probe(); plan.assign(None, seed=77 + w)
+        plan.fetch([h.data_ptr() for h in st.host], False)
+        uo, ko, wo = plan.offsets()
+        expect = []
+        for k in range(T):
+            u = torch.unique(win[k].cpu())
+            resident = pre[k][pre[k] != -1]
+            winners = plan.win_idx[wo[k]:wo[k + 1]].cpu()
+            expect.append(u[~torch.isin(u, resident) & ~torch.isin(u, winners)])
+        total = sum(int(e.numel()) for e in expect)
+        cap = max(1, total if cap_mode == "full" else total // 2)
+        vic = ops.Victims(st.ctx, cap)
+        plan.victims(vic)
+        plan.commit()
+        plan.writeback([h.data_ptr() for h in st.host], False)
+        torch.cuda.synchronize(); st.ctx.check()
+        off = vic.off.cpu().tolist()
+        flat = torch.cat(expect)[:cap]
+        assert off[T] == min(total, cap)
+        assert torch.equal(vic.idx[:off[T]].cpu(), flat)
+        lo = 0
+        for k in range(T):      # per-table boundaries of the (possibly cut) list
+            hi = min(cap, lo + int(expect[k].numel()))
+            assert off[k] == lo
+            assert torch.equal(vic.rows[lo:hi].cpu(), st.host[k][flat[lo:hi]])
+            lo = hi
+        saw_victims += total
+        # per-iteration probe: window ids + ids from outside the window, victims bound vs host reads
+        n = 3 * B
+        idx = torch.stack([torch.from_numpy(np.concatenate([
+            rng.choice(win[k].cpu().numpy(), n - n // 4), rng.randint(0, ln_emb[k], n // 4)])) for k in range(T)]).to(DEV)
+        st.ctx.bind_victims(vic)
+        s1, mp1, mc1 = ops.embbag_probe(st.ctx, idx)
+        torch.cuda.synchronize()
+        aux1 = [st.w(k)[ways * cache_sizes[k]:].clone() for k in range(T)]
+        st.weight.zero_()
+        st.ctx.bind_victims(None)
+        s2, mp2, mc2 = ops.embbag_probe(st.ctx, idx)
+        torch.cuda.synchronize(); st.ctx.check()
+        assert torch.equal(s1, s2) and torch.equal(mc1, mc2)
+        for k in range(T):
+            m = int(mc1[k])
+            ids = idx[k].cpu()[mp1[k, :m].long().cpu()]
+            assert torch.equal(aux1[k][:m], st.host[k][ids]), k
+            assert torch.equal(st.w(k)[ways * cache_sizes[k]:][:m], st.host[k][ids]), k
+        st.weight.zero_()
+    assert saw_victims > 0, "the fixture must exercise the victim path"
+
+
 @pytest.mark.parametrize("name", ["embsgd_onehot", "embsgd_multihot"])
 def test_embbag_bwd_sgd_golden(ops, golden, name):
     g = golden(name)
