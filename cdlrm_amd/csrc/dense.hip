@@ -305,11 +305,186 @@ __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ 
     }
 }
 
+// ---- software-pipelined variants (D = 32 / 64 / 128 / 256) ---------------------------------------------------
+// One wave per sample as above, but a wave walks its samples with the NEXT sample's rows already in flight: global ->
+// registers (prefetch) -> LDS (ds_write_b128, row pitch D+4 floats = odd multiple of 16 B: conflict-free b128 writes
+// and fragment reads) -> MFMA.  The feature matrix is both MFMA operands of T T^T, so one ds_read_b128 feeds four
+// MFMA steps (lane half lk holds contraction indices 8g + 4 lk .. +3, as in gemm.h).  No workgroup barrier: every
+// wave owns its LDS slice.  HBM-bound by design: 15.7 KB in + 1.9 KB out per sample against 64 MFMAs.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int D4>
+__device__ __forceinline__ void interact_prefetch(const float* __restrict__ feat, int64_t b, int FD4, int lane,
+                                                  v4f (&v)[D4 / 2]) {
+    const v4f* src = reinterpret_cast<const v4f*>(feat) + b * FD4;
+#pragma unroll
+    for (int i = 0; i < D4 / 2; ++i) v[i] = src[min(lane + 64 * i, FD4 - 1)];       // straight-line, clamped
+}
+
+template <int D4>
+__device__ __forceinline__ void interact_stage(float* __restrict__ Ts, int FD4, int lane, const v4f (&v)[D4 / 2]) {
+    constexpr int PITCH = 4 * D4 + 4;
+    // unconditional: slots past row F-1 receive (finite) copies of the last element; rows >= F never reach an output
+    // (forward: only pairs i, j < F are stored; backward: their S coefficients are zero).  A condition here makes
+    // the compiler keep the prefetch registers in scratch memory.
+#pragma unroll
+    for (int i = 0; i < D4 / 2; ++i) {
+        const int e = lane + 64 * i;
+        *reinterpret_cast<v4f*>(Ts + (e / D4) * PITCH + (e % D4) * 4) = v[i];
+    }
+}
+
+template <int D4>
+__global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict__ feat, int64_t B, int F, int itself,
+                                                        float* __restrict__ R, int64_t ld_r) {
+    constexpr int D = 4 * D4, PITCH = D + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    float* Ts = smem + wave * (32 * PITCH);
+    for (int e = lane; e < 32 * PITCH; e += 64) Ts[e] = 0.f;        // rows F..31 stay zero
+    const int FD4 = F * D4;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    v4f nxt[D4 / 2];
+    interact_prefetch<D4>(feat, b, FD4, lane, nxt);
+    for (; b < B; b += nw) {
+        interact_stage<D4>(Ts, FD4, lane, nxt);
+        interact_prefetch<D4>(feat, min(b + nw, B - 1), FD4, lane, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* tp = Ts + lr * PITCH + 4 * lk;
+#pragma unroll 4
+        for (int g = 0; g < D / 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(tp + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, a.w, acc, 0, 0, 0);
+        }
+        float* out = R + b * ld_r;
+        for (int c = lane; c < D; c += 64) out[c] = Ts[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (i < F && lr < i + (itself ? 1 : 0)) out[D + pair_base(i, itself) + lr] = acc[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// backward: dR row staged as float4 (needs ld_r % 4 == 0 and a 16-byte aligned dR)
+template <int D4>
+__global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict__ feat, const float* __restrict__ dR,
+                                                        int64_t ld_r, int64_t B, int F, int itself, int x_act,
+                                                        float* __restrict__ dfeat) {
+    constexpr int D = 4 * D4, PITCH = D + 4;
+    constexpr int GMAX = D + 528;               // dense part + up to 32*33/2 pair gradients
+    constexpr int NG = (GMAX / 4 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    float* Ts = smem + wave * (32 * PITCH + GMAX);
+    float* Gs = Ts + 32 * PITCH;
+    for (int e = lane; e < 32 * PITCH; e += 64) Ts[e] = 0.f;
+    const int FD4 = F * D4;
+    const int off = itself ? 1 : 0;
+    const int npairs = pair_base(F, itself);
+    const int G4 = (D + npairs + 3) / 4;        // float4 words of one dR row (the pad word lies inside the pitch)
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    v4f nxt[D4 / 2], gn[NG];
+    interact_prefetch<D4>(feat, b, FD4, lane, nxt);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) gn[i] = reinterpret_cast<const v4f*>(dR + b * ld_r)[min(lane + 64 * i, G4 - 1)];
+    for (; b < B; b += nw) {
+        interact_stage<D4>(Ts, FD4, lane, nxt);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) *reinterpret_cast<v4f*>(Gs + 4 * min(lane + 64 * i, GMAX / 4 - 1)) = gn[i];
+        const int64_t bn = min(b + nw, B - 1);
+        interact_prefetch<D4>(feat, bn, FD4, lane, nxt);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gn[i] = reinterpret_cast<const v4f*>(dR + bn * ld_r)[min(lane + 64 * i, G4 - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        // A fragments of S = G + G^T: lane holds S[lr][lk + 2m], m = 0..15
+        float sreg[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int j = lk + 2 * m;
+            float v = 0.f;
+            if (lr < F && j < F) {
+                if (j < lr + off) v += Gs[D + pair_base(lr, itself) + j];
+                if (lr < j + off) v += Gs[D + pair_base(j, itself) + lr];
+            }
+            sreg[m] = v;
+        }
+        float* out = dfeat + b * F * D;
+#pragma unroll 1
+        for (int n0 = 0; n0 < D; n0 += 32) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* tp = Ts + lk * PITCH + n0 + lr;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sreg[m], tp[2 * m * PITCH], acc, 0, 0, 0);
+            const int col = n0 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (i < F) {
+                    float v = acc[r];
+                    if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
+                        v += Gs[col];
+                        const float y = Ts[col];
+                        if (x_act == 1) v = y > 0.f ? v : 0.f;
+                        else if (x_act == 2) v = v * ((1.0f - y) * y);
+                    }
+                    out[i * D + col] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename K>
+static int interact_set_lds(K kernel, size_t lds, size_t* cached) {
+    if (lds > *cached) {
+        CDLRM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        *cached = lds;
+    }
+    return 0;
+}
+
 extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32_t itself, float* R,
                                   int64_t ld_r, void* stream) {
     CDLRM_REQUIRE(feat && R && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape (F<=32, D%4==0)");
     CDLRM_REQUIRE(aligned16(feat) && ld_r >= D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2), "alignment / ld_r");
     if (B == 0) return 0;
+    if (D == 32 || D == 64 || D == 128 || D == 256) {
+        const size_t ldsp = (size_t)4 * 32 * (D + 4) * sizeof(float);
+        int64_t gp = cdiv(B, 4);
+        if (gp > 512) gp = 512;             // 2 workgroups per CU (LDS), each wave streams ~4 samples
+        static size_t a32 = 0, a64 = 0, a128 = 0, a256 = 0;
+#define IFWD(D4_, A_)                                                                                          \
+    do {                                                                                                       \
+        int rc = interact_set_lds(k_interact_fwd_p<D4_>, ldsp, &A_);                                           \
+        if (rc) return rc;                                                                                     \
+        hipLaunchKernelGGL(k_interact_fwd_p<D4_>, dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, feat, B, \
+                           F, itself, R, ld_r);                                                                \
+    } while (0)
+        if (D == 32) IFWD(8, a32);
+        else if (D == 64) IFWD(16, a64);
+        else if (D == 128) IFWD(32, a128);
+        else IFWD(64, a256);
+#undef IFWD
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)4 * (32 * (D + 1) + 32) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
@@ -329,6 +504,25 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     CDLRM_REQUIRE(aligned16(feat), "alignment");
     if (B == 0) return 0;
     const int npairs = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    if ((D == 32 || D == 64 || D == 128) && ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3)) {
+        const size_t ldsp = (size_t)4 * (32 * (D + 4) + D + 528) * sizeof(float);
+        int64_t gp = cdiv(B, 4);
+        if (gp > 512) gp = 512;
+        static size_t b32 = 0, b64 = 0, b128 = 0;
+#define IBWD(D4_, A_)                                                                                          \
+    do {                                                                                                       \
+        int rc = interact_set_lds(k_interact_bwd_p<D4_>, ldsp, &A_);                                           \
+        if (rc) return rc;                                                                                     \
+        hipLaunchKernelGGL(k_interact_bwd_p<D4_>, dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, feat, dR, \
+                           ld_r, B, F, itself, x_act, dfeat);                                                  \
+    } while (0)
+        if (D == 32) IBWD(8, b32);
+        else if (D == 64) IBWD(16, b64);
+        else IBWD(32, b128);
+#undef IBWD
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)4 * (32 * (D + 1) + 32 + ((npairs + 3) & ~3)) * sizeof(float);
     CDLRM_REQUIRE(lds <= 160 * 1024, "LDS budget");
     static size_t attr = 0;

@@ -459,6 +459,30 @@ def test_fused_activation_backward_chain(ops, M):
     np.testing.assert_allclose(dfeat[:, 0].cpu().numpy(), pre0.grad.float().numpy(), **tol)
 
 
+@pytest.mark.parametrize("B,F,D,itself,pad", [(3000, 27, 128, 0, 1), (2049, 9, 32, 1, 3), (700, 32, 64, 0, 0),
+                                               (5000, 27, 128, 1, 2), (33, 27, 256, 0, 1), (257, 4, 16, 0, 0),
+                                               (1, 27, 128, 0, 1)])
+def test_interaction_kernels_vs_torch(ops, B, F, D, itself, pad):
+    """Pairwise-dot interaction forward/backward (software-pipelined kernels for D = 32/64/128/256, generic otherwise)
+    against torch autograd on the oracle's interact_features; R/dR with a padded row pitch as the engine uses."""
+    rng = np.random.RandomState(B + F + D)
+    feat = torch.from_numpy(rng.randn(B, F, D).astype(np.float32))
+    npairs = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+    width = D + npairs + pad
+    f = feat.clone().double().requires_grad_(True)
+    ref = O.interact_features(f[:, 0, :], [f[:, k, :] for k in range(1, F)], "dot", bool(itself))
+    G = torch.from_numpy(rng.randn(B, width).astype(np.float32))
+    ref.backward(G[:, :D + npairs].double())
+    fd = feat.to(DEV)
+    R = torch.full((B, width), 7.0, device=DEV)
+    ops.interact_fwd(fd, bool(itself), R)
+    np.testing.assert_allclose(R[:, :D + npairs].cpu().numpy(), ref.detach().float().numpy(), rtol=2e-5, atol=2e-5)
+    assert bool((R[:, D + npairs:] == 7.0).all())           # pad columns untouched
+    dfeat = torch.empty_like(fd)
+    ops.interact_bwd(fd, G.to(DEV), bool(itself), dfeat)
+    np.testing.assert_allclose(dfeat.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
+
+
 @pytest.mark.parametrize("M", [64, 1000, 2048, 4100])
 def test_mlp_wgrad_group(ops, M):
     """All layers' weight + bias gradients in one call (grouped LDS-free launch up to M = 2048, tiled split-M path

@@ -53,6 +53,7 @@ def _worker_body(rank, world, port, name, host_shared, ret):
     pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
     lbs = B // world
     losses = []
+    dev_idx = {}
     batches = _batches(g)
     for j, (X, lS_i, Tt) in enumerate(batches):
         if j % L == 0:
@@ -62,7 +63,13 @@ def _worker_body(rank, world, port, name, host_shared, ret):
             pipe.commit()
             pipe.wait_writeback()
         sl = slice(rank * lbs, (rank + 1) * lbs)
-        loss = eng.step(X[sl].to(dev), lS_i[:, sl].contiguous().to(dev), Tt[sl].to(dev), j=j)
+        if j not in dev_idx:
+            dev_idx[j] = lS_i[:, sl].contiguous().to(dev)
+        nxt = None
+        if j + 1 < len(batches) and (j + 1) % L != 0:       # same window: pipeline the next batch's probe / aux fill
+            dev_idx[j + 1] = batches[j + 1][1][:, sl].contiguous().to(dev)
+            nxt = dev_idx[j + 1]
+        loss = eng.step(X[sl].to(dev), dev_idx[j], Tt[sl].to(dev), j=j, next_idx=nxt)
         losses.append(float(loss[0]))
     cg.ctx.check()
     lin = M._linears(dl.top_l)
