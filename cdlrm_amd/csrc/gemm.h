@@ -11,7 +11,7 @@
 // Measured (tools/gemm_ablate.hip, 8192x512x512): 80 TF with staging, 107 TF with the staging ablated; the vendor
 // sgemm reaches 95-113 TF on the forward/dgrad shapes and 40-77 TF on the wgrad shapes, i.e. the MLP as a whole
 // runs at the library's speed.  Tried without gain: LDS double-buffering, 2-stage register prefetch, BK=64,
-// step-major MFMA order.
+// step-major MFMA order, two accumulators per wave in the 64x64 tile (two MFMA dependency chains: 90.5 vs 93.7 TF).
 #pragma once
 #include "common.h"
 

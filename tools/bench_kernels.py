@@ -85,8 +85,9 @@ def main():
         F = 27
         feat = torch.randn(B, F, D, device=DEV)
         npairs = F * (F - 1) // 2
-        R = torch.empty(B, D + npairs, device=DEV)
-        dR = torch.randn(B, D + npairs, device=DEV)
+        width = (D + npairs + 3) // 4 * 4          # the engine pads the interaction output to a 16-byte row pitch
+        R = torch.empty(B, width, device=DEV)
+        dR = torch.randn(B, width, device=DEV)
         dfeat = torch.empty_like(feat)
         us = timeit(lambda: ops.interact_fwd(feat, False, R))
         byt = B * (F * D * 4 + (D + npairs) * 4)

@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     for (int64_t i = 0; i < M * K; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     hipMemcpy(X, h, M * K * 4, hipMemcpyHostToDevice);
     hipMemcpy(W, h, (size_t)N * K * 4, hipMemcpyHostToDevice);
-    GemmArgs g;
+    GemmArgs g = gemm_args();
     g.A = X; g.lda = K; g.B = W; g.ldb = K; g.C = Y; g.ldc = N; g.slab = 0;
     g.M = M; g.N = N; g.K = K; g.kchunk = K; g.bias = b; g.act = 1; g.vecA = 1; g.vecB = 1;
     hipEvent_t e0, e1;
