@@ -461,6 +461,74 @@ __global__ void __launch_bounds__(256) k_writeback(int T, int D4, int lpr, const
 
 static int lanes_per_row_w(int D4) { int l = pow2ceil(D4); return l > 64 ? 64 : (l < 4 ? 4 : l); }
 
+// Rows of the pinned HOST tables -> HBM, for the plan's bulk fetches (winners, victims).  PCIe-bound: the link needs
+// ~1 MB of reads in flight, not thousands of waves -- a wide grid of waves parked on PCIe round trips takes the wave
+// slots of every CU and starves the training kernels running beside the plan (measured: GEMMs 2x slower for the
+// 180 ms per window the old 2048-workgroup fetches ran).  So: a SMALL grid, HOSTROWS_U independent 16-B reads per
+// lane, loads phased (ids first, then all host reads back to back -- see k_fill_aux).
+#define HOSTROWS_U 8
+template <bool VIA_POS>
+__global__ void __launch_bounds__(256) k_host_rows(int T, int D4, const int64_t* __restrict__ off, int64_t cap,
+                                                   const int64_t* __restrict__ ids, const int32_t* __restrict__ pos,
+                                                   const int64_t* __restrict__ uniq, float* const* __restrict__ src,
+                                                   float4* __restrict__ out, int64_t* __restrict__ idx_out) {
+    __shared__ int64_t soff[1025];
+    __shared__ uint64_t sptr[1024];
+    for (int k = threadIdx.x; k <= T; k += blockDim.x) soff[k] = off[k];
+    for (int k = threadIdx.x; k < T; k += blockDim.x) sptr[k] = (uint64_t)(uintptr_t)src[k];
+    __syncthreads();
+    const int64_t n = min(soff[T], cap);
+    const int64_t total = n * D4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f32x4* host_ptr;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * HOSTROWS_U) {
+        int64_t j[HOSTROWS_U], id[HOSTROWS_U];
+        int c[HOSTROWS_U];
+        host_ptr sp[HOSTROWS_U];
+        f32x4 v[HOSTROWS_U];
+#pragma unroll
+        for (int u = 0; u < HOSTROWS_U; ++u) {
+            const int64_t e = min(e0 + u * stride, total - 1);
+            j[u] = e / D4;
+            c[u] = (int)(e % D4);
+            sp[u] = (host_ptr)sptr[table_of(soff, T, j[u])];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (VIA_POS) {
+            int32_t p[HOSTROWS_U];
+#pragma unroll
+            for (int u = 0; u < HOSTROWS_U; ++u) p[u] = pos[j[u]];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < HOSTROWS_U; ++u) id[u] = uniq[p[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < HOSTROWS_U; ++u) id[u] = ids[j[u]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < HOSTROWS_U; ++u) v[u] = sp[u][id[u] * D4 + c[u]];
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional stores: elements past the end were clamped to the last one (same value, same address)
+#pragma unroll
+        for (int u = 0; u < HOSTROWS_U; ++u) {
+            *reinterpret_cast<f32x4*>(out + j[u] * D4 + c[u]) = v[u];
+            if (VIA_POS) idx_out[j[u]] = id[u];
+        }
+    }
+}
+
+static int host_rows_grid() {
+    static int g = -1;
+    if (g < 0) {
+        const char* e = getenv("CDLRM_HOSTROWS_GRID");     // development switch
+        g = e ? atoi(e) : 32;
+        if (g < 1) g = 1;
+    }
+    return g;
+}
+
 extern "C" int cdlrm_plan_fetch(cdlrm_ctx* ctx, const cdlrm_plan* plan, const float* const* src_rows, int by_position,
                                 void* stream) {
     CDLRM_REQUIRE(ctx && plan && src_rows, "null argument");
@@ -472,6 +540,14 @@ extern "C" int cdlrm_plan_fetch(cdlrm_ctx* ctx, const cdlrm_plan* plan, const fl
     int64_t gx = cdiv(plan->cap_win * lpr, 256);
     if (gx > WIN_BLOCKS) gx = WIN_BLOCKS;
     if (gx < 1) gx = 1;
+    if (!by_position) {
+        CDLRM_REQUIRE(ctx->T <= 1024, "more than 1024 tables");
+        hipLaunchKernelGGL(k_host_rows<false>, dim3((unsigned)host_rows_grid()), dim3(256), 0, s, ctx->T, D4, plan->win_off,
+                           plan->cap_win, plan->win_idx, nullptr, nullptr, ctx->d_ptr_fetch,
+                           reinterpret_cast<float4*>(plan->stage), nullptr);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_fetch, dim3((unsigned)gx), dim3(256), 0, s, ctx->T, D4, lpr, plan->win_off, plan->cap_win,
                        plan->win_idx, plan->win_claim, plan->kept, plan->uniq_off, ctx->d_ptr_fetch, by_position,
                        reinterpret_cast<float4*>(plan->stage));
@@ -532,23 +608,6 @@ __global__ void __launch_bounds__(WIN_THREADS) k_victim_unflag(const int64_t* __
         flags[kept[win_claim[w]]] = 0;
 }
 
-__global__ void __launch_bounds__(256) k_victim_fetch(int T, int D4, int lpr, const int64_t* __restrict__ v_off, int64_t cap,
-                                                      const int32_t* __restrict__ v_pos, const int64_t* __restrict__ uniq,
-                                                      float* const* __restrict__ src, int64_t* __restrict__ v_idx,
-                                                      float4* __restrict__ v_rows) {
-    const int64_t Vn = min(v_off[T], cap);
-    const int c = threadIdx.x % lpr;
-    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
-    const int64_t ng = (int64_t)gridDim.x * blockDim.x / lpr;
-    for (int64_t j = g0; j < Vn; j += ng) {
-        const int t = table_of(v_off, T, j);
-        const int64_t id = uniq[v_pos[j]];
-        if (c == 0) v_idx[j] = id;
-        const float4* sp = reinterpret_cast<const float4*>(src[t]) + id * D4;
-        for (int cc = c; cc < D4; cc += lpr) v_rows[j * D4 + cc] = sp[cc];
-    }
-}
-
 extern "C" int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* v, void* stream) {
     CDLRM_REQUIRE(ctx && plan && v, "null argument");
     CDLRM_REQUIRE(v->pos && v->idx && v->off && v->rows && v->cap >= 1 && ((uintptr_t)v->rows & 15) == 0, "victim buffers");
@@ -575,12 +634,10 @@ extern "C" int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const 
     if (rc) return rc;
     hipLaunchKernelGGL(k_offsets_from_sorted, dim3(cdiv(ctx->T + 1, 64)), dim3(64), 0, s, v->pos, ctx->d_small + 2, v->cap,
                        plan->uniq_off, ctx->T, v->off);
-    const int D4 = ctx->D / 4, lpr = lanes_per_row_w(D4);
-    int64_t gf = cdiv(v->cap * lpr, 256);
-    if (gf > WIN_BLOCKS) gf = WIN_BLOCKS;
-    if (gf < 1) gf = 1;
-    hipLaunchKernelGGL(k_victim_fetch, dim3((unsigned)gf), dim3(256), 0, s, ctx->T, D4, lpr, v->off, v->cap, v->pos,
-                       plan->uniq, ctx->d_host_rows, v->idx, reinterpret_cast<float4*>(v->rows));
+    CDLRM_REQUIRE(ctx->T <= 1024, "more than 1024 tables");
+    const int D4 = ctx->D / 4;
+    hipLaunchKernelGGL(k_host_rows<true>, dim3((unsigned)host_rows_grid()), dim3(256), 0, s, ctx->T, D4, v->off, v->cap,
+                       nullptr, v->pos, plan->uniq, ctx->d_host_rows, reinterpret_cast<float4*>(v->rows), v->idx);
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
