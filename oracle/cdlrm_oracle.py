@@ -325,10 +325,13 @@ def embbag_bwd_sgd(weight: torch.Tensor, slots: torch.Tensor, offsets: torch.Ten
 
 def init_mlp(ln: Sequence[int]):
     """model_no_ddp.py:244-262: per layer W ~ N(0, sqrt(2/(m+n))) [m,n], b ~ N(0, sqrt(1/m)) [m],
-    drawn from the *numpy* global RNG in that order, float32."""
+    drawn from the *numpy* global RNG in that order, float32.  The reference constructs `nn.Linear(n, m)` first
+    (:252), whose default init draws from the torch CPU generator before the weights are replaced: those draws are
+    reproduced (and discarded) here because the insert's Exp(1) draws come from the same stream later."""
     ws, bs = [], []
     for i in range(len(ln) - 1):
         n, m = int(ln[i]), int(ln[i + 1])
+        torch.nn.Linear(n, m, bias=True)
         W = np.random.normal(0.0, np.sqrt(2 / (m + n)), size=(m, n)).astype(np.float32)
         b = np.random.normal(0.0, np.sqrt(1 / m), size=m).astype(np.float32)
         ws.append(torch.tensor(W))

@@ -52,7 +52,8 @@ def build(g, world=1, rank=0, host=None, aux_phases=2):
 
 @pytest.mark.parametrize("name,pipelined,aux_phases", [("train_small", False, 2), ("train_c1", False, 2),
                                                         ("train_small", True, 2), ("train_c1", True, 2),
-                                                        ("train_small", True, 1)])
+                                                        ("train_small", True, 1), ("train_stream", False, 2),
+                                                        ("train_stream", True, 2)])
 def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases):
     """pipelined: the next batch's indices are handed to step() (as bench.py does inside a window), so its tag probe
     and aux-row fill run during the current step, into the other aux region (aux_phases = 2) or behind the current
@@ -66,7 +67,9 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases):
     for j, (X, lS_i, Tt) in enumerate(batches):
         if j % L == 0:
             win = torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV)
-            torch.manual_seed(5000 + j)          # the q stream the reference consumed for this refill
+            if "reseed" not in g.files or bool(g["reseed"]):
+                torch.manual_seed(5000 + j)      # the q stream the reference consumed for this refill
+            # (train_stream: no re-seeding -- the draws continue the stream the trainer's construction left behind)
             pipe.plan_window(win)
             pipe.commit()
             pipe.wait_writeback()

@@ -1,0 +1,91 @@
+"""`main_no_ddp.Run` (the reference's trainer entry, main_no_ddp.py:324-502) end to end on the MI355X: the loop that a
+user of the reference's CLI gets, against the oracle's trainer on the same loader, host tables and seeds -- the loss
+printed every iteration (print-freq 1) within 1e-5 relative, the final tag state bit-exact; and the module's
+`main()` with the reference's flag spelling on synthetic Criteo-shaped data."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cdlrm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = ["--arch-sparse-feature-size=16", "--arch-mlp-bot=13-32-16", "--arch-mlp-top=32-1",
+         "--arch-embedding-size=3000-50-7-1200-40000", "--mini-batch-size=64", "--lookahead=4", "--cache-size=40",
+         "--num-ways=4", "--loss-function=bce", "--round-targets=True", "--learning-rate=0.1", "--lr-embeds=0.3",
+         "--print-freq=1", "--world-size=1", "--numpy-rand-seed=11", "--table-agg-freq=5"]
+
+
+def _loader(ln_emb, B, nb, seed):
+    rng = np.random.RandomState(seed)
+    lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+    out = []
+    for _ in range(nb):
+        X = torch.from_numpy(rng.rand(B, 13).astype(np.float32))
+        idx = torch.stack([torch.from_numpy((rng.zipf(1.2, size=B).astype(np.int64) * 2654435761 % n)) for n in ln_emb])
+        T = torch.from_numpy(np.round(rng.rand(B, 1)).astype(np.float32))
+        out.append((X, lS_o, idx, T))
+    return out
+
+
+class _Loader(list):
+    pass
+
+
+def test_run_matches_oracle_trainer(capsys):
+    from cdlrm_amd.main_no_ddp import ProcessArgs, Run
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    args = ProcessArgs(FLAGS)
+    ln_emb = np.array([3000, 50, 7, 1200, 40000])
+    m_spa, B, L, nb, seed = 16, 64, 4, 14, 11            # 14 batches: three full windows and a short last one
+    ln_bot = np.array([13, 32, 16])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+    batches = _Loader(_loader(ln_emb, B, nb, 5))
+    # oracle
+    torch.set_num_threads(1)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host_o = O.init_host_tables([int(n) for n in ln_emb], m_spa)
+    otr = O.OracleTrainer([int(n) for n in ln_emb], m_spa, ln_bot, ln_top, cache_size=40, num_ways=4, mini_batch_size=B,
+                          lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=5, seed=seed,
+                          host_tables=[h.clone() for h in host_o])
+    for j, (X, lS_o, idx, T) in enumerate(batches):
+        if j % L == 0:
+            otr.refill(torch.cat([b[2] for b in batches[j:j + L]], dim=1))
+        otr.step(j, X, lS_o, idx, T)
+    # Run
+    eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+    for k in range(len(ln_emb)):
+        eg.emb_l[k].weight.data = host_o[k].clone()
+    eg.pin()
+    capsys.readouterr()
+    eng = Run(0, m_spa, ln_emb, ln_bot, ln_top, batches, None, None, None, None, eg, args)
+    printed = capsys.readouterr().out
+    got = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", printed)]
+    want = np.array([l[0] for l in otr.losses])
+    # the reference prints for j > 0 and resets its running sums at every print (main_no_ddp.py:455-477): the first
+    # line averages iterations 0 and 1, every later line is one iteration
+    assert len(got) == nb - 1
+    expect = np.concatenate([[(want[0] + want[1]) / 2], want[2:]])
+    np.testing.assert_allclose(np.array(got), expect, rtol=1e-5)
+    eng.cg.ctx.check()
+    for k in range(len(ln_emb)):
+        assert torch.equal(eng.cg.occupancy_tables[k].cpu(), otr.occ[k]), k
+        np.testing.assert_allclose(eg.emb_l[k].weight.data.double().sum().item(), otr.host[k].double().sum().item(),
+                                   rtol=1e-6, atol=1e-6)
+
+
+def test_main_cli_synthetic(capsys):
+    """python -m cdlrm_amd.main_no_ddp <reference flags> on Criteo-shaped synthetic data: runs, prints the
+    reference's progress line, the loss stays finite and the cache state is consistent."""
+    from cdlrm_amd import main_no_ddp
+    main_no_ddp.main(FLAGS + ["--data-generation=criteo-synthetic", "--num-batches=21", "--device-rng"])
+    out = capsys.readouterr().out
+    lines = [l for l in out.splitlines() if l.startswith("Epoch 0: Finished")]
+    assert len(lines) == 20
+    losses = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", out)]
+    assert all(np.isfinite(losses)) and 0.3 < losses[-1] < 1.0
+    assert "Caching overhead" in lines[0] and "Train Acc" in lines[0]

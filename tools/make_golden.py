@@ -338,7 +338,7 @@ def g_embbag_sgd(M, MD, CM, QR):
 
 
 def ref_train(M, MD, CM, QR, *, ln_emb, m_spa, ln_bot, top, cache_size, ways, B, L, nbatch, seed,
-              lr, lr_emb, alpha):
+              lr, lr_emb, alpha, reseed=True):
     """World-size-1 replay of Run's loop body (main_no_ddp.py:387-415) around the reference's own
     objects: Prefetcher.process_batch_slice -> CacheEmbeddings -> cache_group -> DLRM_Net -> BCELoss
     -> backward -> optimizer_embeds.step -> optimizer_mlps.step.  Schedule: prefetch distance 0,
@@ -372,7 +372,8 @@ def ref_train(M, MD, CM, QR, *, ln_emb, m_spa, ln_bot, top, cache_size, ways, B,
             win = torch.cat([b[2] for b in batches[j:j + L]], dim=1)
             rows, uniqs, maps = CM.Prefetcher.process_batch_slice(win, eg)
             fifo = queue.Queue()
-            torch.manual_seed(5000 + j)
+            if reseed:      # False: ONE generator stream from the trainer's seeding on, as Run itself runs
+                torch.manual_seed(5000 + j)
             M.CacheEmbeddings(rows, uniqs, maps, cg, fifo, rank)
             evq = queue.Queue()
             evq.put(fifo.get())
@@ -399,6 +400,11 @@ def g_train_w1(M, MD, CM, QR):
         # small, eviction-heavy
         "train_small": dict(ln_emb=[3000, 50, 7, 1200], m_spa=8, ln_bot=[4, 16, 8], top=[16, 1], cache_size=40,
                             ways=4, B=32, L=4, nbatch=40, seed=9, lr=0.1, lr_emb=0.3, alpha=1.3),
+        # no re-seeding before the refills: the way choices depend on every draw the trainer made since its
+        # seeding (cache-table init, nn.Linear default init) -- pins the generator-stream contract of Run
+        "train_stream": dict(ln_emb=[3000, 50, 7, 1200, 40000], m_spa=16, ln_bot=[13, 32, 16], top=[32, 1],
+                             cache_size=40, ways=4, B=64, L=4, nbatch=14, seed=11, lr=0.1, lr_emb=0.3, alpha=1.2,
+                             reseed=False),
     }
     for name, c in cfgs.items():
         r = ref_train(M, MD, CM, QR, **c)
