@@ -105,11 +105,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    # development: CDLRM_BENCH_EMULATE=1 runs the N ranks on ONE GPU with gloo collectives (RCCL cannot place two ranks
+    # on a device) -- exercises the whole multi-rank path on a 1-GPU box; its numbers mean nothing
+    emulate = os.environ.get("CDLRM_BENCH_EMULATE", "0") == "1"
+    if emulate:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:

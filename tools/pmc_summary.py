@@ -47,6 +47,8 @@ def main():
     doc = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py "
                    "--no-cpu-baseline --steps 300 --warmup 50 (two separate passes, MI355X, 1 GPU, config c3)",
+        "workload": "c3",
+        "n_gpus": 1,
         "kernel": gk,
         "FETCH_SIZE_KB_median": fe[gk]["median_counter_KB"],
         "WRITE_SIZE_KB_median": wr[gk]["median_counter_KB"],
