@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cdlrm_linear_bwd_work_bytes": (c_u64, [c_i64, c_i32, c_i32]),
     "cdlrm_linear_bwd": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i32, c_i32,
                                    c_i32, c_i32, vp, vp]),
+    "cdlrm_mlp_wgrad_work_bytes": (c_u64, [c_i32, c_i64, vp, vp]),
     "cdlrm_mlp_wgrad": (C.c_int, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp]),
     "cdlrm_bce_fwd_bwd": (C.c_int, [vp, vp, c_i64, vp, vp, c_i32, vp]),
     "cdlrm_sgd_step": (C.c_int, [vp, vp, c_i64, c_f32, vp]),
@@ -91,11 +92,50 @@ PROTOTYPES = {
 }
 
 _lib: Optional[C.CDLL] = None
+_proxy = None
+_tape: Optional[list] = None        # when a list: every library call is appended as (function, args) before it is made
 
 
-def lib() -> C.CDLL:
+class _Recording:
+    """Thin view of the library whose calls can be recorded: the engine records the launch sequence of a training
+    step once and replays it (same functions, same argument objects) without the Python around each launch."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)          # AttributeError for an unknown symbol
+
+        def call(*args):
+            if _tape is not None:
+                _tape.append((fn, args))
+            return fn(*args)
+
+        call.__name__ = name
+        self.__dict__[name] = call
+        return call
+
+
+def start_recording(tape: list) -> None:
+    global _tape
+    _tape = tape
+
+
+def stop_recording() -> None:
+    global _tape
+    _tape = None
+
+
+def record(fn, *args):
+    """Run a non-library call (event record / stream wait) and, while recording, put it on the tape as well."""
+    if _tape is not None:
+        _tape.append((fn, args))
+    return fn(*args)
+
+
+def lib():
     """The loaded library; raises loudly when it is missing (no fallback path exists)."""
-    global _lib
+    global _lib, _proxy
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise CdlrmLibraryError(
@@ -109,7 +149,8 @@ def lib() -> C.CDLL:
         if l.cdlrm_abi_version() != 1:
             raise CdlrmLibraryError("ABI version mismatch")
         _lib = l
-    return _lib
+        _proxy = _Recording(l)
+    return _proxy
 
 
 def check(rc: int) -> None:

@@ -37,19 +37,17 @@ __global__ void __launch_bounds__(256) k_act_grad(const float* __restrict__ Y, i
     }
 }
 
-// Two reductions in one launch (dW slabs and the bias-gradient partials of the same layer): blocks [0, gxa) work
-// on job A, the rest on job B.  Fixed summation order (slab 0, 1, 2, ...): reproducible; 4 slabs in flight.
-__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ partA, int64_t countA, int splitsA,
-                                                      float* __restrict__ outA, int gxa,
-                                                      const float* __restrict__ partB, int64_t countB, int splitsB,
-                                                      float* __restrict__ outB) {
-    const bool jobA = (int)blockIdx.x < gxa;
-    if (!jobA) {
-        // job B (bias gradient): few elements, many partials -> 4 lanes per element, each summing every 4th
+// Two reductions in one job (dW slabs and the bias-gradient partials of the same layer): logical blocks [0, gxa) work
+// on part A, the rest on part B.  Fixed summation order (slab 0, 1, 2, ...): reproducible; 4 slabs in flight.
+__device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restrict__ partA, int64_t countA, int splitsA,
+                                                  float* __restrict__ outA, int gxa, const float* __restrict__ partB,
+                                                  int64_t countB, int splitsB, float* __restrict__ outB,
+                                                  float (*red)[64]) {
+    if (bid >= gxa) {
+        // part B (bias gradient): few elements, many partials -> 4 lanes per element, each summing every 4th
         // partial, combined in a fixed order through LDS
-        __shared__ float red[4][64];
         const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
-        const int64_t e = (int64_t)(blockIdx.x - gxa) * 64 + c;
+        const int64_t e = (int64_t)(bid - gxa) * 64 + c;
         float s = 0.f;
         if (e < countB)
             for (int z = sub; z < splitsB; z += 4) s += partB[(int64_t)z * countB + e];
@@ -58,23 +56,47 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
         if (sub == 0 && e < countB) outB[e] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
         return;
     }
-    const float* part = partA;
-    const int64_t count = countA;
-    const int splits = splitsA;
-    float* out = outA;
-    const int64_t bid = blockIdx.x;
-    const int64_t nblk = gxa;
-    for (int64_t e = bid * blockDim.x + threadIdx.x; e < count; e += nblk * blockDim.x) {
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < countA; e += (int64_t)gxa * blockDim.x) {
         float s = 0.f;
         int z = 0;
-        for (; z + 4 <= splits; z += 4) {
-            const float v0 = part[(int64_t)z * count + e], v1 = part[(int64_t)(z + 1) * count + e];
-            const float v2 = part[(int64_t)(z + 2) * count + e], v3 = part[(int64_t)(z + 3) * count + e];
+        for (; z + 4 <= splitsA; z += 4) {
+            const float v0 = partA[(int64_t)z * countA + e], v1 = partA[(int64_t)(z + 1) * countA + e];
+            const float v2 = partA[(int64_t)(z + 2) * countA + e], v3 = partA[(int64_t)(z + 3) * countA + e];
             s += v0; s += v1; s += v2; s += v3;
         }
-        for (; z < splits; ++z) s += part[(int64_t)z * count + e];
-        out[e] = s;
+        for (; z < splitsA; ++z) s += partA[(int64_t)z * countA + e];
+        outA[e] = s;
     }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ partA, int64_t countA, int splitsA,
+                                                      float* __restrict__ outA, int gxa,
+                                                      const float* __restrict__ partB, int64_t countB, int splitsB,
+                                                      float* __restrict__ outB) {
+    __shared__ float red[4][64];
+    reduce_slabs_body((int)blockIdx.x, partA, countA, splitsA, outA, gxa, partB, countB, splitsB, outB, red);
+}
+
+// the reductions of several layers in one launch (grouped weight gradients)
+struct ReduceJob {
+    const float* partA; int64_t countA; float* outA; int gxa;
+    const float* partB; int64_t countB; float* outB;
+    int splits;
+};
+struct ReduceGroup {
+    int n;
+    unsigned first[GEMM_GROUP_MAX + 1];
+    ReduceJob j[GEMM_GROUP_MAX];
+};
+__global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup grp) {
+    __shared__ float red[4][64];
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+        if (q < grp.n && blockIdx.x >= grp.first[q]) p = q;
+    const ReduceJob& r = grp.j[p];
+    reduce_slabs_body((int)(blockIdx.x - grp.first[p]), r.partA, r.countA, r.splits, r.outA, r.gxa, r.partB, r.countB,
+                      r.splits, r.outB, red);
 }
 
 // Weight-gradient contraction (over the batch) is cut into slabs when the batch is long: small batches go to the
@@ -95,6 +117,24 @@ extern "C" uint64_t cdlrm_linear_bwd_work_bytes(int64_t M, int32_t N, int32_t K)
     const uint64_t slabs = splits * N * K * 4;
     const uint64_t cs = splits * N * 4;
     return ((slabs + 255) & ~(uint64_t)255) + ((cs + 255) & ~(uint64_t)255) + 256;
+}
+
+// scratch for cdlrm_mlp_wgrad: every layer's slabs at once on the grouped small-batch path, the largest layer's
+// otherwise
+extern "C" uint64_t cdlrm_mlp_wgrad_work_bytes(int32_t n_layers, int64_t M, const int32_t* N, const int32_t* K) {
+    uint64_t total = 256, largest = 0;
+    if (!N || !K) return 0;
+    if (M <= WGRAD_DIRECT_MAX_M) {
+        const uint64_t zs = (uint64_t)cdiv(M, 4 * GBK) + 1;         // upper bound of the split count
+        for (int i = 0; i < n_layers; ++i)
+            total += ((zs * N[i] * K[i] * 4 + 255) & ~(uint64_t)255) + ((zs * N[i] * 4 + 255) & ~(uint64_t)255);
+        return total;
+    }
+    for (int i = 0; i < n_layers; ++i) {
+        const uint64_t b = cdlrm_linear_bwd_work_bytes(M, N[i], K[i]);
+        if (b > largest) largest = b;
+    }
+    return largest;
 }
 
 extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y, float* dY,
@@ -160,16 +200,103 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
                   "bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (M <= WGRAD_DIRECT_MAX_M) {
-        std::vector<GemmArgs> probs((size_t)n_layers);
+        // Small batches, all layers at once.  Layers whose operands are 16-byte loadable go through the LDS-tiled
+        // kernel as ONE grouped launch, the contraction (the batch) cut into slabs so that the group has ~1000
+        // workgroups; the rest (13-wide input, 1-wide output) through the grouped LDS-free kernel with the same slabs;
+        // then ONE grouped reduction of all layers (fixed slab order).  CDLRM_WGRAD_TILED=0: everything LDS-free.
+        static int use_tiled = -1;
+        if (use_tiled < 0) {
+            const char* e = getenv("CDLRM_WGRAD_TILED");
+            use_tiled = e ? atoi(e) : 1;
+        }
+        std::vector<GemmArgs> direct, tiled;
+        std::vector<int> direct_layer, tiled_layer;
+        int64_t tiles = 0;
         for (int i = 0; i < n_layers; ++i) {
             CDLRM_REQUIRE(X[i] && dZ[i] && dW[i] && N[i] >= 1 && K[i] >= 1 && ld_x[i] >= K[i] && ld_dz[i] >= N[i],
                           "bad layer argument");
             GemmArgs g = gemm_args();
             g.A = dZ[i]; g.lda = ld_dz[i]; g.B = X[i]; g.ldb = ld_x[i]; g.C = dW[i]; g.ldc = K[i];
             g.M = N[i]; g.N = K[i]; g.K = M; g.kchunk = M; g.colsum = db[i];
-            probs[(size_t)i] = g;
+            g.vecA = aligned16(dZ[i]) && ld_dz[i] % 4 == 0 && N[i] % 4 == 0;
+            g.vecB = aligned16(X[i]) && ld_x[i] % 4 == 0 && K[i] % 4 == 0;
+            if (use_tiled && g.vecA && g.vecB && M >= 256) {
+                tiled.push_back(g);
+                tiled_layer.push_back(i);
+                tiles += cdiv(N[i], 64) * cdiv(K[i], 64);
+            } else {
+                direct.push_back(g);
+                direct_layer.push_back(i);
+            }
         }
-        return launch_wgrad_group(probs.data(), n_layers, s);
+        // one split count for the whole group (slabs of the batch); 1 = no slabs, no reduction
+        int64_t kchunk = M;
+        int zs = 1;
+        if (!tiled.empty()) {
+            int64_t splits = cdiv(1024, tiles);
+            const int64_t smax = cdiv(M, 4 * GBK);
+            if (splits > smax) splits = smax;
+            if (splits < 1) splits = 1;
+            kchunk = cdiv(cdiv(M, splits), GBK) * GBK;
+            zs = (int)cdiv(M, kchunk);
+        }
+        CDLRM_REQUIRE(zs == 1 || (work && ((uintptr_t)work & 255) == 0), "work must be 256-byte aligned");
+        char* wp = (char*)work;
+        std::vector<ReduceJob> jobs;
+        auto slabbed = [&](GemmArgs& g, int li) {          // redirect one problem's outputs to its slabs
+            const int64_t cnt = (int64_t)N[li] * K[li];
+            g.kchunk = kchunk;
+            g.slab = cnt;
+            if (zs == 1) return;
+            float* slabs = (float*)wp;
+            wp += (((uint64_t)zs * cnt * 4) + 255) & ~(uint64_t)255;
+            float* cs = (float*)wp;
+            wp += (((uint64_t)zs * N[li] * 4) + 255) & ~(uint64_t)255;
+            g.C = slabs;
+            g.colsum = db[li] ? cs : nullptr;
+            ReduceJob r;
+            r.partA = slabs; r.countA = cnt; r.outA = dW[li];
+            int64_t gxa = cdiv(cnt, 1024);
+            if (gxa > 256) gxa = 256;
+            r.gxa = (int)gxa;
+            r.partB = cs; r.countB = db[li] ? N[li] : 0; r.outB = db[li];
+            r.splits = zs;
+            jobs.push_back(r);
+        };
+        for (size_t q = 0; q < direct.size(); ++q) slabbed(direct[q], direct_layer[q]);
+        for (size_t q = 0; q < tiled.size(); ++q) slabbed(tiled[q], tiled_layer[q]);
+        if (!direct.empty()) {
+            int rc = launch_wgrad_group(direct.data(), (int)direct.size(), s);
+            if (rc) return rc;
+        }
+        for (size_t q0 = 0; q0 < tiled.size(); q0 += GEMM_GROUP_MAX) {
+            GemmGroup grp;
+            memset(&grp, 0, sizeof(grp));
+            unsigned blocks = 0;
+            for (size_t q = q0; q < tiled.size() && q < q0 + GEMM_GROUP_MAX; ++q) {
+                grp.first[grp.n] = blocks;
+                grp.g[grp.n] = tiled[q];
+                blocks += (unsigned)(cdiv(tiled[q].M, 64) * cdiv(tiled[q].N, 64) * zs);
+                grp.n++;
+            }
+            grp.first[grp.n] = blocks;
+            hipLaunchKernelGGL((k_gemm_group<false, false, true, true>), dim3(blocks), dim3(256), 0, s, grp);
+        }
+        for (size_t q0 = 0; q0 < jobs.size(); q0 += GEMM_GROUP_MAX) {
+            ReduceGroup red;
+            memset(&red, 0, sizeof(red));
+            unsigned rblocks = 0;
+            for (size_t q = q0; q < jobs.size() && q < q0 + GEMM_GROUP_MAX; ++q) {
+                red.first[red.n] = rblocks;
+                red.j[red.n] = jobs[q];
+                rblocks += (unsigned)(jobs[q].gxa + cdiv(jobs[q].countB, 64));
+                red.n++;
+            }
+            red.first[red.n] = rblocks;
+            hipLaunchKernelGGL(k_reduce_group, dim3(rblocks), dim3(256), 0, s, red);
+        }
+        CDLRM_LAUNCH_CHECK();
+        return 0;
     }
     for (int i = 0; i < n_layers; ++i) {
         // dY = dZ with act 0, no dX: only the weight-gradient part of cdlrm_linear_bwd runs

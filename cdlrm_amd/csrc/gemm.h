@@ -104,21 +104,30 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (
     }
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2), so give
+// each XCD a contiguous run of logical tiles: the tiles of one row panel then re-read A from their own L2
+// instead of fetching it once per XCD.  Bijective for any grid size; placement only affects speed.
+__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
+    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
+    return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
+}
+
+// Several independent GEMMs of one operand layout in ONE launch (the weight gradients of all layers of the MLPs: at
+// small batches every launch costs ~10 us of fixed latency against a few us of MFMA work, and one problem alone
+// cannot fill the chip).  Workgroup -> problem by the running workgroup count.
+#define GEMM_GROUP_MAX 8
+struct GemmGroup {
+    int n;
+    unsigned first[GEMM_GROUP_MAX + 1];      // first[p] .. first[p+1]: workgroups of problem p (x fastest, then y, then z)
+    GemmArgs g[GEMM_GROUP_MAX];
+};
+
 template <bool A_KC, bool B_KC, int TM, int TN, bool VA, bool VB>
-__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, unsigned bx, unsigned by, unsigned bz,
+                                               float* __restrict__ As, float* __restrict__ Bs) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_KC];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_KC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2), so give
-    // each XCD a contiguous run of logical tiles: the tiles of one row panel then re-read A from their own L2
-    // instead of fetching it once per XCD.  Bijective for any grid size; placement only affects speed.
-    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
-    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
-    const unsigned bx = wgid % gridDim.x, by = (wgid / gridDim.x) % gridDim.y, bz = wgid / (gridDim.x * gridDim.y);
     const int64_t m0 = (int64_t)by * BM;
     const int64_t n0 = (int64_t)bx * BN;
     const int64_t kbeg = (int64_t)bz * g.kchunk;
@@ -239,6 +248,32 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         }
 }
 
+template <bool A_KC, bool B_KC, int TM, int TN, bool VA, bool VB>
+__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[64 * TM * LDS_KC];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * TN * LDS_KC];
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nwg);
+    gemm_tile_body<A_KC, B_KC, TM, TN, VA, VB>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y,
+                                               wgid / (gridDim.x * gridDim.y), As, Bs);
+}
+
+// grouped launch of 64x64-tile problems, each with its own contraction split (slabs + a grouped reduction)
+template <bool A_KC, bool B_KC, bool VA, bool VB>
+__global__ void __launch_bounds__(256) k_gemm_group(GemmGroup grp) {
+    __shared__ __attribute__((aligned(16))) float As[64 * LDS_KC];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * LDS_KC];
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+        if (q < grp.n && wgid >= grp.first[q]) p = q;
+    const GemmArgs& g = grp.g[p];
+    const unsigned local = wgid - grp.first[p];
+    const unsigned gx = (unsigned)((g.N + 63) / 64), gy = (unsigned)((g.M + 63) / 64);
+    gemm_tile_body<A_KC, B_KC, 1, 1, VA, VB>(g, local % gx, (local / gx) % gy, local / (gx * gy), As, Bs);
+}
+
 // ---- small problems: LDS-free GEMM -------------------------------------------------------------------
 // When the tiled kernel's grid cannot fill the chip (M <= ~2048 with these layer widths: 128 workgroups, one wave per
 // SIMD, every K tile paying a full load latency -- 20 us for 0.5 GFLOP) the work is re-cut finer: one workgroup per
@@ -293,12 +328,6 @@ __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&
 }
 
 // LOOP = false: each wave's share of the contraction is <= 64 (one batch of loads, no loop)
-// XCD-aware bijective renumbering of a 1-D grid (see k_gemm)
-__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
-    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
-    return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
-}
-
 template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
 __device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsigned by, unsigned bz,
                                             float (*red)[32][33], float (*csr)[32]) {
@@ -395,16 +424,6 @@ __global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
                                           wgid / (gridDim.x * gridDim.y), red, csr);
 }
 
-// Several independent small GEMMs of one operand layout in ONE launch (the weight gradients of all layers of the
-// MLPs: at small batches every launch costs ~10 us of fixed latency against ~3 us of MFMA work, and one problem
-// alone cannot fill the chip).  Workgroup -> problem by the running workgroup count.
-#define GEMM_GROUP_MAX 8
-struct GemmGroup {
-    int n;
-    unsigned first[GEMM_GROUP_MAX + 1];      // first[p] .. first[p+1]: workgroups of problem p (x fastest, then y)
-    GemmArgs g[GEMM_GROUP_MAX];
-};
-
 template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
 __global__ void __launch_bounds__(256) k_gemm_direct_group(GemmGroup grp) {
     __shared__ float red[4][32][33];
@@ -416,8 +435,8 @@ __global__ void __launch_bounds__(256) k_gemm_direct_group(GemmGroup grp) {
         if (q < grp.n && wgid >= grp.first[q]) p = q;
     const GemmArgs& g = grp.g[p];
     const unsigned local = wgid - grp.first[p];
-    const unsigned gx = (unsigned)((g.N + 31) / 32);
-    direct_body<A_KC, B_KC, VA, VB, LOOP>(g, local % gx, local / gx, 0, red, csr);
+    const unsigned gx = (unsigned)((g.N + 31) / 32), gy = (unsigned)((g.M + 31) / 32);
+    direct_body<A_KC, B_KC, VA, VB, LOOP>(g, local % gx, (local / gx) % gy, local / (gx * gy), red, csr);
 }
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -494,14 +513,16 @@ static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s
             blocks = 0;
         };
         for (int i = 0; i < n; ++i) {
-            const bool loop = cdiv(probs[i].K, 32) * 8 > 64;
+            // kchunk < K: the contraction is cut into slabs (C + z*slab, colsum + z*M), summed by the caller
+            const int64_t kc = probs[i].kchunk > 0 && probs[i].kchunk < probs[i].K ? probs[i].kchunk : probs[i].K;
+            const bool loop = cdiv(kc, 32) * 8 > 64;
             if ((int)loop != want_loop) continue;
             if (grp.n == GEMM_GROUP_MAX) flush();
             grp.first[grp.n] = blocks;
             grp.g[grp.n] = probs[i];
-            grp.g[grp.n].kchunk = probs[i].K;
-            grp.g[grp.n].vecC = aligned16(probs[i].C) && probs[i].ldc % 4 == 0;
-            blocks += (unsigned)(cdiv(probs[i].M, 32) * cdiv(probs[i].N, 32));
+            grp.g[grp.n].kchunk = kc;
+            grp.g[grp.n].vecC = aligned16(probs[i].C) && probs[i].ldc % 4 == 0 && probs[i].slab % 4 == 0;
+            blocks += (unsigned)(cdiv(probs[i].M, 32) * cdiv(probs[i].N, 32) * cdiv(probs[i].K, kc));
             grp.n++;
         }
         flush();

@@ -14,13 +14,16 @@ boundary (main_no_ddp.py:393-399, 148-209; cache_manager.py:66-115).
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from . import _streams as S
 from . import ops
+from ._lib import record as rec
 from .model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group, _linears
 
 
@@ -144,6 +147,11 @@ class TrainEngine:
         self._pref = None
         self._phase = 0                             # aux region of the batch being trained
         self._emb_done = None
+        ne = lambda: S.new_event(self.dev)
+        self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
+                            emb_done=ne())
+        self._tapes = {}
+        self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -199,6 +207,8 @@ class TrainEngine:
         work = 0
         for l, _ in self.bot + self.top:
             work = max(work, ops.linear_bwd_work(B, l.out_features, self.W[l].shape[1], dev).numel())
+        work = max(work, ops.mlp_wgrad_work(B, [l.out_features for l, _ in self.bot + self.top],
+                                            [self.W[l].shape[1] for l, _ in self.bot + self.top], dev).numel())
         b["lin_work"] = torch.empty(work, dtype=torch.uint8, device=dev)
         # weight/bias gradients of all layers are taken at the end of the backward, from the pre-activation
         # gradients the dgrad chain leaves in these buffers (one grouped launch at small batches)
@@ -271,7 +281,7 @@ class TrainEngine:
         on the device; lS_o None = Criteo layout; j = batch number inside the epoch (table-agg schedule).
         Returns the device loss buffer (element 0 = BCE loss)."""
         B, n = X.shape[0], lS_i.shape[1]
-        main = S.current_stream(self.dev)
+        sgd_done = False
         if getattr(self, "use_graph", False) and gather_events is None and lS_o is None:
             key = (B, n)
             g = self._graphs.get(key)
@@ -300,13 +310,18 @@ class TrainEngine:
                 j = self.iter
             if self.world > 1 and j > 0 and j % self.agg_freq == 0:
                 next_idx = None      # the row merge below rewrites touched aux rows: no fill may be in flight
-            self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
+            sgd_done = False
+            if self.use_tape and gather_events is None and lS_o is None:
+                sgd_done = self._step_taped(X, lS_i, T, next_idx)
+            else:
+                self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
         # ---- dense gradient exchange + SGD ----
         if self.world > 1:
             gw = self.grad_flat[:self.n_weight]
             ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
             dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
-        ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
+        if not sgd_done:
+            ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
         # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
         if j is None:
             j = self.iter
@@ -326,20 +341,22 @@ class TrainEngine:
         # ---- forward ----
         # tag probe + aux-row fill (PCIe) on the side stream, under the bottom MLP -- or already done: the previous
         # step issues them for this batch behind its embedding backward (software-pipelined across iterations)
+        # Stream/event calls go through `rec` so that a recorded step (see _step_taped) replays them too; the events
+        # are persistent engine objects (a wait always sees the latest record, whichever tape issued it).
         main = S.current_stream(self.dev)
         side = self.side
+        ev = self._events
         two_phase = ctx.aux_phases >= 2
         pref, self._pref = self._pref, None
         if pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape):
             slots, miss_pos, miss_count, probed = pref["res"]
             self._phase = pref["phase"]
         else:
-            side.wait_stream(main)
-            with S.on_stream(side):
-                slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side, aux_phase=self._phase,
-                                                               out=self._probe_bufs(n, self._phase))
-                probed = S.new_event(self.dev)
-                probed.record(side)
+            rec(side.wait_stream, main)
+            slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side, aux_phase=self._phase,
+                                                           out=self._probe_bufs(n, self._phase))
+            probed = ev["probed_inline"]
+            rec(probed.record, side)
         cur = X
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
@@ -348,7 +365,7 @@ class TrainEngine:
             bot_acts.append(y)
             cur = y
         # the gather runs alone on the main stream (it is the HBM-roofline kernel: nothing competes for bandwidth)
-        main.wait_event(probed)
+        rec(main.wait_event, probed)
         if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
             e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
             e0.record(main)
@@ -362,23 +379,22 @@ class TrainEngine:
             # reads at c3) start right behind this batch's gather, on their own stream, into the OTHER aux region
             # (this batch still reads and updates its own aux rows).  The other region was last used by the previous
             # batch: its embedding update must have landed (emb_done).
-            ev_g = S.new_event(self.dev)
-            ev_g.record(main)
+            ev_g = ev["gathered"]
+            rec(ev_g.record, main)
             pst = self.pref
-            pst.wait_event(ev_g)
+            rec(pst.wait_event, ev_g)
             if self._emb_done is not None:
-                pst.wait_event(self._emb_done)
-            with S.on_stream(pst):
-                ph = 1 - self._phase
-                res = ops.embbag_probe(ctx, next_idx, stream=pst, aux_phase=ph, out=self._probe_bufs(n, ph))
-                ev = S.new_event(self.dev)
-                ev.record(pst)
+                rec(pst.wait_event, self._emb_done)
+            ph = 1 - self._phase
+            res = ops.embbag_probe(ctx, next_idx, stream=pst, aux_phase=ph, out=self._probe_bufs(n, ph))
+            evp = ev["probed"][ph]
+            rec(evp.record, pst)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=ph,
-                              res=(res[0], res[1], res[2], ev))
+                              res=(res[0], res[1], res[2], evp))
         # the backward's sort of the slot ids needs nothing but the probe result: run it on the side, under the MLPs
         emb_work = self._emb_work(n)
-        with S.on_stream(side):
-            ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
+        rec(side.wait_event, probed)
+        ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         ops.interact_fwd(feat, self.itself, R)
         cur = R
         top_acts = [R]
@@ -409,20 +425,21 @@ class TrainEngine:
         ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
-        self.side.wait_stream(main)
-        with S.on_stream(self.side):
-            ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, emb_work, cg.touched,
-                                 stream=self.side)
-            emb_done = S.new_event(self.dev)
-            emb_done.record(self.side)
-            self._emb_done = emb_done
-            if next_idx is not None and not two_phase:
-                # single aux region: the next batch's fill can only follow this batch's embedding update
-                res = ops.embbag_probe(ctx, next_idx, stream=self.side, out=self._probe_bufs(n, 2 + (self.iter & 1)))
-                ev = S.new_event(self.dev)
-                ev.record(self.side)
-                self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
-                                  res=(res[0], res[1], res[2], ev))
+        rec(ev["interacted"].record, main)
+        rec(side.wait_event, ev["interacted"])
+        ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, emb_work, cg.touched,
+                             stream=side)
+        emb_done = ev["emb_done"]
+        rec(emb_done.record, side)
+        self._emb_done = emb_done
+        if next_idx is not None and not two_phase:
+            # single aux region: the next batch's fill can only follow this batch's embedding update
+            which = 2 + (self.iter & 1)
+            res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
+            evp = ev["probed"][which]
+            rec(evp.record, side)
+            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
+                              res=(res[0], res[1], res[2], evp))
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
@@ -434,9 +451,73 @@ class TrainEngine:
         plan.set_x(0, X)
         ops.mlp_wgrad(plan)
         if next_idx is None:
-            main.wait_stream(self.side)      # full join (also what a hipGraph capture needs)
+            rec(main.wait_stream, side)      # full join (also what a hipGraph capture needs)
         else:
-            main.wait_event(emb_done)        # cache rows are updated; the prefetched probe keeps running
+            rec(main.wait_event, emb_done)   # cache rows are updated; the prefetched probe keeps running
+
+    # ----------------------------------------------------------------------------------------------
+    def _step_taped(self, X, lS_i, T, next_idx):
+        """The same launch sequence as _fwd_bwd, replayed from a recording.  At small local batches the ~30 launches
+        of a step take less GPU time than the Python around them (argument marshalling, stream lookups): the first
+        step of each control path (batch shape, aux phase, prefetched or in-line probe, next batch handed over or
+        not) runs _fwd_bwd under `_lib.start_recording`, later ones re-issue the recorded (function, arguments)
+        list.  Pointers that change from step to step (X, T, the index tensors) are shared ctypes cells patched before
+        each replay; everything else the step touches is a preallocated buffer with a fixed address."""
+        import ctypes as C
+        B, n = X.shape[0], lS_i.shape[1]
+        main = S.current_stream(self.dev)
+        pref = self._pref
+        hit = pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape)
+        phase = pref["phase"] if hit else self._phase
+        nxt = next_idx is not None
+        key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
+               next_idx.stride(0) if nxt else 0, (self.iter & 1) if self.ctx.aux_phases < 2 else 0)
+        tape = self._tapes.get(key)
+        if tape is None:
+            calls = []
+            _lib.start_recording(calls)
+            try:
+                self._fwd_bwd(X, lS_i, T, None, None, next_idx)
+                if self.world == 1:         # no gradient exchange in between: the dense SGD rides on the tape too
+                    ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
+            finally:
+                _lib.stop_recording()
+            # pointer arguments equal to one of the per-step tensors become shared cells
+            cells = {"X": C.c_void_p(X.data_ptr()), "T": C.c_void_p(T.data_ptr()), "idx": C.c_void_p(lS_i.data_ptr())}
+            if nxt:
+                cells["next"] = C.c_void_p(next_idx.data_ptr())
+            by_value = {c.value: c for c in cells.values()}
+            if len(by_value) != len(cells):
+                return self.world == 1      # aliased inputs: stay on the untaped path
+            prog = []
+            for fn, args in calls:
+                if getattr(fn, "argtypes", None) is not None:
+                    args = tuple(by_value.get(a, a) if isinstance(a, int) and not isinstance(a, bool) else a for a in args)
+                    prog.append((fn, args, True))
+                else:
+                    prog.append((fn, args, False))
+            post = self._pref
+            self._tapes[key] = dict(prog=prog, cells=cells, phase=self._phase,
+                                    pref=None if post is None else (post["phase"], post["res"]))
+            return self.world == 1
+        cells = tape["cells"]
+        cells["X"].value = X.data_ptr()
+        cells["T"].value = T.data_ptr()
+        cells["idx"].value = lS_i.data_ptr()
+        if nxt:
+            cells["next"].value = next_idx.data_ptr()
+        self._buffers(B)["wgrad"].set_x(0, X)
+        for fn, args, is_lib in tape["prog"]:
+            rc = fn(*args)
+            if is_lib and rc:
+                _lib.check(rc)
+        # the state _fwd_bwd leaves behind
+        self._phase = tape["phase"]
+        self._emb_done = self._events["emb_done"]
+        self._pref = None
+        if tape["pref"] is not None:
+            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1])
+        return self.world == 1
 
     def table_aggregate(self):
         """broadcast_and_aggregate (main_no_ddp.py:250-292): average the rows any rank touched since the last

@@ -328,6 +328,14 @@ def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=Non
                                       stream_ptr(stream)))
 
 
+def mlp_wgrad_work(M: int, Ns: Sequence[int], Ks: Sequence[int], device) -> torch.Tensor:
+    """Scratch for mlp_wgrad over layers with output widths Ns and input widths Ks at batch M."""
+    n = len(Ns)
+    NA = C.c_int32 * n
+    nbytes = int(_lib.lib().cdlrm_mlp_wgrad_work_bytes(n, int(M), NA(*[int(x) for x in Ns]), NA(*[int(x) for x in Ks])))
+    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+
+
 class WgradPlan:
     """Host-side argument block of cdlrm_mlp_wgrad for a fixed set of layers and buffers (built once per batch shape;
     `set_x` re-points one layer's input, e.g. the dense features of the current batch)."""
@@ -351,6 +359,8 @@ class WgradPlan:
         for x, d, w in zip(Xs, dZs, dWs):
             assert x.shape[0] == self.M and d.shape[0] == self.M and x.stride(1) == 1 and d.stride(1) == 1
             assert w.is_contiguous() and d.shape[1] == w.shape[0] and x.shape[1] <= w.shape[1] <= x.stride(0)
+        need = int(_lib.lib().cdlrm_mlp_wgrad_work_bytes(n, self.M, self.N, self.K))
+        assert work.numel() * work.element_size() >= need and work.data_ptr() % 256 == 0, "work too small: ops.mlp_wgrad_work"
         self.work = work
 
     def set_x(self, i: int, x: torch.Tensor):

@@ -291,7 +291,9 @@ int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* 
  * cdlrm_linear_bwd(dW = NULL) left behind: dW[i] [N[i], K[i]] = dZ[i]^T X[i], db[i] [N[i]] (entries may be NULL)
  * = column sums of dZ[i].  The arrays are HOST arrays of device pointers / sizes.  Replaces the per-parameter
  * autograd accumulation of the reference's loss.backward() (main_no_ddp.py:409) for the MLP weights: at small
- * per-GPU batches all layers run as one grouped launch.  work: as for cdlrm_linear_bwd, sized for the largest layer. */
+ * per-GPU batches all layers run as one grouped launch (+ one grouped reduction of the batch slabs).
+ * work: device scratch of cdlrm_mlp_wgrad_work_bytes(...) bytes, 256-byte aligned. */
+uint64_t cdlrm_mlp_wgrad_work_bytes(int32_t n_layers, int64_t M, const int32_t* N, const int32_t* K);
 int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
                     const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
                     const int32_t* K, void* work, void* stream);

@@ -228,6 +228,10 @@ def linear_bwd(X, W, Y, dY, dX, dW, db, act, work, stream=None, x_act=0):
         db.copy_(dY.sum(0))
 
 
+def mlp_wgrad_work(M, Ns, Ks, device):
+    return torch.empty(1)
+
+
 class WgradPlan:
     def __init__(self, Xs, dZs, dWs, dbs, work):
         self.Xs, self.dZs, self.dWs, self.dbs = list(Xs), list(dZs), list(dWs), list(dbs)

@@ -497,10 +497,7 @@ def test_mlp_wgrad_group(ops, M):
         dZs.append(torch.from_numpy(rng.randn(M, N).astype(np.float32)).to(DEV))
         dWs.append(torch.empty(N, K, device=DEV))
         dbs.append(None if n == 2 else torch.empty(N, device=DEV))
-    work = 0
-    for N, K in shapes:
-        work = max(work, ops.linear_bwd_work(M, N, K, DEV).numel())
-    plan = ops.WgradPlan(Xs, dZs, dWs, dbs, torch.empty(work, dtype=torch.uint8, device=DEV))
+    plan = ops.WgradPlan(Xs, dZs, dWs, dbs, ops.mlp_wgrad_work(M, [s[0] for s in shapes], [s[1] for s in shapes], DEV))
     ops.mlp_wgrad(plan)
     ops.mlp_wgrad(plan)          # idempotent: no accumulation into the outputs
     torch.cuda.synchronize()
