@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, name, host_shared, ret):
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)        # a stuck worker says where, instead of a silent time-out
     try:
         _worker_body(rank, world, port, name, host_shared, ret)
     except BaseException as e:      # a dead worker must fail the test, not hang it
