@@ -491,6 +491,32 @@ class TrainEngine:
             rec(main.wait_event, emb_done)   # cache rows are updated; the prefetched probe keeps running
 
     # ----------------------------------------------------------------------------------------------
+    def evaluate(self, X: torch.Tensor, lS_i: torch.Tensor, lS_o: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Forward only (the test loop of main_no_ddp.py:479-494: `cache_group(lS_o, lS_i, emb_tables, rank)` then
+        `dlrm(X, lookups)` under no_grad): tag probe with the aux-miss path (test indices outside the cache read their
+        host rows -- into the aux region of the batch trained last, whose rows are dead), cached gather, bottom MLP,
+        interaction, top MLP.  Returns Z [B, 1] (a buffer reused by the next call)."""
+        ctx = self.ctx
+        B, n = X.shape[0], lS_i.shape[1]
+        assert n <= ctx.aux, "test batch larger than the aux table (test_mini_batch_size <= aux_table_size)"
+        buf = self._buffers(B)
+        feat, R = buf["feat"], buf["R"]
+        F, D = self.F, self.D
+        slots, _, _ = ops.embbag_probe(ctx, lS_i, aux_phase=self._phase, out=self._probe_bufs(n, "eval"))
+        cur = X
+        for i, (l, act) in enumerate(self.bot):
+            y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
+            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
+            cur = y
+        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+        ops.interact_fwd(feat, self.itself, R)
+        cur = R
+        for i, (l, act) in enumerate(self.top):
+            y = buf["top_y"][i]
+            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
+            cur = y
+        return cur
+
     def _step_taped(self, X, lS_i, T, next_idx):
         """The same launch sequence as _fwd_bwd, replayed from a recording.  At small local batches the ~30 launches
         of a step take less GPU time than the Python around them (argument marshalling, stream lookups): the first

@@ -374,6 +374,22 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     total_time = total_iter = total_samp = 0
                     total_loss = total_accu = 0.0
                     caching_overhead = []
+                # Testing -- only rank 0 tests (main_no_ddp.py:478-494).  The reference's `j % args.test_freq == 0`
+                # with its default test_freq = -1 is true for every j; here test_freq <= 0 means "at the end only".
+                last = (j == len(train_ld) - 1)
+                if test_ld is not None and ((j > 0 and args.test_freq > 0 and j % args.test_freq == 0) or last):
+                    print('Testing at {}/{}....'.format(j, len(train_ld)), flush=True)
+                    test_samp = 0
+                    total_test_acc = 0
+                    for Xt, lS_ot, lS_it, Tt in test_ld:
+                        lS_it = torch.as_tensor(lS_it) if not isinstance(lS_it, (list, tuple)) else torch.stack(
+                            [torch.as_tensor(s).reshape(-1) for s in lS_it])
+                        Zt = eng.evaluate(Xt.to(dev), lS_it.to(dev))
+                        S_ = Zt.cpu().numpy()
+                        Tn = Tt.cpu().numpy()
+                        total_test_acc += np.sum((np.round(S_, 0) == Tn).astype(np.uint32))
+                        test_samp += Tn.shape[0]
+                    print('Test accuracy = {}%'.format(100 * (total_test_acc / test_samp)), flush=True)
             j += 1
     torch.cuda.synchronize()
     return eng

@@ -509,6 +509,14 @@ class OracleTrainer:
                 self.weights[r][k].copy_(self.weights[0][k])            # broadcast, :318-319
         return ev, details
 
+    def evaluate(self, X, lS_o, lS_i):
+        """The test loop body of main_no_ddp.py:484-487 on rank 0: forward through the cache group (aux rows of the
+        misses are overwritten with the host rows, as in training) and the MLPs, no gradient.  Returns Z [B, 1]."""
+        with torch.no_grad():
+            ly, _ = cache_forward(self.occ, self.weights[0], self.cache_sizes, [lS_o[k] for k in range(len(self.ln_emb))],
+                                  [lS_i[k] for k in range(len(self.ln_emb))], self.host)
+            return dlrm_forward(X, ly, self.bot[0], self.top[0], self.op, self.itself)
+
     def step(self, j, X, lS_o, lS_i, T):
         """One iteration of main_no_ddp.py:387-423 for all emulated ranks.  Returns per-rank losses."""
         Wn, lbs = self.W, self.lbs

@@ -37,13 +37,15 @@ class _Loader(list):
 def test_run_matches_oracle_trainer(capsys):
     from cdlrm_amd.main_no_ddp import ProcessArgs, Run
     from cdlrm_amd.model_no_ddp import Embedding_Table_Group
-    args = ProcessArgs(FLAGS)
+    args = ProcessArgs(FLAGS + ["--test-freq=5"])
     ln_emb = np.array([3000, 50, 7, 1200, 40000])
     m_spa, B, L, nb, seed = 16, 64, 4, 14, 11            # 14 batches: three full windows and a short last one
     ln_bot = np.array([13, 32, 16])
     nf = len(ln_emb) + 1
     ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
     batches = _Loader(_loader(ln_emb, B, nb, 5))
+    test_batches = _loader(ln_emb, B, 3, 77)              # the rank-0 test loop (main_no_ddp.py:478-494)
+    want_acc = []
     # oracle
     torch.set_num_threads(1)
     np.random.seed(seed)
@@ -56,13 +58,24 @@ def test_run_matches_oracle_trainer(capsys):
         if j % L == 0:
             otr.refill(torch.cat([b[2] for b in batches[j:j + L]], dim=1))
         otr.step(j, X, lS_o, idx, T)
+        if (j > 0 and j % 5 == 0) or j == nb - 1:
+            ok = tot = 0
+            Zs = []
+            for Xt, lS_ot, idxt, Tt in test_batches:
+                Z = otr.evaluate(Xt, lS_ot, idxt)
+                Zs.append(Z)
+                ok += int((torch.round(Z) == Tt).sum())
+                tot += Tt.shape[0]
+            want_acc.append(100 * ok / tot)
+            # a sample whose score sits within ~1e-5 of 0.5 could round either way on the GPU
+            assert min(float((Z - 0.5).abs().min()) for Z in Zs) > 2e-5
     # Run
     eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
     for k in range(len(ln_emb)):
         eg.emb_l[k].weight.data = host_o[k].clone()
     eg.pin()
     capsys.readouterr()
-    eng = Run(0, m_spa, ln_emb, ln_bot, ln_top, batches, None, None, None, None, eg, args)
+    eng = Run(0, m_spa, ln_emb, ln_bot, ln_top, batches, test_batches, None, None, None, eg, args)
     printed = capsys.readouterr().out
     got = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", printed)]
     want = np.array([l[0] for l in otr.losses])
@@ -71,6 +84,9 @@ def test_run_matches_oracle_trainer(capsys):
     assert len(got) == nb - 1
     expect = np.concatenate([[(want[0] + want[1]) / 2], want[2:]])
     np.testing.assert_allclose(np.array(got), expect, rtol=1e-5)
+    got_acc = [float(x) for x in re.findall(r"Test accuracy = ([0-9.eE+-]+)%", printed)]
+    assert printed.count("Testing at") == 3 and len(want_acc) == 3          # j = 5, 10 and the last iteration
+    np.testing.assert_allclose(got_acc, want_acc, rtol=0, atol=1e-9)
     eng.cg.ctx.check()
     for k in range(len(ln_emb)):
         assert torch.equal(eng.cg.occupancy_tables[k].cpu(), otr.occ[k]), k
