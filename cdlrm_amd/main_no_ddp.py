@@ -308,6 +308,15 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         raise NotImplementedError("the fused engine implements --loss-function=bce (the north-star metric); "
                                   "mse / wbce run through the autograd surface (model_no_ddp.DLRM_Net)")
     emb_tables.pin() if not getattr(emb_tables, "_pinned", False) else None
+    if args.load_model:
+        # counterpart of --save-model: MLPs + host tables of a previous run (the cache starts empty)
+        ld = torch.load(args.load_model, map_location="cpu")
+        dlrm.load_state_dict({k: v.to(dev) for k, v in ld["dlrm"].items()})
+        if rank == 0 or world == 1:
+            for E, w in zip(emb_tables.emb_l, ld["emb"]):
+                E.weight.data.copy_(w)
+        if world > 1:
+            dist.barrier()
     eng = TrainEngine(cache_group, dlrm, emb_tables, lr=args.learning_rate, lr_embeds=args.lr_embeds, world_size=world,
                       rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op)
     L = args.lookahead
@@ -392,6 +401,16 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     print('Test accuracy = {}%'.format(100 * (total_test_acc / test_samp)), flush=True)
             j += 1
     torch.cuda.synchronize()
+    if args.save_model:
+        # --save-model is parsed but never acted on by the reference (main_no_ddp.py:111); here: flush every valid
+        # cache row to its host row (rank 0's replica, as for evictions), then save the MLPs and the host tables
+        if rank == 0:
+            cache_group.flush_to_host(emb_tables, average=args.average_on_writeback)
+            torch.save({"dlrm": {k: v.detach().cpu() for k, v in dlrm.state_dict().items()},
+                        "emb": [E.weight.data.clone() for E in emb_tables.emb_l],
+                        "ln_emb": [int(n) for n in ln_emb], "m_spa": int(m_spa)}, args.save_model)
+        if world > 1:
+            dist.barrier()
     return eng
 
 

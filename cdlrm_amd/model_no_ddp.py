@@ -294,6 +294,22 @@ class Embedding_Table_Cache_Group(nn.Module):
             self._ctx.bind_cache(self.tags, self.weight.data)
         return self._ctx
 
+    def flush_to_host(self, emb_tables: "Embedding_Table_Group", average: bool = False):
+        """End-of-run cache flush (the reference only ever writes EVICTED rows back,
+        cache_manager.py:57-62): every valid tag's cache row goes to its host row, `W_host[k][tag] = cache row`
+        (or the average with average=True, as --average-on-writeback does for evictions).  Aux rows are transient
+        copies and are not written.  Synchronises."""
+        ptrs = emb_tables.device_pointers()
+        for k in range(len(self.cache_sizes)):
+            P = self.cache_sizes[k]
+            tags = self.occupancy_tables[k].t().reshape(-1)                  # way-major: element w*P + s = slot id
+            valid = (tags != -1).nonzero(as_tuple=False).flatten()
+            if valid.numel() == 0:
+                continue
+            rows = self.weight.data[self.row_base[k]:self.row_base[k] + self.num_ways * P].index_select(0, valid)
+            ops.scatter_rows(ptrs[k], tags.index_select(0, valid).contiguous(), rows.contiguous(), average)
+        torch.cuda.synchronize(self.weight.device)
+
     @property
     def touched(self) -> torch.Tensor:
         """uint8 flag per cache row, set by the fused backward: the rows the table-agg merge exchanges."""

@@ -94,6 +94,69 @@ def test_run_matches_oracle_trainer(capsys):
                                    rtol=1e-6, atol=1e-6)
 
 
+def test_save_model_flushes_cache_and_load_model_resumes(tmp_path, capsys):
+    """--save-model: every valid cache row is written to its host row (the reference only writes EVICTED rows back,
+    so without the flush the trained values of cached rows would be lost), MLPs + host tables saved; --load-model
+    starts a new run from them: its first loss equals a forward pass of the oracle over the flushed state."""
+    from cdlrm_amd.main_no_ddp import ProcessArgs, Run
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    ln_emb = np.array([3000, 50, 7, 1200, 40000])
+    m_spa, B, L, nb, seed = 16, 64, 4, 8, 11
+    ln_bot = np.array([13, 32, 16])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+    batches = _Loader(_loader(ln_emb, B, nb, 5))
+    path = str(tmp_path / "model.pt")
+    torch.set_num_threads(1)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host_o = O.init_host_tables([int(n) for n in ln_emb], m_spa)
+    otr = O.OracleTrainer([int(n) for n in ln_emb], m_spa, ln_bot, ln_top, cache_size=40, num_ways=4, mini_batch_size=B,
+                          lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=5, seed=seed,
+                          host_tables=[h.clone() for h in host_o])
+    for j, (X, lS_o, idx, T) in enumerate(batches):
+        if j % L == 0:
+            otr.refill(torch.cat([b[2] for b in batches[j:j + L]], dim=1))
+        otr.step(j, X, lS_o, idx, T)
+    # oracle flush: W_host[k][tag] = cache row of every valid tag (slot = P*way + set)
+    flushed = [h.clone() for h in otr.host]
+    for k in range(len(ln_emb)):
+        P = otr.cache_sizes[k]
+        occ = otr.occ[k]
+        for s_, w_ in (occ != -1).nonzero().tolist():
+            flushed[k][int(occ[s_, w_])] = otr.weights[0][k][P * w_ + s_]
+    eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+    for k in range(len(ln_emb)):
+        eg.emb_l[k].weight.data = host_o[k].clone()
+    eg.pin()
+    Run(0, m_spa, ln_emb, ln_bot, ln_top, batches, None, None, None, None, eg, ProcessArgs(FLAGS + ["--save-model=" + path]))
+    saved = torch.load(path)
+    for k in range(len(ln_emb)):
+        np.testing.assert_allclose(saved["emb"][k].numpy(), flushed[k].numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(eg.emb_l[k].weight.data.numpy(), flushed[k].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(saved["dlrm"]["top_l.0.weight"].numpy(), otr.top[0][0][0].numpy(), rtol=1e-4, atol=1e-6)
+    # resume: a fresh run from the file; its first window is planned on an empty cache over the flushed tables
+    eg2 = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+    for k in range(len(ln_emb)):
+        eg2.emb_l[k].weight.data = torch.zeros_like(host_o[k])
+    eg2.pin()
+    capsys.readouterr()
+    Run(0, m_spa, ln_emb, ln_bot, ln_top, _Loader(batches[:3]), None, None, None, None, eg2,
+        ProcessArgs(FLAGS + ["--load-model=" + path]))
+    got = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", capsys.readouterr().out)]
+    # oracle: same MLPs, flushed tables, empty cache
+    otr2 = O.OracleTrainer([int(n) for n in ln_emb], m_spa, ln_bot, ln_top, cache_size=40, num_ways=4, mini_batch_size=B,
+                           lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=5, seed=seed,
+                           host_tables=[h.clone() for h in flushed])
+    otr2.bot[0], otr2.top[0] = otr.bot[0], otr.top[0]
+    for j, (X, lS_o, idx, T) in enumerate(batches[:3]):
+        if j % L == 0:
+            otr2.refill(torch.cat([b[2] for b in batches[:3][j:j + L]], dim=1))
+        otr2.step(j, X, lS_o, idx, T)
+    want = np.array([l[0] for l in otr2.losses])
+    np.testing.assert_allclose(np.array(got), np.concatenate([[(want[0] + want[1]) / 2], want[2:]]), rtol=1e-5)
+
+
 def test_main_cli_synthetic(capsys):
     """python -m cdlrm_amd.main_no_ddp <reference flags> on Criteo-shaped synthetic data: runs, prints the
     reference's progress line, the loss stays finite and the cache state is consistent."""
