@@ -355,7 +355,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 [torch.as_tensor(s).reshape(-1) for s in lS_i])
             sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
             Xr = X[sl, :].to(dev)
-            Ir = lS_i[:, sl].to(dev)
+            Ir = lS_i[:, sl].contiguous().to(dev)      # the day-file loader hands out X_cat^T (a strided view)
             Tr = T[sl, :].to(dev)
             t1 = time_wrap(rank)
             lossbuf = eng.step(Xr, Ir, Tr, j=j)
@@ -393,7 +393,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     for Xt, lS_ot, lS_it, Tt in test_ld:
                         lS_it = torch.as_tensor(lS_it) if not isinstance(lS_it, (list, tuple)) else torch.stack(
                             [torch.as_tensor(s).reshape(-1) for s in lS_it])
-                        Zt = eng.evaluate(Xt.to(dev), lS_it.to(dev))
+                        Zt = eng.evaluate(Xt.to(dev), lS_it.contiguous().to(dev))
                         S_ = Zt.cpu().numpy()
                         Tn = Tt.cpu().numpy()
                         total_test_acc += np.sum((np.round(S_, 0) == Tn).astype(np.uint32))
@@ -441,9 +441,24 @@ def main(argv=None):
     if "WORLD_SIZE" in os.environ:
         args.world_size = int(os.environ["WORLD_SIZE"])
     ln_bot = np.fromstring(args.arch_mlp_bot, dtype=int, sep="-")
-    if args.data_generation not in ("random", "criteo-synthetic"):
-        sys.exit("ERROR: --data-generation=%s needs the Criteo files; this build generates Criteo-shaped synthetic "
-                 "data (--data-generation=criteo-synthetic)" % args.data_generation)
+    if args.data_generation not in ("random", "criteo-synthetic", "dataset"):
+        sys.exit("ERROR: --data-generation=%s is not supported (dataset | criteo-synthetic | random)" % args.data_generation)
+    train_ld = test_ld = None
+    if args.data_generation == "dataset":
+        # the pre-processed day files of the reference's terabyte path (dlrm_data_pytorch.py:440-492): table sizes
+        # from <raw>_fea_count.npz (:180-181), batches from <raw>_<day>_reordered.npz
+        from .data_loader_terabyte import DataLoader
+        d_dir, d_name = os.path.dirname(args.raw_data_file) or ".", os.path.basename(args.raw_data_file)
+        with np.load(args.raw_data_file + "_fea_count.npz") as data:
+            counts = data["counts"]
+        args.arch_embedding_size = "-".join(str(int(c)) for c in counts)
+        days = [d for d in range(24) if os.path.exists(os.path.join(d_dir, "%s_%d_reordered.npz" % (d_name, d)))]
+        if not days:
+            sys.exit("ERROR: no %s_<day>_reordered.npz under %s" % (d_name, d_dir))
+        train_days, test_days = (days[:-1], days[-1:]) if len(days) > 1 else (days, days)
+        train_ld = DataLoader(d_name, d_dir, train_days, args.mini_batch_size, args.max_ind_range, "train", True)
+        tb = args.test_mini_batch_size if args.test_mini_batch_size > 0 else args.mini_batch_size
+        test_ld = DataLoader(d_name, d_dir, test_days, tb, args.max_ind_range, "test")
     ln_emb = np.fromstring(args.arch_embedding_size, dtype=int, sep="-")
     if args.max_ind_range > 0:
         ln_emb = np.minimum(ln_emb, args.max_ind_range)
@@ -472,11 +487,12 @@ def main(argv=None):
     emb_tables = make_host_tables(ln_emb, m_spa, device=dev, seed=args.numpy_rand_seed, rank=rank, world=args.world_size,
                                   shm_name="cdlrm_run_%d" % args.master_port,
                                   barrier=(dist.barrier if args.world_size > 1 else (lambda: None)))
-    nb = args.num_batches if args.num_batches > 0 else max(1, args.data_size // args.mini_batch_size)
-    syn = synth.CriteoSynth(ln_emb, int(m_den), args.mini_batch_size, seed=args.numpy_rand_seed,
-                            alpha=args.synthetic_alpha, device="cpu")
-    train_ld = _SyntheticLoader(syn, nb, args.mini_batch_size)
-    Run(local_rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, None, None, None, None, emb_tables, args)
+    if train_ld is None:
+        nb = args.num_batches if args.num_batches > 0 else max(1, args.data_size // args.mini_batch_size)
+        syn = synth.CriteoSynth(ln_emb, int(m_den), args.mini_batch_size, seed=args.numpy_rand_seed,
+                                alpha=args.synthetic_alpha, device="cpu")
+        train_ld = _SyntheticLoader(syn, nb, args.mini_batch_size)
+    Run(local_rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, None, None, None, emb_tables, args)
     if args.world_size > 1:
         dist.destroy_process_group()
 

@@ -157,6 +157,31 @@ def test_save_model_flushes_cache_and_load_model_resumes(tmp_path, capsys):
     np.testing.assert_allclose(np.array(got), np.concatenate([[(want[0] + want[1]) / 2], want[2:]]), rtol=1e-5)
 
 
+def test_main_cli_criteo_day_files(tmp_path, capsys):
+    """--data-generation=dataset over pre-processed day files in the reference's format (<raw>_<day>_reordered.npz,
+    <raw>_day_count.npz, <raw>_fea_count.npz): trains on all days but the last, tests on the last."""
+    import os
+    from cdlrm_amd import main_no_ddp
+    rng = np.random.RandomState(3)
+    counts = np.array([900, 40, 7, 300, 1500])
+    sizes = [64 * 5 + 9, 64 * 4 + 30, 64 * 2]
+    for day, n in enumerate(sizes):
+        np.savez(os.path.join(tmp_path, "day_%d_reordered.npz" % day), X_int=rng.randint(0, 500, size=(n, 13)).astype(np.int32),
+                 X_cat=np.stack([rng.randint(0, c, size=n) for c in counts], axis=1).astype(np.int32),
+                 y=rng.randint(0, 2, size=n).astype(np.int32))
+    np.savez(os.path.join(tmp_path, "day_day_count.npz"), total_per_file=np.array(sizes))
+    np.savez(os.path.join(tmp_path, "day_fea_count.npz"), counts=counts)
+    flags = [f for f in FLAGS if not f.startswith("--arch-embedding-size")]
+    main_no_ddp.main(flags + ["--data-generation=dataset", "--raw-data-file=" + os.path.join(tmp_path, "day"),
+                              "--device-rng"])
+    out = capsys.readouterr().out
+    n_train = (sizes[0] + sizes[1]) // 64                      # drop_last_batch=True, batches run across the file boundary
+    assert out.count("Epoch 0: Finished") == n_train - 1
+    assert out.count("Testing at") == 1 and "Test accuracy = " in out
+    losses = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", out)]
+    assert all(np.isfinite(losses))
+
+
 def test_main_cli_synthetic(capsys):
     """python -m cdlrm_amd.main_no_ddp <reference flags> on Criteo-shaped synthetic data: runs, prints the
     reference's progress line, the loss stays finite and the cache state is consistent."""

@@ -604,7 +604,39 @@ def g_window_groups(M, MD, CM, QR):
     save("window_groups", **res)
 
 
-GENS = dict(isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
+def g_criteo_loader(M, MD, CM, QR):
+    """data_loader_terabyte.DataLoader over three tiny day files (day sizes chosen to hit the file-boundary
+    carry-over, a tail of exactly one batch, and the short last batch), train / val / test splits."""
+    import tempfile
+    import data_loader_terabyte as DL
+    rng = np.random.RandomState(31)
+    sizes = [23, 14, 17]
+    B = 7
+    out = dict(sizes=np.array(sizes), B=B, max_ind_range=50)
+    with tempfile.TemporaryDirectory() as d:
+        for day, n in enumerate(sizes):
+            xi = rng.randint(0, 1000, size=(n, 13)).astype(np.int32)
+            xc = rng.randint(0, 100000, size=(n, 26)).astype(np.int32)
+            y = rng.randint(0, 2, size=n).astype(np.int32)
+            np.savez(os.path.join(d, "day_%d_reordered.npz" % day), X_int=xi, X_cat=xc, y=y)
+            out["xi_%d" % day], out["xc_%d" % day], out["y_%d" % day] = xi, xc, y
+        np.savez(os.path.join(d, "day_day_count.npz"), total_per_file=np.array(sizes))
+        cases = dict(train=([0, 1, 2], "train", False), train_drop=([0, 1, 2], "train", True), val=([2], "val", False),
+                     test=([1, 2], "test", False))
+        for name, (days, split, drop) in cases.items():
+            ld = DL.DataLoader("day", d, days, B, max_ind_range=50, split=split, drop_last_batch=drop)
+            batches = list(ld)
+            out[name + "_len"] = len(ld)
+            out[name + "_nb"] = len(batches)
+            out[name + "_sizes"] = np.array([b[3].shape[0] for b in batches])
+            out[name + "_X"] = torch.cat([b[0] for b in batches])
+            out[name + "_lS_i"] = torch.cat([b[2] for b in batches], dim=1)
+            out[name + "_T"] = torch.cat([b[3] for b in batches])
+            out[name + "_lS_o_last"] = batches[-1][1]
+    save("criteo_loader", **out)
+
+
+GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
             embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_w2=g_train_w2, qr=g_qr,
             window_groups=g_window_groups)
 
