@@ -336,6 +336,10 @@ class TrainEngine:
             gw = self.grad_flat[:self.n_weight]
             ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
             dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
+            if not getattr(self, "use_graph", False):
+                # the join _fwd_bwd left out: the embedding backward / sparse SGD on the side stream ran beside the
+                # all-reduce (the reference overlaps optimizer_embeds.step() with it the same way, :412-414)
+                S.current_stream(self.dev).wait_event(self._events["emb_done"])
         if not sgd_done:
             ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
         # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
@@ -485,6 +489,8 @@ class TrainEngine:
             plan = buf["wgrad"]
             plan.set_x(0, X)
             ops.mlp_wgrad(plan)
+        if self.world > 1 and not getattr(self, "use_graph", False):
+            return       # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
         if next_idx is None:
             rec(main.wait_stream, side)      # full join (also what a hipGraph capture needs)
         else:
