@@ -150,7 +150,10 @@ class TrainEngine:
         ne = lambda: S.new_event(self.dev)
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
                             emb_done=ne(), wgrad_done=ne(), top_dz=ne())
-        self.wst = S.new_stream(self.dev)           # top-MLP weight gradients at small local batches
+        # top-MLP weight gradients at long local batches: the SAME stream as the prefetch (their work never overlaps in
+        # time: probe/fill right after the gather, weight gradients late in the backward) -- four streams in all
+        # (main, side, pref, the window plan's), one per default hardware queue
+        self.wst = self.pref if os.environ.get("CDLRM_WST_OWN_STREAM", "0") != "1" else S.new_stream(self.dev)
         # measured (c3 shapes): the split loses ~3 % at B <= 2048 (two more launches on a latency-bound step), gains
         # 8 % at 4096 (0.580 -> 0.534 ms) and at 8192 (0.853 -> 0.782 ms)
         self.split_wgrad_min = int(os.environ.get("CDLRM_SPLIT_WGRAD_MIN", "2049"))
