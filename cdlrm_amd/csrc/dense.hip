@@ -480,24 +480,40 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
         interact_stage<D4>(Ts, FD4, lane, nxt);
         interact_prefetch<D4>(feat, min(b + nw, B - 1), FD4, lane, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* tp = Ts + lr * PITCH + 4 * lk;
-#pragma unroll 4
-        for (int g = 0; g < D / 8; ++g) {
-            const float4 a = *reinterpret_cast<const float4*>(tp + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, a.w, acc, 0, 0, 0);
+        // Z = T T^T is symmetric and only its lower triangle is stored: three 16x16 tiles -- (0,0), (1,0), (1,1) -- on
+        // the 16x16x4 fp32 MFMA (same FLOP rate as 32x32x2) instead of one 32x32 tile: 96 MFMAs x 32 cycles against
+        // 64 x 64, and three independent accumulator chains.  Lane l = (row l % 16 of its tile's 16 rows, contraction
+        // group l / 16): one ds_read_b128 per row block holds contraction indices 16g + 4 (l/16) .. +3, four MFMA steps.
+        v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
+        const int l16 = lane & 15, g4 = lane >> 4;
+        const float* tp = Ts + l16 * PITCH + 4 * g4;
+#pragma unroll 2
+        for (int g = 0; g < D / 16; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4*>(tp + 16 * g);                  // rows 0..15
+            const float4 a1 = *reinterpret_cast<const float4*>(tp + 16 * PITCH + 16 * g);     // rows 16..31
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a0.x, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a1.x, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, a0.y, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a0.y, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a1.y, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, a0.z, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a0.z, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a1.z, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, a0.w, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a0.w, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, acc11, 0, 0, 0);
         }
         float* out = R + b * ld_r;
         for (int c = lane; c < D; c += 64) out[c] = Ts[c];
+        const int off = itself ? 1 : 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (i < F && lr < i + (itself ? 1 : 0)) out[D + pair_base(i, itself) + lr] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+            // accumulator register r of lane l: tile row 4 (l / 16) + r, tile column l % 16
+            const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
+            if (i0 < F && l16 < i0 + off) out[D + pair_base(i0, itself) + l16] = acc00[r];
+            if (i1 < F) out[D + pair_base(i1, itself) + l16] = acc10[r];
+            if (i1 < F && 16 + l16 < i1 + off) out[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
         }
         __builtin_amdgcn_sched_barrier(0);
     }

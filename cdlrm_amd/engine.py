@@ -3,9 +3,13 @@
 `TrainEngine.step()` is the reference's loop body (main_no_ddp.py:401-423) as one fixed sequence of
 libcdlrm_hip.so launches on preallocated buffers -- no autograd graph, no per-table Python loop:
 
-    probe -> gather -> bottom MLP -> interaction -> top MLP -> BCE -> top MLP bwd -> interaction bwd
-          -> fused embedding bwd + sparse SGD  ||  bottom MLP bwd -> grad all-reduce (RCCL) -> dense SGD
-          -> every table_agg_freq steps: touched-row merge across ranks
+    bottom MLP -> gather (slots probed one step ahead) -> interaction -> top MLP -> BCE -> top dgrad chain
+          -> interaction bwd -> fused embedding bwd + sparse SGD || bottom dgrad chain || weight gradients
+          -> grad all-reduce (RCCL) -> dense SGD -> every table_agg_freq steps: touched-row merge across ranks
+
+Four HIP streams: main (the chain above), side (slot sort, embedding backward), pref (the NEXT batch's tag probe and
+aux-row fill into the other aux region; at long batches also the top MLP's weight gradients), and the window
+plan's.  The launch sequence of a step is recorded once per control path and replayed (`_step_taped`).
 
 `WindowPipeline` is the look-ahead side: it plans window w+1 (unique scan, tag probe, way choice, winners-
 only pinned-host -> HBM row fetch) on a side HIP stream while window w trains, and commits it at the
