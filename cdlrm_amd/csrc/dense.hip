@@ -130,11 +130,9 @@ extern "C" uint64_t cdlrm_mlp_wgrad_work_bytes(int32_t n_layers, int64_t M, cons
             total += ((zs * N[i] * K[i] * 4 + 255) & ~(uint64_t)255) + ((zs * N[i] * 4 + 255) & ~(uint64_t)255);
         return total;
     }
-    for (int i = 0; i < n_layers; ++i) {
-        const uint64_t b = cdlrm_linear_bwd_work_bytes(M, N[i], K[i]);
-        if (b > largest) largest = b;
-    }
-    return largest;
+    (void)largest;
+    for (int i = 0; i < n_layers; ++i) total += cdlrm_linear_bwd_work_bytes(M, N[i], K[i]);      // every layer its own slabs
+    return total;
 }
 
 extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y, float* dY,
@@ -298,12 +296,58 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
         CDLRM_LAUNCH_CHECK();
         return 0;
     }
+    // Long batches: per layer one split-M GEMM of the tiled (or, for degenerate shapes, the LDS-free) kernel into the
+    // layer's own slabs, then ONE grouped reduction of all layers' slabs and bias partials.
+    CDLRM_REQUIRE(work && ((uintptr_t)work & 255) == 0, "work must be 256-byte aligned");
+    char* wp = (char*)work;
+    std::vector<ReduceJob> jobs;
     for (int i = 0; i < n_layers; ++i) {
-        // dY = dZ with act 0, no dX: only the weight-gradient part of cdlrm_linear_bwd runs
-        int rc = cdlrm_linear_bwd(X[i], ld_x[i], /*W (unused without dX)*/ X[i], nullptr, 0, const_cast<float*>(dZ[i]),
-                                  ld_dz[i], nullptr, 0, dW[i], db[i], M, N[i], K[i], 0, 0, work, stream);
+        CDLRM_REQUIRE(X[i] && dZ[i] && dW[i] && N[i] >= 1 && K[i] >= 1 && ld_x[i] >= K[i] && ld_dz[i] >= N[i],
+                      "bad layer argument");
+        const int splits = wgrad_splits(M, N[i], K[i]);
+        const int64_t cnt = (int64_t)N[i] * K[i];
+        GemmArgs g = gemm_args();
+        g.A = dZ[i]; g.lda = ld_dz[i]; g.B = X[i]; g.ldb = ld_x[i]; g.ldc = K[i];
+        g.slab = cnt;
+        g.M = N[i]; g.N = K[i]; g.K = M; g.kchunk = cdiv(cdiv(M, splits), GBK) * GBK;
+        g.vecA = aligned16(dZ[i]) && ld_dz[i] % 4 == 0 && N[i] % 4 == 0;
+        g.vecB = aligned16(X[i]) && ld_x[i] % 4 == 0 && K[i] % 4 == 0;
+        const int zs = (int)cdiv(M, g.kchunk);
+        g.C = dW[i];
+        g.colsum = db[i];
+        if (zs > 1) {
+            float* slabs = (float*)wp;
+            wp += (((uint64_t)zs * cnt * 4) + 255) & ~(uint64_t)255;
+            float* cs = (float*)wp;
+            wp += (((uint64_t)zs * N[i] * 4) + 255) & ~(uint64_t)255;
+            g.C = slabs;
+            g.colsum = db[i] ? cs : nullptr;
+            ReduceJob r;
+            r.partA = slabs; r.countA = cnt; r.outA = dW[i];
+            int64_t gxa = cdiv(cnt, 256);
+            if (gxa > 1024) gxa = 1024;
+            r.gxa = (int)gxa;
+            r.partB = cs; r.countB = db[i] ? N[i] : 0; r.outB = db[i];
+            r.splits = zs;
+            jobs.push_back(r);
+        }
+        int rc = launch_gemm<false, false>(g, zs, s);
         if (rc) return rc;
     }
+    for (size_t q0 = 0; q0 < jobs.size(); q0 += GEMM_GROUP_MAX) {
+        ReduceGroup red;
+        memset(&red, 0, sizeof(red));
+        unsigned rblocks = 0;
+        for (size_t q = q0; q < jobs.size() && q < q0 + GEMM_GROUP_MAX; ++q) {
+            red.first[red.n] = rblocks;
+            red.j[red.n] = jobs[q];
+            rblocks += (unsigned)(jobs[q].gxa + cdiv(jobs[q].countB, 64));
+            red.n++;
+        }
+        red.first[red.n] = rblocks;
+        hipLaunchKernelGGL(k_reduce_group, dim3(rblocks), dim3(256), 0, s, red);
+    }
+    CDLRM_LAUNCH_CHECK();
     return 0;
 }
 

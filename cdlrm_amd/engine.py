@@ -229,17 +229,16 @@ class TrainEngine:
         xs = [x0] + b["bot_y"] + [b["R"]] + b["top_y"][:-1]
         dzs = b["bot_dy"] + [b["dfeat"][:, 0, :]] + b["top_dy"]
         b["wgrad"] = ops.WgradPlan(xs, dzs, [self.gW[l] for l in layers], [self.gb[l] for l in layers], b["lin_work"])
-        # long local batches: every layer's weight gradient is launched on its own stream the moment its dZ is final,
-        # beside the dgrad chain (the critical path) -- one plan and one scratch buffer per layer.  Index = position in
-        # bot + top.
+        # long local batches: the top MLP's weight gradients run on their own stream beside the interaction backward
+        # and the bottom MLP's backward -- (bottom plan, top plan), each with its own scratch
         b["wgrad_split"] = None
         if S.is_hip(dev) and self.split_wgrad_min <= B <= self.split_wgrad_max:
+            nb = len(self.bot)
             gw = [self.gW[l] for l in layers]
             gb = [self.gb[l] for l in layers]
-            b["wgrad_split"] = [
-                ops.WgradPlan([xs[i]], [dzs[i]], [gw[i]], [gb[i]],
-                              ops.mlp_wgrad_work(B, [layers[i].out_features], [self.W[layers[i]].shape[1]], dev))
-                for i in range(len(layers))]
+            wk = lambda ls: ops.mlp_wgrad_work(B, [l.out_features for l in ls], [self.W[l].shape[1] for l in ls], dev)
+            b["wgrad_split"] = (ops.WgradPlan(xs[:nb], dzs[:nb], gw[:nb], gb[:nb], wk(layers[:nb])),
+                                ops.WgradPlan(xs[nb:], dzs[nb:], gw[nb:], gb[nb:], wk(layers[nb:])))
         self._bufs[B] = b
         return b
 
@@ -459,8 +458,7 @@ class TrainEngine:
             # chain is the critical path and loses CUs to them.)
             rec(ev["top_dz"].record, main)
             rec(wst.wait_event, ev["top_dz"])
-            for i in reversed(range(len(self.top))):
-                ops.mlp_wgrad(split[nb_ + i], stream=wst)
+            ops.mlp_wgrad(split[1], stream=wst)
             rec(ev["wgrad_done"].record, wst)
         ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
@@ -489,8 +487,7 @@ class TrainEngine:
             dY = dX
         if split is not None:
             split[0].set_x(0, X)
-            for i in reversed(range(nb_)):
-                ops.mlp_wgrad(split[i])
+            ops.mlp_wgrad(split[0])
             rec(main.wait_event, ev["wgrad_done"])
         else:
             plan = buf["wgrad"]
