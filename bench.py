@@ -63,9 +63,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-sample", type=int, default=8, help="time the gather kernel every k-th step")
     ap.add_argument("--seed", type=int, default=123)
-    ap.add_argument("--no-graph", action="store_true", help="never replay the step from a hipGraph")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (measured slower than eager launches + cross-iteration "
-                    "pipelining at every batch size tried: 0.36 vs 0.30 ms at B=1024, 0.51 vs 0.43 at 2048)")
     return ap.parse_args()
 
 
@@ -158,11 +155,8 @@ def main():
     dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
     eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
                       table_agg_freq=cfg["agg"], table_agg_op="mean")
-    # eager launches + cross-iteration pipelining of the probe / aux fill at every N (the hipGraph replay of the
-    # step was measured slower at local batches 1024 .. 8192 and stays an option)
-    use_graph = (not a.no_graph) and a.graph
-    if use_graph:
-        eng.enable_graph()
+    # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
+    # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
     pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world)
     syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=a.seed, alpha=a.alpha, device=dev)
     torch.cuda.synchronize()
@@ -211,7 +205,7 @@ def main():
         sample = timed and a.gather_sample > 0 and (j % a.gather_sample == 0)
         # eager mode: hand the next batch's indices over so its tag probe / aux fill run behind this step's backward
         nxt = None
-        if not use_graph and jj + 1 < L and jj + 1 != plan_at:
+        if jj + 1 < L and jj + 1 != plan_at:
             nxt = state["win"][:, col + B:col + B + lbs]
         eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
 
@@ -255,7 +249,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": a.config, "global_batch": B, "local_batch": lbs,
                        "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
-                       "parallelism": "dp%d" % world, "hipgraph": use_graph, "final_loss": loss, "setup_s": round(setup_s, 1)},
+                       "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1)},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

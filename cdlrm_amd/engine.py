@@ -288,14 +288,6 @@ class TrainEngine:
         self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.agg_count_host = S.pinned(torch.zeros(1, dtype=torch.int64), self.dev)
 
-    def enable_graph(self, on: bool = True):
-        """Replay the per-iteration launch sequence from a captured hipGraph (one graph per batch shape) instead of
-        issuing ~60 launches from Python: at small local batches the step is launch-bound otherwise.  The collective
-        and the dense SGD stay outside the graph."""
-        self.use_graph = bool(on) and S.is_hip(self.dev)
-        self._graphs = {}
-        self._eager_seen = {}
-
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
              j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None):
         """One training iteration on this rank's slice (next_idx: the NEXT batch's indices, if it belongs to the same
@@ -303,49 +295,23 @@ class TrainEngine:
         on the device; lS_o None = Criteo layout; j = batch number inside the epoch (table-agg schedule).
         Returns the device loss buffer (element 0 = BCE loss)."""
         B, n = X.shape[0], lS_i.shape[1]
+        if j is None:
+            j = self.iter
+        if self.world > 1 and j > 0 and j % self.agg_freq == 0:
+            next_idx = None      # the row merge below rewrites touched aux rows: no fill may be in flight
         sgd_done = False
-        if getattr(self, "use_graph", False) and gather_events is None and lS_o is None:
-            key = (B, n)
-            g = self._graphs.get(key)
-            if g is None:
-                seen = self._eager_seen.get(key, 0)
-                if seen < 3:            # warm-up: buffers, attributes and allocator state settle eagerly first
-                    self._eager_seen[key] = seen + 1
-                    self._fwd_bwd(X, lS_i, T, lS_o, None)
-                else:
-                    st = dict(X=torch.empty_like(X), idx=torch.empty((self.T, n), dtype=torch.int64, device=self.dev),
-                              T=torch.empty_like(T))
-                    st["X"].copy_(X); st["idx"].copy_(lS_i); st["T"].copy_(T)
-                    torch.cuda.synchronize(self.dev)
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        self._fwd_bwd(st["X"], st["idx"], st["T"], None, None)
-                    g = (graph, st)
-                    self._graphs[key] = g
-                    graph.replay()
-            else:
-                graph, st = g
-                st["X"].copy_(X); st["idx"].copy_(lS_i); st["T"].copy_(T)
-                graph.replay()
+        if self.use_tape and gather_events is None and lS_o is None:
+            sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
-            if j is None:
-                j = self.iter
-            if self.world > 1 and j > 0 and j % self.agg_freq == 0:
-                next_idx = None      # the row merge below rewrites touched aux rows: no fill may be in flight
-            sgd_done = False
-            if self.use_tape and gather_events is None and lS_o is None:
-                sgd_done = self._step_taped(X, lS_i, T, next_idx)
-            else:
-                self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
+            self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
         # ---- dense gradient exchange + SGD ----
         if self.world > 1:
             gw = self.grad_flat[:self.n_weight]
             ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
             dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
-            if not getattr(self, "use_graph", False):
-                # the join _fwd_bwd left out: the embedding backward / sparse SGD on the side stream ran beside the
-                # all-reduce (the reference overlaps optimizer_embeds.step() with it the same way, :412-414)
-                S.current_stream(self.dev).wait_event(self._events["emb_done"])
+            # the join _fwd_bwd left out: the embedding backward / sparse SGD on the side stream ran beside the
+            # all-reduce (the reference overlaps optimizer_embeds.step() with it the same way, :412-414)
+            S.current_stream(self.dev).wait_event(self._events["emb_done"])
         if not sgd_done:
             ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
         # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
@@ -493,10 +459,10 @@ class TrainEngine:
             plan = buf["wgrad"]
             plan.set_x(0, X)
             ops.mlp_wgrad(plan)
-        if self.world > 1 and not getattr(self, "use_graph", False):
+        if self.world > 1:
             return       # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
         if next_idx is None:
-            rec(main.wait_stream, side)      # full join (also what a hipGraph capture needs)
+            rec(main.wait_stream, side)      # full join
         else:
             rec(main.wait_event, emb_done)   # cache rows are updated; the prefetched probe keeps running
 
