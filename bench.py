@@ -157,7 +157,9 @@ def main():
                       table_agg_freq=cfg["agg"], table_agg_op="mean")
     # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
     # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
-    pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world)
+    pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world,
+                          host_gather=os.environ.get("CDLRM_HOST_GATHER", "1") != "0",
+                          gather_threads=max(4, min(32, (os.cpu_count() or 8) // max(1, world))))
     syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=a.seed, alpha=a.alpha, device=dev)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
@@ -208,6 +210,17 @@ def main():
         if jj + 1 < L and jj + 1 != plan_at:
             nxt = state["win"][:, col + B:col + B + lbs]
         eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
+        if dma_test is not None and j % dma_test["every"] == 0:       # experiment: H2D DMA traffic beside training
+            with torch.cuda.stream(dma_test["stream"]):
+                dma_test["dst"].copy_(dma_test["src"], non_blocking=True)
+
+    dma_test = None
+    if os.environ.get("CDLRM_BENCH_DMA_TEST"):
+        gb = float(os.environ["CDLRM_BENCH_DMA_TEST"])
+        nel = int(gb * (1 << 30) / 4)
+        dma_test = dict(src=torch.empty(nel, dtype=torch.float32).pin_memory(), dst=torch.empty(nel, device=dev),
+                        stream=torch.cuda.Stream(), every=int(os.environ.get("CDLRM_BENCH_DMA_EVERY", "100")))
+        dma_test["src"].fill_(1.0)
 
     for j in range(a.warmup):
         run_step(j, False)

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "cdlrm_plan_commit": (C.c_int, [vp, C.POINTER(Plan), vp]),
     "cdlrm_plan_writeback": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(vp), C.c_int, vp]),
     "cdlrm_plan_victims": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(Victims), vp]),
+    "cdlrm_plan_victims_list": (C.c_int, [vp, C.POINTER(Plan), C.POINTER(Victims), vp]),
+    "cdlrm_host_gather_rows": (C.c_int, [C.POINTER(vp), vp, vp, c_i32, c_i32, vp, c_i32]),
     "cdlrm_ctx_bind_victims": (C.c_int, [vp, C.POINTER(Victims)]),
     "cdlrm_gather_rows": (C.c_int, [vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_agg_compact": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, vp]),

@@ -1,6 +1,9 @@
 // Context, binding and error plumbing of libcdlrm_hip.so (no kernels of the hot path live here).
 #include <stdarg.h>
 
+#include <algorithm>
+#include <thread>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -106,6 +109,52 @@ extern "C" int cdlrm_host_register(void* host_ptr, uint64_t bytes, void** device
 extern "C" int cdlrm_host_unregister(void* host_ptr) {
     CDLRM_REQUIRE(host_ptr, "null argument");
     CDLRM_HIP_CHECK(hipHostUnregister(host_ptr));
+    return 0;
+}
+
+// Host-side row gather for the plan's bulk fetches: dst[j, :] = tables[t(j)][idx[j], :], t(j) from off[0..T].
+// The window plan can move its winners' and victims' rows this way -- CPU threads gather into a pinned staging buffer,
+// one DMA copies it to HBM -- instead of letting GPU waves read the host tables: a copy-engine transfer beside training
+// costs the training kernels ~2 %, shader reads over PCIe cost them ~2x for as long as they run (measured).
+// This is what the reference's Prefetcher process does on the CPU (model_no_ddp.py:80-87) -- here it overlaps training.
+static void host_gather_range(const float* const* tables, const int64_t* idx, const int64_t* off, int T, int D, float* dst,
+                              int64_t a, int64_t b) {
+    int t = 0;
+    const size_t row_bytes = (size_t)D * sizeof(float);
+    constexpr int AHEAD = 16;
+    int ta = 0;                                   // table of the row being prefetched
+    for (int64_t j = a; j < b; ++j) {
+        const int64_t jp = j + AHEAD;
+        if (jp < b) {
+            while (ta < T - 1 && jp >= off[ta + 1]) ++ta;
+            const char* p = (const char*)(tables[ta] + idx[jp] * D);
+            for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 0);
+        }
+        while (t < T - 1 && j >= off[t + 1]) ++t;
+        memcpy(dst + j * D, tables[t] + idx[j] * D, row_bytes);
+    }
+}
+
+extern "C" int cdlrm_host_gather_rows(const float* const* tables, const int64_t* idx, const int64_t* off, int32_t T,
+                                      int32_t D, float* dst, int32_t nthreads) {
+    CDLRM_REQUIRE(tables && idx && off && dst && T >= 1 && D >= 1, "bad argument");
+    const int64_t n = off[T];
+    if (n <= 0) return 0;
+    for (int k = 0; k < T; ++k) CDLRM_REQUIRE(off[k] <= off[k + 1] && (off[k] == off[k + 1] || tables[k]), "bad offsets / table");
+    int nt = nthreads < 1 ? 1 : nthreads;
+    if ((int64_t)nt > (n + 4095) / 4096) nt = (int)((n + 4095) / 4096);
+    if (nt <= 1) {
+        host_gather_range(tables, idx, off, T, D, dst, 0, n);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int i = 0; i < nt; ++i) {
+        const int64_t a = i * per, b = std::min<int64_t>(n, a + per);
+        if (a >= b) break;
+        th.emplace_back(host_gather_range, tables, idx, off, (int)T, (int)D, dst, a, b);
+    }
+    for (auto& x : th) x.join();
     return 0;
 }
 

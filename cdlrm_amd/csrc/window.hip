@@ -608,7 +608,15 @@ __global__ void __launch_bounds__(WIN_THREADS) k_victim_unflag(const int64_t* __
         flags[kept[win_claim[w]]] = 0;
 }
 
-extern "C" int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* v, void* stream) {
+__global__ void __launch_bounds__(WIN_THREADS) k_victim_ids(const int64_t* __restrict__ v_off, int T, int64_t cap,
+                                                            const int32_t* __restrict__ pos, const int64_t* __restrict__ uniq,
+                                                            int64_t* __restrict__ idx) {
+    const int64_t n = min(v_off[T], cap);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        idx[j] = uniq[pos[j]];
+}
+
+static int plan_victims_impl(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* v, int fetch, void* stream) {
     CDLRM_REQUIRE(ctx && plan && v, "null argument");
     CDLRM_REQUIRE(v->pos && v->idx && v->off && v->rows && v->cap >= 1 && ((uintptr_t)v->rows & 15) == 0, "victim buffers");
     CDLRM_REQUIRE(plan->uniq && plan->uniq_off && plan->hit && plan->kept && plan->win_claim && plan->win_off && plan->flags,
@@ -635,11 +643,27 @@ extern "C" int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const 
     hipLaunchKernelGGL(k_offsets_from_sorted, dim3(cdiv(ctx->T + 1, 64)), dim3(64), 0, s, v->pos, ctx->d_small + 2, v->cap,
                        plan->uniq_off, ctx->T, v->off);
     CDLRM_REQUIRE(ctx->T <= 1024, "more than 1024 tables");
-    const int D4 = ctx->D / 4;
-    hipLaunchKernelGGL(k_host_rows<true>, dim3((unsigned)host_rows_grid()), dim3(256), 0, s, ctx->T, D4, v->off, v->cap,
-                       nullptr, v->pos, plan->uniq, ctx->d_host_rows, reinterpret_cast<float4*>(v->rows), v->idx);
+    if (fetch) {
+        const int D4 = ctx->D / 4;
+        hipLaunchKernelGGL(k_host_rows<true>, dim3((unsigned)host_rows_grid()), dim3(256), 0, s, ctx->T, D4, v->off, v->cap,
+                           nullptr, v->pos, plan->uniq, ctx->d_host_rows, reinterpret_cast<float4*>(v->rows), v->idx);
+    } else {
+        int64_t gv = cdiv(v->cap, WIN_THREADS);
+        if (gv > WIN_BLOCKS) gv = WIN_BLOCKS;
+        hipLaunchKernelGGL(k_victim_ids, dim3((unsigned)gv), dim3(WIN_THREADS), 0, s, v->off, ctx->T, v->cap, v->pos,
+                           plan->uniq, v->idx);
+    }
     CDLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* v, void* stream) {
+    return plan_victims_impl(ctx, plan, v, 1, stream);
+}
+
+// the list only (idx / off); the caller moves the rows itself (cdlrm_host_gather_rows + one DMA copy into v->rows)
+extern "C" int cdlrm_plan_victims_list(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* v, void* stream) {
+    return plan_victims_impl(ctx, plan, v, 0, stream);
 }
 
 extern "C" int cdlrm_ctx_bind_victims(cdlrm_ctx* ctx, const cdlrm_victims* v) {

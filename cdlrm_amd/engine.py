@@ -35,10 +35,14 @@ class WindowPipeline:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, host_tables: Embedding_Table_Group, max_window: int,
                  *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
                  world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None,
-                 victim_rows: Optional[int] = None):
+                 victim_rows: Optional[int] = None, host_gather: bool = False, gather_threads: int = 16):
         """victim_rows: capacity (rows) of each of the two HBM buffers that hold the host rows of a window's
         non-cached indices (None: every unique index of a window, at most 8 GiB per buffer; 0: off -- every miss
-        reads the host table over PCIe as the reference does)."""
+        reads the host table over PCIe as the reference does).
+        host_gather: move the plan's bulk rows (winners, victims) the way the reference's Prefetcher does -- CPU threads
+        gather them from the host tables into pinned staging, ONE DMA copy brings them to HBM -- from a background
+        thread, instead of GPU waves reading host memory (which slows every kernel beside them ~2x while they run;
+        a DMA copy costs the training ~2 %).  Not with parity_rng (that path draws its random numbers in-line)."""
         self.cg, self.host = cache_group, host_tables
         self.ctx = cache_group.ctx
         self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
@@ -56,11 +60,75 @@ class WindowPipeline:
         self.planned = None          # event: plan of the next window is ready
         self.written_back = None     # event: evictions of the last commit are in the host tables
         self.last_offsets = None
+        self.host_gather = bool(host_gather) and not parity_rng and S.is_hip(self.dev)
+        self.gather_threads = int(gather_threads)
+        self._worker = None          # background thread of a host-gather plan
+        self._worker_err = None
+        self._pin = {}               # pinned host staging, grown on demand
+
+    def _pinned(self, key, shape, dtype):
+        t = self._pin.get(key)
+        if t is None or t.shape[0] < shape[0]:
+            rows = int(shape[0] * 1.25) + 1024
+            t = torch.empty((rows,) + tuple(shape[1:]), dtype=dtype, pin_memory=True)
+            self._pin[key] = t
+        return t
+
+    def _plan_host_gather(self, window_idx, lists_ready):
+        """Background half of a host-gather plan: wait for the winner / victim lists, copy them down, gather the rows on
+        the CPU, issue the two DMA copies and the `planned` event on the plan stream."""
+        try:
+            torch.cuda.set_device(self.dev)
+            plan, side, T, D = self.plan, self.side, self.ctx.T, self.ctx.D
+            vic = self.victims[self._vnext] if self.victims is not None else None
+            lists_ready.synchronize()
+            _, _, wo = plan.offsets(stream=side)
+            W = wo[T]
+            with torch.cuda.stream(side):
+                win_h = self._pinned("win_idx", (max(W, 1),), torch.int64)
+                win_h[:W].copy_(plan.win_idx[:W], non_blocking=True)
+                if vic is not None:
+                    voff = vic.off.cpu().tolist()
+                    V = min(voff[T], vic.cap)
+                    voff = [min(o, V) for o in voff]
+                    vic_h = self._pinned("vic_idx", (max(V, 1),), torch.int64)
+                    vic_h[:V].copy_(vic.idx[:V], non_blocking=True)
+                side.synchronize()
+                stage_h = self._pinned("stage", (max(W, 1), D), torch.float32)
+                ops.host_gather_rows(self.host_ptrs, win_h, wo, D, stage_h, self.gather_threads)
+                plan.stage[:W].copy_(stage_h[:W], non_blocking=True)
+                if vic is not None:
+                    vrows_h = self._pinned("vic_rows", (max(V, 1), D), torch.float32)
+                    ops.host_gather_rows(self.host_ptrs, vic_h, voff, D, vrows_h, self.gather_threads)
+                    vic.rows[:V].copy_(vrows_h[:V], non_blocking=True)
+                if window_idx.is_cuda:
+                    window_idx.record_stream(side)
+                self.planned = S.new_event(self.dev)
+                self.planned.record(side)
+        except BaseException as e:          # surfaced by commit()
+            self._worker_err = e
 
     def plan_window(self, window_idx: torch.Tensor, q_source=None):
         """Launch the plan of one window ([T, n] int64 on device) on the side stream."""
         plan, side = self.plan, self.side
         side.wait_stream(S.current_stream(self.dev))          # window_idx may have been produced there
+        if self.host_gather:
+            import threading
+            assert self._worker is None, "the previous plan was never committed"
+            with S.on_stream(side):
+                plan.unique(window_idx, stream=side)
+                plan.probe(stream=side)
+                plan.assign(None, seed=self.seed * 1000003 + self.window_no, stream=side)
+                if self.victims is not None:
+                    plan.victims(self.victims[self._vnext], stream=side, list_only=True)
+                lists_ready = S.new_event(self.dev)
+                lists_ready.record(side)
+            self.planned = None
+            self._worker_err = None
+            self._worker = threading.Thread(target=self._plan_host_gather, args=(window_idx, lists_ready), daemon=True)
+            self._worker.start()
+            self.window_no += 1
+            return
         with S.on_stream(side):
             plan.unique(window_idx, stream=side)
             plan.probe(stream=side)
@@ -87,6 +155,11 @@ class WindowPipeline:
     def commit(self):
         """At the window boundary: swap the fetched rows in, write the tags, write the evicted rows back."""
         main = S.current_stream(self.dev)
+        if self._worker is not None:            # host-gather plan: the background half has to have issued its copies
+            self._worker.join()
+            self._worker = None
+            if self._worker_err is not None:
+                raise self._worker_err
         assert self.planned is not None, "plan_window() first"
         main.wait_event(self.planned)
         self.plan.commit(stream=main)

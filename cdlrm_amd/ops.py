@@ -230,9 +230,11 @@ class WindowPlan:
         check(_lib.lib().cdlrm_plan_fetch(self.ctx.handle, C.byref(self.c), arr, 1 if by_position else 0,
                                           stream_ptr(stream)))
 
-    def victims(self, victims: "Victims", stream=None):
-        """After assign(): list the window's indices that stay outside the cache and fetch their host rows."""
-        check(_lib.lib().cdlrm_plan_victims(self.ctx.handle, C.byref(self.c), C.byref(victims.c), stream_ptr(stream)))
+    def victims(self, victims: "Victims", stream=None, list_only: bool = False):
+        """After assign(): list the window's indices that stay outside the cache and fetch their host rows
+        (list_only: the caller moves the rows itself -- host_gather_rows + one DMA copy)."""
+        fn = _lib.lib().cdlrm_plan_victims_list if list_only else _lib.lib().cdlrm_plan_victims
+        check(fn(self.ctx.handle, C.byref(self.c), C.byref(victims.c), stream_ptr(stream)))
 
     # K4 + K5b
     def commit(self, stream=None):
@@ -257,6 +259,19 @@ class Victims:
         self.rows = torch.empty((self.cap, ctx.D), dtype=torch.float32, device=dev)
         self.c = _VictimsStruct(self.pos.data_ptr(), self.idx.data_ptr(), self.off.data_ptr(), self.rows.data_ptr(),
                                 self.cap)
+
+
+def host_gather_rows(table_ptrs: Sequence[int], idx: torch.Tensor, off: Sequence[int], dim: int, dst: torch.Tensor,
+                     threads: int = 16):
+    """HOST-side gather (CPU threads, releases the GIL): dst[j] = table_{t(j)}[idx[j]] for j < off[-1].  idx: CPU int64,
+    dst: CPU fp32 [>= off[-1], dim] (pinned for the DMA that follows)."""
+    T = len(table_ptrs)
+    assert idx.device.type == "cpu" and idx.dtype == torch.int64 and idx.is_contiguous()
+    assert dst.device.type == "cpu" and dst.dtype == torch.float32 and dst.is_contiguous() and dst.shape[1] == dim
+    assert len(off) == T + 1 and off[-1] <= idx.numel() and off[-1] <= dst.shape[0]
+    tp = (C.c_void_p * T)(*[int(p) for p in table_ptrs])
+    oa = (C.c_int64 * (T + 1))(*[int(o) for o in off])
+    check(_lib.lib().cdlrm_host_gather_rows(tp, idx.data_ptr(), oa, T, int(dim), dst.data_ptr(), int(threads)))
 
 
 def gather_rows(src_ptr: int, index: torch.Tensor, dim: int, stream=None) -> torch.Tensor:

@@ -207,6 +207,16 @@ typedef struct {
     int64_t  cap;
 } cdlrm_victims;
 int cdlrm_plan_victims(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* victims, void* stream);
+/* The list only (pos / idx / off); the caller fills victims->rows itself (cdlrm_host_gather_rows + one DMA). */
+int cdlrm_plan_victims_list(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm_victims* victims, void* stream);
+
+/* HOST function (no GPU work): dst[j, :] = tables[t(j)][idx[j], :] for j < off[T], t(j) = the table whose range
+ * [off[t], off[t+1]) holds j; tables / idx / off / dst are host pointers (dst typically pinned), nthreads CPU threads.
+ * The CPU-side counterpart of cdlrm_plan_fetch / the victims' row fetch -- what the reference's Prefetcher process does
+ * in `emb_tables.fetch_unique_idx_slices` (model_no_ddp.py:80-87): gathered rows then reach HBM by ONE DMA copy, which
+ * disturbs the training kernels far less than GPU waves reading host memory. */
+int cdlrm_host_gather_rows(const float* const* tables, const int64_t* idx, const int64_t* off, int32_t T,
+                           int32_t D, float* dst, int32_t nthreads);
 int cdlrm_ctx_bind_victims(cdlrm_ctx* ctx, const cdlrm_victims* victims);
 
 /* Generic row gather used by the drop-in process_batch_slice (rows = W_host[uniq],

@@ -91,6 +91,45 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases):
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
+def test_host_gather_plan_equals_device_fetch(golden):
+    """WindowPipeline(host_gather=True) -- CPU threads gather the winners' / victims' rows, one DMA copy each, from a
+    background thread -- leaves exactly the cache, tag and victim state of the default plan (GPU waves reading the
+    host tables), window after window, evictions written back included."""
+    from cdlrm_amd.engine import WindowPipeline
+    g = golden("train_small")
+    L = int(g["L"])
+    batches = make_batches(g)
+    states = []
+    for hg in (False, True):
+        host, cg, dl, eng, _ = build(g)
+        pipe = WindowPipeline(cg, host, L * int(g["B"]), parity_rng=False, seed=5, host_gather=hg, gather_threads=3)
+        assert pipe.host_gather == hg
+        snaps = []
+        for j in range(0, len(batches), L):
+            win = torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV)
+            pipe.plan_window(win)
+            pipe.commit()
+            pipe.wait_writeback()
+            torch.cuda.synchronize()
+            vic = pipe.victims[pipe._vnext ^ 1]
+            voff = vic.off.cpu().tolist()
+            nv = voff[-1]
+            snaps.append((cg.tags.cpu().clone(), [cg.emb_l[k].weight[: int(g["ways"]) * cg.cache_sizes[k]].cpu().clone()
+                                                  for k in range(len(cg.cache_sizes))], voff,
+                          vic.idx[:nv].cpu().clone(), vic.rows[:nv].cpu().clone(),
+                          [h.weight.data.clone() for h in host.emb_l]))
+        cg.ctx.check()
+        states.append(snaps)
+    assert sum(s[2][-1] for s in states[0]) > 0, "the fixture must produce victims"
+    for a, b in zip(*states):
+        assert torch.equal(a[0], b[0])
+        for x, y in zip(a[1], b[1]):
+            assert torch.equal(x, y)
+        assert a[2] == b[2] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+        for x, y in zip(a[5], b[5]):
+            assert torch.equal(x, y)
+
+
 def test_dropin_autograd_surface_matches_engine(golden):
     """The reference-shaped loop (cache_group(...) -> dlrm(...) -> loss -> backward -> optimizer steps) through the
     autograd wrappers gives the same trajectory as the fused engine."""
