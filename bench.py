@@ -210,17 +210,6 @@ def main():
         if jj + 1 < L and jj + 1 != plan_at:
             nxt = state["win"][:, col + B:col + B + lbs]
         eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
-        if dma_test is not None and j % dma_test["every"] == 0:       # experiment: H2D DMA traffic beside training
-            with torch.cuda.stream(dma_test["stream"]):
-                dma_test["dst"].copy_(dma_test["src"], non_blocking=True)
-
-    dma_test = None
-    if os.environ.get("CDLRM_BENCH_DMA_TEST"):
-        gb = float(os.environ["CDLRM_BENCH_DMA_TEST"])
-        nel = int(gb * (1 << 30) / 4)
-        dma_test = dict(src=torch.empty(nel, dtype=torch.float32).pin_memory(), dst=torch.empty(nel, device=dev),
-                        stream=torch.cuda.Stream(), every=int(os.environ.get("CDLRM_BENCH_DMA_EVERY", "100")))
-        dma_test["src"].fill_(1.0)
 
     for j in range(a.warmup):
         run_step(j, False)
