@@ -281,13 +281,21 @@ __global__ void __launch_bounds__(256) k_gemm_group(GemmGroup grp) {
 // the MFMA operand layout (lane = row, 4 consecutive contraction indices per lane half), 64 contraction indices per
 // batch of loads, two batches in flight.  The 4 partial tiles meet in LDS and are summed in wave order (fixed
 // order: reproducible), then bias / activation / mask and a row-contiguous store.
+// Contraction-index pairing of the LDS-free kernel: a batch is 64 indices = two groups of 32; inside a group lane-half
+// lk owns the 16 CONSECUTIVE indices 16*lk .. 16*lk+15, fetched by four back-to-back 16-byte loads (j = 0..3).  A row of
+// a contraction-contiguous operand is then read 64 contiguous bytes per lane, the two lane halves completing the 128-B
+// line, and the four instructions that touch a line are adjacent in issue order (the earlier pairing 8*s + 4*lk spread
+// them over the whole batch: with 8 waves per CU the lines were evicted from the 32-KB vector L1 in between and came
+// from L2 four times -- forward layout 15.3 -> see DESIGN.md).  Any pairing is valid as long as A and B agree.
+__device__ __forceinline__ int64_t direct_k(int64_t k, int s, int lk) { return k + 32 * (s >> 2) + 16 * lk + 4 * (s & 3); }
+
 template <bool KC, bool VEC>
 __device__ __forceinline__ void direct_load(const float* __restrict__ p, int64_t ld, int64_t k, int64_t kmax, int lk,
                                             float4 (&v)[8]) {
     // straight-line, clamped addresses (see tile_load)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const int64_t kk = k + 8 * s + 4 * lk;
+        const int64_t kk = direct_k(k, s, lk);
         if (KC) {
             if (VEC) {
                 v[s] = *reinterpret_cast<const float4*>(p + min(kk, kmax - 4));
@@ -298,6 +306,34 @@ __device__ __forceinline__ void direct_load(const float* __restrict__ p, int64_t
         } else {
             v[s] = make_float4(p[min(kk, kmax - 1) * ld], p[min(kk + 1, kmax - 1) * ld], p[min(kk + 2, kmax - 1) * ld],
                                p[min(kk + 3, kmax - 1) * ld]);
+        }
+    }
+}
+
+// Aligned fast path (contraction length and split boundaries multiples of 32, waves starting on multiples of 32): the
+// contraction part of every address is wave-uniform -- a scalar base per load, computed on the scalar ALU -- and the
+// lane part (row / column and the lane half's 16*lk) is ONE 32-bit byte offset per operand.  The generic loader keeps a
+// 64-bit address per load in flight: 280-320 VGPRs for the contraction-strided layouts (dgrad, wgrad), one wave per
+// SIMD, and hipcc then parks loaded values in AGPRs behind `s_waitcnt vmcnt(0)` -- a dozen serialised round trips at
+// the head of the kernel (seen in the ISA).  A 32-group that starts inside [0, K) lies inside it entirely (K % 32 == 0),
+// so the uniform clamp below only moves addresses of fully masked groups.
+template <bool KC>
+__device__ __forceinline__ void direct_load_al(const float* __restrict__ base, int64_t ld, unsigned voff, int64_t k,
+                                               int64_t K, float4 (&v)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int64_t ku = k + 32 * (s >> 2) + 4 * (s & 3);
+        if (KC) {
+            const char* sb = reinterpret_cast<const char*>(base + min(ku, K - 20));
+            v[s] = *reinterpret_cast<const float4*>(sb + voff);
+        } else {
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const char* sb = reinterpret_cast<const char*>(base + min(ku + u, K - 17) * ld);
+                e[u] = *reinterpret_cast<const float*>(sb + voff);
+            }
+            v[s] = make_float4(e[0], e[1], e[2], e[3]);
         }
     }
 }
@@ -315,7 +351,7 @@ __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&
 #endif
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const int64_t kk = k + 8 * s + 4 * lk;
+        const int64_t kk = direct_k(k, s, lk);
         // zeroing ONE operand past the end of this wave's contraction range is enough
         const float ax = kk + 0 < kw1 ? a[s].x : 0.f, ay = kk + 1 < kw1 ? a[s].y : 0.f;
         const float az = kk + 2 < kw1 ? a[s].z : 0.f, aw = kk + 3 < kw1 ? a[s].w : 0.f;
@@ -327,54 +363,82 @@ __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&
     }
 }
 
-// LOOP = false: each wave's share of the contraction is <= 64 (one batch of loads, no loop)
-template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
+// MODE 0: each wave's share of the contraction is <= 64 (one batch of loads, no loop); 1: <= 128 (two batches, no
+// loop); 2: longer (two batches in flight around a loop, the last <= 128 indices peeled so that no batch is fetched
+// past the end: at K = 512 that trailing prefetch was a third of all the loads)
+template <bool A_KC, bool B_KC, bool VA, bool VB, int MODE, bool AL>
 __device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsigned by, unsigned bz,
                                             float (*red)[32][33], float (*csr)[32]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the contraction range is uniform
     const int lr = lane & 31, lk = lane >> 5;
     const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
     const int64_t kbeg = (int64_t)bz * g.kchunk;
     const int64_t kend = min(g.K, kbeg + g.kchunk);
-    const int64_t kq = ((kend - kbeg + 31) / 32) * 8;        // a quarter of the range, rounded up to 8
+    // a quarter of the range: rounded up to 8, or (aligned path) to 32 so that every wave starts on a 32-group
+    const int64_t kq = AL ? ((kend - kbeg + 127) / 128) * 32 : ((kend - kbeg + 31) / 32) * 8;
     const int64_t kw0 = kbeg + wave * kq, kw1 = min(kend, kw0 + kq);
     const int64_t am = min(m0 + lr, g.M - 1), bn = min(n0 + lr, (int64_t)g.N - 1);
     const float* pa = A_KC ? g.A + am * g.lda : g.A + am;
     const float* pb = B_KC ? g.B + bn * g.ldb : g.B + bn;
+    // aligned path: this lane's byte offset into each operand (its row / column + its half's 16 contraction indices)
+    const unsigned va_off = (unsigned)((A_KC ? am * g.lda + 16 * lk : 16 * lk * g.lda + am) * 4);
+    const unsigned vb_off = (unsigned)((B_KC ? bn * g.ldb + 16 * lk : 16 * lk * g.ldb + bn) * 4);
+#define DIRECT_LOAD_A(k_, dst_)                                                   \
+    do {                                                                          \
+        if (AL) direct_load_al<A_KC>(g.A, g.lda, va_off, (k_), g.K, dst_);        \
+        else direct_load<A_KC, VA>(pa, g.lda, (k_), g.K, lk, dst_);               \
+    } while (0)
+#define DIRECT_LOAD_B(k_, dst_)                                                   \
+    do {                                                                          \
+        if (AL) direct_load_al<B_KC>(g.B, g.ldb, vb_off, (k_), g.K, dst_);        \
+        else direct_load<B_KC, VB>(pb, g.ldb, (k_), g.K, lk, dst_);               \
+    } while (0)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float cs = 0.f;
     float4 a0[8], b0[8];
-    direct_load<A_KC, VA>(pa, g.lda, kw0, g.K, lk, a0);
-    direct_load<B_KC, VB>(pb, g.ldb, kw0, g.K, lk, b0);
-    if (LOOP) {
+    DIRECT_LOAD_A(kw0, a0);
+    DIRECT_LOAD_B(kw0, b0);
+    if (MODE >= 1) {
         // Both MFMA batches of an iteration are UNCONDITIONAL (indices past kw1 are zeroed in direct_mma): with a
         // condition on the second batch the compiler sinks its loads into the conditional block, right in front
         // of their use, and the double buffering is gone (seen in the ISA).
         float4 a1[8], b1[8];
+        int64_t k = kw0;
         // sched_barrier: the machine scheduler otherwise drags each load down to just before its use (fewer
         // live registers, 2-4 loads in flight, one exposed latency per step -- seen in the ISA)
-        for (int64_t k = kw0; k < kw1; k += 128) {
-            if (!(DIRECT_ABLATE & 1) || k == kw0) {
-                direct_load<A_KC, VA>(pa, g.lda, k + 64, g.K, lk, a1);
-                direct_load<B_KC, VB>(pb, g.ldb, k + 64, g.K, lk, b1);
+        if (MODE == 2) {
+            for (; k + 128 < kw1; k += 128) {
+                if (!(DIRECT_ABLATE & 1) || k == kw0) {
+                    DIRECT_LOAD_A(k + 64, a1);
+                    DIRECT_LOAD_B(k + 64, b1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                direct_mma(a0, b0, k, kw1, lk, acc, cs);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(DIRECT_ABLATE & 1)) {
+                    DIRECT_LOAD_A(k + 128, a0);
+                    DIRECT_LOAD_B(k + 128, b0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                direct_mma(a1, b1, k + 64, kw1, lk, acc, cs);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            direct_mma(a0, b0, k, kw1, lk, acc, cs);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(DIRECT_ABLATE & 1)) {
-                direct_load<A_KC, VA>(pa, g.lda, k + 128, g.K, lk, a0);
-                direct_load<B_KC, VB>(pb, g.ldb, k + 128, g.K, lk, b0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            direct_mma(a1, b1, k + 64, kw1, lk, acc, cs);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        DIRECT_LOAD_A(k + 64, a1);
+        DIRECT_LOAD_B(k + 64, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        direct_mma(a0, b0, k, kw1, lk, acc, cs);
+        __builtin_amdgcn_sched_barrier(0);
+        direct_mma(a1, b1, k + 64, kw1, lk, acc, cs);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         direct_mma(a0, b0, kw0, kw1, lk, acc, cs);
     }
+#undef DIRECT_LOAD_A
+#undef DIRECT_LOAD_B
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[r];
     if (!A_KC && g.colsum != nullptr && bx == 0) {
@@ -414,17 +478,17 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsi
     }
 }
 
-template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
+template <bool A_KC, bool B_KC, bool VA, bool VB, int MODE, bool AL>
 __global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
     __shared__ float red[4][32][33];
     __shared__ float csr[4][32];
     const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
     const unsigned wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nwg);
-    direct_body<A_KC, B_KC, VA, VB, LOOP>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y,
+    direct_body<A_KC, B_KC, VA, VB, MODE, AL>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y,
                                           wgid / (gridDim.x * gridDim.y), red, csr);
 }
 
-template <bool A_KC, bool B_KC, bool VA, bool VB, bool LOOP>
+template <bool A_KC, bool B_KC, bool VA, bool VB, int MODE, bool AL>
 __global__ void __launch_bounds__(256) k_gemm_direct_group(GemmGroup grp) {
     __shared__ float red[4][32][33];
     __shared__ float csr[4][32];
@@ -436,7 +500,7 @@ __global__ void __launch_bounds__(256) k_gemm_direct_group(GemmGroup grp) {
     const GemmArgs& g = grp.g[p];
     const unsigned local = wgid - grp.first[p];
     const unsigned gx = (unsigned)((g.N + 31) / 32), gy = (unsigned)((g.M + 31) / 32);
-    direct_body<A_KC, B_KC, VA, VB, LOOP>(g, local % gx, (local / gx) % gy, local / (gx * gy), red, csr);
+    direct_body<A_KC, B_KC, VA, VB, MODE, AL>(g, local % gx, (local / gx) % gy, local / (gx * gy), red, csr);
 }
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -477,17 +541,49 @@ static inline bool gemm_use_direct(int64_t M, int64_t N, int64_t splits) {
     return cdiv(M, 64) * cdiv(N, 64) * splits < 512;
 }
 
+// per-wave share of the contraction (a quarter, rounded up to 8 -- to 32 on the aligned path): one batch of 64, two
+// batches, or a loop
+static inline int direct_mode(int64_t klen, bool al) {
+    const int64_t kq = al ? cdiv(klen, 128) * 32 : cdiv(klen, 32) * 8;
+    return kq <= 64 ? 0 : kq <= 128 ? 1 : 2;
+}
+
+// the aligned loader applies: contraction and split boundaries on multiples of 32, 16-byte loads legal on the
+// contraction-contiguous operands, lane offsets within 32 bits
+template <bool A_KC, bool B_KC>
+static inline bool direct_aligned(const GemmArgs& g, int64_t klen) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("CDLRM_GEMM_ALIGNED");
+        off = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    if (off) return false;
+    if (g.K < 32 || g.K % 32 != 0 || (klen < g.K && klen % 32 != 0)) return false;
+    if ((A_KC && !g.vecA) || (B_KC && !g.vecB)) return false;
+    const int64_t lim = (int64_t)1 << 30;      // elements: byte offsets stay below 2^32
+    if ((A_KC ? g.M * g.lda : 16 * g.lda + g.M) >= lim || (B_KC ? (int64_t)g.N * g.ldb : 16 * g.ldb + g.N) >= lim) return false;
+    return true;
+}
+
 template <bool A_KC, bool B_KC>
 static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
     g.vecC = aligned16(g.C) && g.ldc % 4 == 0 && g.slab % 4 == 0;
     const bool va = A_KC && g.vecA, vb = B_KC && g.vecB;     // only contraction-contiguous operands use 16-B loads
     dim3 grid((unsigned)cdiv(g.N, 32), (unsigned)cdiv(g.M, 32), (unsigned)splits);
     const int64_t klen = g.kchunk < g.K ? g.kchunk : g.K;
-    const bool loop = cdiv(klen, 32) * 8 > 64;                // per-wave share of the contraction > one batch
+    const bool al = direct_aligned<A_KC, B_KC>(g, klen);
+    const int mode = direct_mode(klen, al);
+    if (al) {
+        if (mode == 2) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, A_KC, B_KC, 2, true>), grid, dim3(256), 0, s, g);
+        else if (mode == 1) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, A_KC, B_KC, 1, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, A_KC, B_KC, 0, true>), grid, dim3(256), 0, s, g);
+        return;
+    }
 #define CDLRM_DIRECT(VA_, VB_)                                                                              \
     do {                                                                                                    \
-        if (loop) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, true>), grid, dim3(256), 0, s, g);   \
-        else hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, false>), grid, dim3(256), 0, s, g);       \
+        if (mode == 2) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, 2, false>), grid, dim3(256), 0, s, g);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, 1, false>), grid, dim3(256), 0, s, g); \
+        else hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, VA_, VB_, 0, false>), grid, dim3(256), 0, s, g);                \
     } while (0)
     if (va && vb) CDLRM_DIRECT(A_KC, B_KC);
     else if (va) CDLRM_DIRECT(A_KC, false);
@@ -498,25 +594,37 @@ static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
 
 // up to GEMM_GROUP_MAX un-split problems of the weight-gradient layout (both operands contraction-strided) per launch
 static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s) {
-    for (int want_loop = 0; want_loop < 2; ++want_loop) {
+    for (int want = 0; want < 6; ++want) {
+        const int want_mode = want % 3;
+        const bool want_al = want >= 3;
         GemmGroup grp;
         memset(&grp, 0, sizeof(grp));
         unsigned blocks = 0;
         auto flush = [&]() {
             if (grp.n == 0) return;
             grp.first[grp.n] = blocks;
-            if (want_loop)
-                hipLaunchKernelGGL((k_gemm_direct_group<false, false, false, false, true>), dim3(blocks), dim3(256), 0, s, grp);
-            else
-                hipLaunchKernelGGL((k_gemm_direct_group<false, false, false, false, false>), dim3(blocks), dim3(256), 0, s, grp);
+#define CDLRM_DGROUP(MODE_, AL_) \
+    hipLaunchKernelGGL((k_gemm_direct_group<false, false, false, false, MODE_, AL_>), dim3(blocks), dim3(256), 0, s, grp)
+            if (want_al) {
+                if (want_mode == 2) CDLRM_DGROUP(2, true);
+                else if (want_mode == 1) CDLRM_DGROUP(1, true);
+                else CDLRM_DGROUP(0, true);
+            } else {
+                if (want_mode == 2) CDLRM_DGROUP(2, false);
+                else if (want_mode == 1) CDLRM_DGROUP(1, false);
+                else CDLRM_DGROUP(0, false);
+            }
+#undef CDLRM_DGROUP
             grp.n = 0;
             blocks = 0;
         };
         for (int i = 0; i < n; ++i) {
             // kchunk < K: the contraction is cut into slabs (C + z*slab, colsum + z*M), summed by the caller
             const int64_t kc = probs[i].kchunk > 0 && probs[i].kchunk < probs[i].K ? probs[i].kchunk : probs[i].K;
-            const bool loop = cdiv(kc, 32) * 8 > 64;
-            if ((int)loop != want_loop) continue;
+            GemmArgs pg = probs[i];
+            pg.kchunk = kc;
+            const bool al = direct_aligned<false, false>(pg, kc);
+            if (al != want_al || direct_mode(kc, al) != want_mode) continue;
             if (grp.n == GEMM_GROUP_MAX) flush();
             grp.first[grp.n] = blocks;
             grp.g[grp.n] = probs[i];

@@ -153,6 +153,35 @@ def test_dense_fwd_bwd(golden, itself):
         assert torch.equal(tw[i].grad, t(g[f"top_gw{i}"])) and torch.equal(tb[i].grad, t(g[f"top_gb{i}"]))
 
 
+DENSE_VARIANTS = ["cat_bce", "dot_mse", "dot_wbce", "dot_bce_thr", "cat_wbce_thr"]
+
+
+@pytest.mark.parametrize("name", DENSE_VARIANTS)
+def test_dense_variants(golden, name):
+    """"cat" interaction, MSE / weighted BCE, the --loss-threshold clamp (model_no_ddp.py:297-316,
+    main_no_ddp.py:212-221): the oracle against the reference's DLRM_Net + loss_fn_wrap."""
+    g = golden("dense_" + name)
+    op, kind, thr = str(g["op"]), str(g["loss_kind"]), float(g["loss_threshold"])
+    ws = torch.tensor(g["loss_weights"])                    # float64, as main_no_ddp.py:370 builds it
+    nb, nt = len(g["ln_bot"]) - 1, len(g["ln_top"]) - 1
+    bw = [t(g[f"bot_w{i}"]).requires_grad_(True) for i in range(nb)]
+    bb = [t(g[f"bot_b{i}"]).requires_grad_(True) for i in range(nb)]
+    tw = [t(g[f"top_w{i}"]).requires_grad_(True) for i in range(nt)]
+    tb = [t(g[f"top_b{i}"]).requires_grad_(True) for i in range(nt)]
+    ly = [t(g[f"ly_{k}"]).requires_grad_(True) for k in range(5)]
+    X, Tt = t(g["X"]), t(g["T"])
+    Z = O.dlrm_forward(X, ly, (bw, bb), (tw, tb), op, False, thr)
+    E = O.loss_fn(Z, Tt, kind, ws)
+    E.backward()
+    assert torch.equal(Z.detach(), t(g["Z"])) and float(E) == float(g["loss"])
+    for k in range(5):
+        assert torch.equal(ly[k].grad, t(g[f"ly_grad_{k}"]))
+    for i in range(nb):
+        assert torch.equal(bw[i].grad, t(g[f"bot_gw{i}"])) and torch.equal(bb[i].grad, t(g[f"bot_gb{i}"]))
+    for i in range(nt):
+        assert torch.equal(tw[i].grad, t(g[f"top_gw{i}"])) and torch.equal(tb[i].grad, t(g[f"top_gb{i}"]))
+
+
 @pytest.mark.parametrize("name", ["embsgd_onehot", "embsgd_multihot"])
 def test_embbag_bwd_sgd(golden, name):
     g = golden(name)

@@ -311,6 +311,49 @@ def g_dense(M, MD, CM, QR):
         save("dense_itself%d" % int(itself), **out)
 
 
+def g_dense_variants(M, MD, CM, QR):
+    """The non-default arms of the dense path, through the reference's own DLRM_Net + loss_fn_wrap
+    (main_no_ddp.py:212-221, 364-372; model_no_ddp.py:272-316): "cat" interaction, MSE, weighted BCE
+    (`--loss-weights`), and the `--loss-threshold` clamp of the prediction."""
+    variants = dict(cat_bce=("cat", "bce", "1.0-1.0", 0.0), dot_mse=("dot", "mse", "1.0-1.0", 0.0),
+                    dot_wbce=("dot", "wbce", "0.4-2.5", 0.0), dot_bce_thr=("dot", "bce", "1.0-1.0", 0.1),
+                    cat_wbce_thr=("cat", "wbce", "1.5-0.7", 0.25))
+    for name, (op, loss, lw, thr) in variants.items():
+        np.random.seed(13)
+        torch.manual_seed(13)
+        D, Tn, B = 16, 5, 24
+        nf = Tn + 1
+        n_in = D + (nf * (nf - 1)) // 2 if op == "dot" else nf * D
+        ln_bot, ln_top = np.array([13, 32, D]), np.array([n_in, 24, 8, 1])
+        dl = MD.DLRM_Net(ln_bot, ln_top, op, False, True, -1, ln_top.size - 2, thr)
+        X = torch.rand(B, 13)
+        ly = [torch.randn(B, D, requires_grad=True) for _ in range(Tn)]
+        Tt = torch.round(torch.rand(B, 1))
+        args = types.SimpleNamespace(loss_function=loss, loss_weights=lw)
+        if loss == "mse":
+            loss_fn, loss_ws = torch.nn.MSELoss(reduction="mean"), None
+        elif loss == "bce":
+            loss_fn, loss_ws = torch.nn.BCELoss(reduction="mean"), None
+        else:       # main_no_ddp.py:370-372 (np.fromstring there; same parse)
+            loss_ws = torch.tensor(np.array([float(s) for s in lw.split("-")], dtype=float))
+            loss_fn = torch.nn.BCELoss(reduction="none")
+        Z = dl(X, ly)
+        E = M.loss_fn_wrap(Z, Tt, loss_fn, args, loss_ws)
+        E.backward()
+        out = dict(op=op, loss_kind=loss, loss_weights=np.array([float(s) for s in lw.split("-")]), loss_threshold=thr,
+                   X=X, T=Tt, Z=Z.detach(), loss=E.detach().to(torch.float64), ln_bot=ln_bot, ln_top=ln_top)
+        for k in range(Tn):
+            out[f"ly_{k}"], out[f"ly_grad_{k}"] = ly[k].detach(), ly[k].grad
+        for nm, seq in (("bot", dl.bot_l), ("top", dl.top_l)):
+            i = 0
+            for l in seq:
+                if isinstance(l, torch.nn.Linear):
+                    out[f"{nm}_w{i}"], out[f"{nm}_b{i}"] = l.weight.data.clone(), l.bias.data.clone()
+                    out[f"{nm}_gw{i}"], out[f"{nm}_gb{i}"] = l.weight.grad.clone(), l.bias.grad.clone()
+                    i += 1
+        save("dense_" + name, **out)
+
+
 def g_embbag_sgd(M, MD, CM, QR):
     """nn.EmbeddingBag(sum, sparse) backward + optim.SGD step on cache rows (a-7), with repeated
     slots and a multi-hot case."""
@@ -637,6 +680,7 @@ def g_criteo_loader(M, MD, CM, QR):
 
 
 GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
+            dense_variants=g_dense_variants,
             embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_w2=g_train_w2, qr=g_qr,
             window_groups=g_window_groups)
 
