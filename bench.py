@@ -154,7 +154,10 @@ def main():
     np.random.seed(a.seed)
     dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
     eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
-                      table_agg_freq=cfg["agg"], table_agg_op="mean")
+                      table_agg_freq=cfg["agg"], table_agg_op="mean",
+                      # measured on one GPU: no gain (the side-stream weight gradients slow the main chain by what they
+                      # save); with more ranks it takes the top MLP's all-reduce off the critical path
+                      defer_top_update=os.environ.get("CDLRM_DEFER_TOP", "1" if world > 1 else "0") != "0")
     # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
     # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
     pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world,
@@ -227,6 +230,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
+    eng.finish()
     cg.ctx.check()
     loss = float(eng._bufs[lbs]["loss"][0])
 
@@ -242,7 +246,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc.get("workload") == a.config and pmc.get("n_gpus") == world and a.alpha == 1.05:
+            if (pmc.get("workload") == a.config and pmc.get("n_gpus") == world and a.alpha == 1.05 and a.batch <= 0
+                    and a.max_ind_range <= 0):
                 traffic = pmc.get("hbm_bytes_per_launch")
         out = {
             "metric": "training samples/sec, Criteo-Terabyte-shape synthetic (cached data-parallel DLRM step, refills included)",

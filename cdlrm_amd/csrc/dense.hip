@@ -821,6 +821,247 @@ extern "C" int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n,
     return 0;
 }
 
+// -------------------------------------------------------------------------------------------------
+// The other arms of the loss (main_no_ddp.py:212-221, 364-372) and the --loss-threshold clamp of the prediction
+// (model_no_ddp.py:311-314), element-wise: kind 0 BCELoss, 1 MSELoss, 2 weighted BCE (loss_ws[T.long()] * BCE(none),
+// mean).  Returns the element's loss term (before the division by n); *d = dL/d(pre-clamp prediction).
+// -------------------------------------------------------------------------------------------------
+struct LossCfg {
+    int kind;
+    float w0, w1;        // wbce: weight of target class 0 / 1
+    float thr;           // 0 < thr < 1: z = clamp(p, thr, 1 - thr); gradient only where thr <= p <= 1 - thr
+};
+
+__device__ __forceinline__ float loss_elem(float p, float t, const LossCfg& c, int64_t n, float* zc, float* d) {
+    float z = p;
+    bool pass = true;
+    if (c.thr > 0.f && c.thr < 1.f) {
+        const float hi = 1.0f - c.thr;
+        z = fminf(fmaxf(p, c.thr), hi);
+        pass = (p >= c.thr) && (p <= hi);
+    }
+    *zc = z;
+    float l, g;
+    if (c.kind == 1) {                      // mse_loss: (z - t)^2, backward 2 (z - t) / n
+        const float df = z - t;
+        l = df * df;
+        g = 2.0f * df * (1.0f / (float)n);
+    } else {
+        // torch binary_cross_entropy: log terms clamped at -100; backward (z - t) / max((1 - z) z, 1e-12) * grad
+        const float l1 = fmaxf(logf(z), -100.f), l0 = fmaxf(log1pf(-z), -100.f);
+        l = (t - 1.0f) * l0 - t * l1;
+        float go = 1.0f / (float)n;
+        if (c.kind == 2) {                  // the weights are float64 in the reference: w / n is rounded once
+            const float w = ((long)t == 0) ? c.w0 : c.w1;
+            l *= w;
+            go = (float)((double)w / (double)n);
+        }
+        g = (z - t) / fmaxf((1.0f - z) * z, 1e-12f) * go;
+    }
+    *d = pass ? g : 0.f;
+    return l;
+}
+
+__global__ void __launch_bounds__(1024) k_loss_one(const float* __restrict__ Z, const float* __restrict__ T, int64_t n,
+                                                   LossCfg c, float* __restrict__ loss, float* __restrict__ dZ,
+                                                   float* __restrict__ Zc, int sigmoid_bwd) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float p = Z[i];
+        float zc, d;
+        s += loss_elem(p, T[i], c, n, &zc, &d);
+        if (sigmoid_bwd) d = d * ((1.0f - p) * p);
+        if (dZ) dZ[i] = d;
+        if (Zc) Zc[i] = zc;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        loss[0] = tot / (float)n;
+    }
+}
+
+extern "C" int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t kind, float w0, float w1,
+                                  float threshold, float* loss_out, float* dZ, float* Zc, int32_t sigmoid_bwd,
+                                  void* stream) {
+    CDLRM_REQUIRE(Z && target && loss_out && n >= 1 && kind >= 0 && kind <= 2, "bad argument");
+    LossCfg c;
+    c.kind = kind; c.w0 = w0; c.w1 = w1; c.thr = threshold;
+    hipLaunchKernelGGL(k_loss_one, dim3(1), dim3(1024), 0, (hipStream_t)stream, Z, target, n, c, loss_out, dZ, Zc,
+                       (int)sigmoid_bwd);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Output head in ONE launch: the last top-MLP layer (out_features = 1, sigmoid; main_no_ddp.py:358), the loss and
+// that layer's input gradient.  At a local batch of 1024 the three stand-alone kernels (256 -> 1 GEMM, loss, 1 -> 256
+// outer product) cost 8.7 + 7.4 + 7.5 us of fixed latency for 2 MB of traffic.  One wave per row: dot over K by
+// lanes, sigmoid, loss term, dz (pre-activation gradient of the last layer), then dY[row, :] = dz * w, times the
+// derivative of the activation that produced Y.  Loss: per-workgroup partials, summed in index order by the
+// workgroup that arrives last (reproducible).  scratch: [0] arrival counter (zero before the first call; the kernel
+// leaves it zero), [1 .. grid] partial sums.
+// -------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ w,
+                                              const float* __restrict__ bias, const float* __restrict__ T, int64_t B,
+                                              int K, LossCfg c, int x_act, float* __restrict__ Zout,
+                                              float* __restrict__ Zc, float* __restrict__ dZ, float* __restrict__ dY,
+                                              int64_t lddy, float* __restrict__ loss, float* __restrict__ scratch) {
+    __shared__ float red[4];
+    __shared__ unsigned last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float b0 = bias ? bias[0] : 0.f;
+    float lsum = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < B; row += (int64_t)gridDim.x * 4) {
+        const float* y = Y + row * ldy;
+        float acc = 0.f;
+        if (VEC) {
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(y + k);
+                const float4 ww = *reinterpret_cast<const float4*>(w + k);
+                acc = fmaf(a.x, ww.x, acc); acc = fmaf(a.y, ww.y, acc);
+                acc = fmaf(a.z, ww.z, acc); acc = fmaf(a.w, ww.w, acc);
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) acc = fmaf(y[k], w[k], acc);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        const float pre = acc + b0;
+        const float p = 1.0f / (1.0f + expf(-pre));
+        float zc, d;
+        const float l = loss_elem(p, T[row], c, B, &zc, &d);
+        d = d * ((1.0f - p) * p);                       // sigmoid backward: gradient w.r.t. the pre-activation
+        if (lane == 0) {
+            lsum += l;
+            Zout[row] = p;
+            if (Zc) Zc[row] = zc;
+            dZ[row] = d;
+        }
+        if (dY) {
+            float* dy = dY + row * lddy;
+            if (VEC) {
+                for (int k = lane * 4; k < K; k += 256) {
+                    const float4 a = *reinterpret_cast<const float4*>(y + k);
+                    const float4 ww = *reinterpret_cast<const float4*>(w + k);
+                    float4 o = make_float4(d * ww.x, d * ww.y, d * ww.z, d * ww.w);
+                    if (x_act == 1) {
+                        o.x = a.x > 0.f ? o.x : 0.f; o.y = a.y > 0.f ? o.y : 0.f;
+                        o.z = a.z > 0.f ? o.z : 0.f; o.w = a.w > 0.f ? o.w : 0.f;
+                    } else if (x_act == 2) {
+                        o.x *= (1.0f - a.x) * a.x; o.y *= (1.0f - a.y) * a.y;
+                        o.z *= (1.0f - a.z) * a.z; o.w *= (1.0f - a.w) * a.w;
+                    }
+                    *reinterpret_cast<float4*>(dy + k) = o;
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) {
+                    const float a = y[k];
+                    float o = d * w[k];
+                    if (x_act == 1) o = a > 0.f ? o : 0.f;
+                    else if (x_act == 2) o *= (1.0f - a) * a;
+                    dy[k] = o;
+                }
+            }
+        }
+    }
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(scratch), 1u);
+    }
+    __syncthreads();
+    if (last == gridDim.x - 1 && wave == 0) {
+        // fixed order for a given grid: lane i sums partials i, i + 64, ..., then a butterfly over the lanes
+        __threadfence();
+        float s = 0.f;
+        for (unsigned i = lane; i < gridDim.x; i += 64) s += __builtin_nontemporal_load(scratch + 1 + i);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) {
+            loss[0] = s / (float)B;
+            *reinterpret_cast<unsigned*>(scratch) = 0u;
+        }
+    }
+}
+
+#define HEAD_MAX_BLOCKS 256
+extern "C" int64_t cdlrm_head_scratch_floats(void) { return 1 + HEAD_MAX_BLOCKS; }
+
+extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
+                                  int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold,
+                                  int32_t x_act, float* Z, float* Zc, float* dZ, float* dY, int64_t lddy,
+                                  float* loss_out, float* scratch, void* stream) {
+    CDLRM_REQUIRE(Y && w && target && Z && dZ && loss_out && scratch && B >= 1 && K >= 1, "bad argument");
+    CDLRM_REQUIRE(kind >= 0 && kind <= 2 && x_act >= 0 && x_act <= 2, "bad loss kind / activation");
+    LossCfg c;
+    c.kind = kind; c.w0 = w0; c.w1 = w1; c.thr = threshold;
+    int64_t gx = cdiv(B, 4);
+    if (gx > HEAD_MAX_BLOCKS) gx = HEAD_MAX_BLOCKS;
+    const bool vec = K % 4 == 0 && ldy % 4 == 0 && (!dY || lddy % 4 == 0) && (((uintptr_t)Y | (uintptr_t)w | (uintptr_t)dY) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_head<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B,
+                           (int)K, c, (int)x_act, Z, Zc, dZ, dY, lddy, loss_out, scratch);
+    else
+        hipLaunchKernelGGL(k_head<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B,
+                           (int)K, c, (int)x_act, Z, Zc, dZ, dY, lddy, loss_out, scratch);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// dX *= act'(X) over an [M, N] block with row pitches (the "cat" interaction has no interaction backward whose
+// epilogue could apply the bottom MLP's last activation: model_no_ddp.py:297-299)
+__global__ void __launch_bounds__(256) k_act_bwd(float* __restrict__ dX, int64_t lddx, const float* __restrict__ X,
+                                                 int64_t ldx, int64_t M, int N, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / N, c = i % N;
+        const float x = X[r * ldx + c];
+        float d = dX[r * lddx + c];
+        d = act == 1 ? (x > 0.f ? d : 0.f) : act == 2 ? d * ((1.0f - x) * x) : d;
+        dX[r * lddx + c] = d;
+    }
+}
+
+extern "C" int cdlrm_act_bwd(float* dX, int64_t lddx, const float* X, int64_t ldx, int64_t M, int32_t N, int32_t act,
+                             void* stream) {
+    CDLRM_REQUIRE(dX && X && M >= 0 && N >= 1 && act >= 0 && act <= 2, "bad argument");
+    if (M == 0 || act == 0) return 0;
+    int64_t gx = cdiv(M * N, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, dX, lddx, X, ldx, M, (int)N, (int)act);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// two ranges of one flat buffer in one launch (a sub-network's weights and, behind all weights, its biases)
+__global__ void __launch_bounds__(256) k_sgd2(float* __restrict__ p, const float* __restrict__ g, int64_t off0, int64_t n0,
+                                              int64_t off1, int64_t n1, float lr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = i < n0 ? off0 + i : off1 + (i - n0);
+        p[j] = fmaf(-lr, g[j], p[j]);
+    }
+}
+
+extern "C" int cdlrm_sgd_step2(float* param, const float* grad, int64_t off0, int64_t n0, int64_t off1, int64_t n1,
+                               float lr, void* stream) {
+    CDLRM_REQUIRE(param && grad && off0 >= 0 && n0 >= 0 && off1 >= 0 && n1 >= 0, "bad argument");
+    if (n0 + n1 == 0) return 0;
+    int64_t gx = cdiv(n0 + n1, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_sgd2, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, param, grad, off0, n0, off1, n1, lr);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void __launch_bounds__(256) k_sgd(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = fmaf(-lr, g[i], p[i]);

@@ -199,7 +199,14 @@ class WindowPipeline:
 class TrainEngine:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, dlrm: DLRM_Net, host_tables: Embedding_Table_Group,
                  *, lr: float, lr_embeds: float, world_size: int = 1, rank: int = 0, table_agg_freq: int = 1,
-                 table_agg_op: str = "mean", process_group=None):
+                 table_agg_op: str = "mean", process_group=None, loss: str = "bce", loss_weights=(1.0, 1.0),
+                 defer_top_update: bool = False):
+        """loss / loss_weights: --loss-function / --loss-weights (main_no_ddp.py:364-372); the --loss-threshold clamp
+        is read from `dlrm.loss_threshold`.
+        defer_top_update: the top MLP's weight gradients, their all-reduce and their SGD update leave the critical
+        path -- they run on a side stream beside the interaction backward, the bottom MLP's backward and the HEAD of the
+        next step (gather, bottom MLP forward), which only waits for them in front of its interaction.  Same values,
+        different schedule; readers of the top MLP's weights outside step()/evaluate() call finish() first."""
         self.cg, self.dlrm, self.host = cache_group, dlrm, host_tables
         self.ctx = cache_group.ctx
         self.dev = cache_group.weight.device
@@ -210,7 +217,13 @@ class TrainEngine:
         self.T, self.D = self.ctx.T, self.ctx.D
         self.F = self.T + 1
         self.itself = bool(dlrm.arch_interaction_itself)
-        assert dlrm.arch_interaction_op == "dot", "the fused engine implements the dot interaction"
+        assert dlrm.arch_interaction_op in ("dot", "cat"), "--arch-interaction-op: dot or cat (model_no_ddp.py:272-304)"
+        self.cat = dlrm.arch_interaction_op == "cat"
+        self.loss_kind = ops.LOSS[loss]
+        self.loss_weights = (float(loss_weights[0]), float(loss_weights[1]))
+        thr = float(getattr(dlrm, "loss_threshold", 0.0) or 0.0)
+        self.loss_threshold = thr if 0.0 < thr < 1.0 else 0.0
+        self.defer_top = bool(defer_top_update)
         self.bot = dlrm._acts(dlrm.bot_l, dlrm.sigmoid_bot)
         self.top = dlrm._acts(dlrm.top_l, dlrm.sigmoid_top)
         self._flatten_params()
@@ -226,7 +239,11 @@ class TrainEngine:
         self._emb_done = None
         ne = lambda: S.new_event(self.dev)
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
-                            emb_done=ne(), wgrad_done=ne(), top_dz=ne())
+                            emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne())
+        self._head_scratch = ops.head_scratch(self.dev)
+        # output head in one launch (last layer + loss + its input gradient) when the last top layer is 1-wide + sigmoid
+        l_last, a_last = self.top[-1]
+        self.fused_head = (l_last.out_features == 1 and a_last == 2 and os.environ.get("CDLRM_FUSED_HEAD", "1") != "0")
         # top-MLP weight gradients at long local batches: the SAME stream as the prefetch (their work never overlaps in
         # time: probe/fill right after the gather, weight gradients late in the backward) -- four streams in all
         # (main, side, pref, the window plan's), one per default hardware queue
@@ -252,6 +269,12 @@ class TrainEngine:
         self.param_flat = torch.zeros(nw + nb, dtype=torch.float32, device=self.dev)
         self.grad_flat = torch.zeros(nw + nb, dtype=torch.float32, device=self.dev)
         self.n_weight = nw
+        nbot = len(_linears(self.dlrm.bot_l))
+        nw_bot = sum(l.out_features * kp[l] for l in lin[:nbot])
+        nb_bot = sum(l.bias.numel() for l in lin[:nbot])
+        # (weights offset, count, biases offset, count) of the bottom / top MLP inside the flat buffers
+        self.rng_bot = (0, nw_bot, nw, nb_bot)
+        self.rng_top = (nw_bot, nw - nw_bot, nw + nb_bot, nb - nb_bot)
         off_w, off_b = 0, nw
         self.W, self.gW, self.gb = {}, {}, {}
         for l in lin:
@@ -278,11 +301,21 @@ class TrainEngine:
         f32 = torch.float32
         npairs = F * (F + 1) // 2 if self.itself else F * (F - 1) // 2
         b = dict()
-        b["feat"] = torch.empty(B, F, D, dtype=f32, device=dev)
-        b["dfeat"] = torch.empty(B, F, D, dtype=f32, device=dev)
-        assert self.r_width >= D + npairs
-        b["R"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)      # pad column (if any) stays zero
-        b["dR"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
+        if self.cat:
+            # "cat" interaction (model_no_ddp.py:297-299): R = cat([x] + ly) IS the feature block the bottom MLP and
+            # the gather write into -- no interaction kernel, no copy
+            assert self.r_width >= F * D
+            b["R"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
+            b["dR"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
+            b["feat"] = b["R"].as_strided((B, F, D), (self.r_width, D, 1))
+            b["dfeat"] = b["dR"].as_strided((B, F, D), (self.r_width, D, 1))
+        else:
+            b["feat"] = torch.empty(B, F, D, dtype=f32, device=dev)
+            b["dfeat"] = torch.empty(B, F, D, dtype=f32, device=dev)
+            assert self.r_width >= D + npairs
+            b["R"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)      # pad column (if any) stays zero
+            b["dR"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
+        b["Zc"] = torch.empty(B, 1, dtype=f32, device=dev) if self.loss_threshold > 0.0 else None
         # activations / gradients of the hidden layers
         b["bot_y"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.bot[:-1]]
         b["bot_dy"] = [torch.empty(B, l.out_features, dtype=f32, device=dev) for l, _ in self.bot[:-1]]
@@ -305,7 +338,7 @@ class TrainEngine:
         # long local batches: the top MLP's weight gradients run on their own stream beside the interaction backward
         # and the bottom MLP's backward -- (bottom plan, top plan), each with its own scratch
         b["wgrad_split"] = None
-        if S.is_hip(dev) and self.split_wgrad_min <= B <= self.split_wgrad_max:
+        if self.defer_top or (S.is_hip(dev) and self.split_wgrad_min <= B <= self.split_wgrad_max):
             nb = len(self.bot)
             gw = [self.gW[l] for l in layers]
             gb = [self.gb[l] for l in layers]
@@ -376,9 +409,28 @@ class TrainEngine:
         if self.use_tape and gather_events is None and lS_o is None:
             sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
-            self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
+            sgd_done = self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
         # ---- dense gradient exchange + SGD ----
-        if self.world > 1:
+        if self.world > 1 and self.defer_top:
+            # two exchanges, issued in the same order on every rank: the top MLP's (its weight gradients were launched
+            # on the side stream right after the top dgrad chain) runs beside the rest of this step's backward and the
+            # head of the next step; the bottom MLP's is the only one on the critical path
+            wst, W = self.wst, float(self.world)
+            o, n_, ob, nb_ = self.rng_top
+            with S.on_stream(wst):
+                gt = self.grad_flat[o:o + n_]
+                ops.scale_div(gt, W, stream=wst)                 # layer.weight.grad /= world (:239); biases untouched
+                dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.pg)
+                ops.sgd_step2(self.param_flat, self.grad_flat, o, n_, ob, nb_, self.lr, stream=wst)
+                self._events["top_updated"].record(wst)
+            o, n_, ob, nb_ = self.rng_bot
+            gb = self.grad_flat[o:o + n_]
+            ops.scale_div(gb, W)
+            dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=self.pg)
+            S.current_stream(self.dev).wait_event(self._events["emb_done"])
+            ops.sgd_step2(self.param_flat, self.grad_flat, o, n_, ob, nb_, self.lr)
+            sgd_done = True
+        elif self.world > 1:
             gw = self.grad_flat[:self.n_weight]
             ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
             dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
@@ -412,6 +464,9 @@ class TrainEngine:
         side = self.side
         ev = self._events
         two_phase = ctx.aux_phases >= 2
+        if self.defer_top and self.cat:
+            # the previous step's top weight gradients read R = the feature block this step's first kernels overwrite
+            rec(main.wait_event, ev["top_updated"])
         pref, self._pref = self._pref, None
         if pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape):
             slots, miss_pos, miss_count, probed = pref["res"]
@@ -434,11 +489,11 @@ class TrainEngine:
         if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
             e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
             e0.record(main)
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=B)
             e1.record(main)
             gather_events.append((e0, e1))
         else:
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=B)
         if next_idx is not None and two_phase:
             # Software pipelining across iterations: the NEXT batch's tag probe and aux-row fill (~0.25 ms of PCIe
             # reads at c3) start right behind this batch's gather, on their own stream, into the OTHER aux region
@@ -460,12 +515,19 @@ class TrainEngine:
         emb_work = self._emb_work(n)
         rec(side.wait_event, probed)
         ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
-        ops.interact_fwd(feat, self.itself, R)
+        if self.defer_top and not self.cat:
+            # the previous step's top-MLP update (weight gradients read R / top_y / top_dy, then all-reduce and SGD on
+            # the side stream) has to have landed before this step overwrites those buffers and reads the weights
+            rec(main.wait_event, ev["top_updated"])
+        if not self.cat:
+            ops.interact_fwd(feat, self.itself, R)
         cur = R
         top_acts = [R]
+        fused_head = self.fused_head
         for i, (l, act) in enumerate(self.top):
             y = buf["top_y"][i]
-            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
+            if not (fused_head and i == len(self.top) - 1):
+                ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             top_acts.append(y)
             cur = y
         Z = cur
@@ -478,9 +540,21 @@ class TrainEngine:
         split = buf["wgrad_split"]
         nb_, wst = len(self.bot), self.wst
 
-        ops.bce_fwd_bwd(Z, T, buf["loss"], buf["top_dy"][-1], sigmoid_bwd=(last_act == 2))
-        dY = buf["top_dy"][-1]
-        for i in reversed(range(len(self.top))):
+        n_top = len(self.top)
+        if fused_head:
+            # last layer + loss + the layer's input gradient in one launch
+            l = self.top[-1][0]
+            dX = dR if n_top == 1 else buf["top_dy"][-2]
+            ops.head_fwd_bwd(top_acts[-2][:, :l.in_features], self.W[l], l.bias.data, T, Z, buf["top_dy"][-1],
+                             dX[:, :l.in_features], buf["loss"], self._head_scratch,
+                             x_act=(self.top[-2][1] if n_top > 1 else 0), kind=self.loss_kind,
+                             weights=self.loss_weights, threshold=self.loss_threshold, Zc=buf["Zc"])
+            dY = dX
+        else:
+            ops.loss_fwd_bwd(Z, T, buf["loss"], buf["top_dy"][-1], kind=self.loss_kind, weights=self.loss_weights,
+                             threshold=self.loss_threshold, Zc=buf["Zc"], sigmoid_bwd=(last_act == 2))
+            dY = buf["top_dy"][-1]
+        for i in reversed(range(n_top - 1 if fused_head else n_top)):
             l, act = self.top[i]
             if i == len(self.top) - 1 and act == 2:
                 act = 0                                      # already applied by the loss kernel
@@ -498,13 +572,22 @@ class TrainEngine:
             rec(ev["top_dz"].record, main)
             rec(wst.wait_event, ev["top_dz"])
             ops.mlp_wgrad(split[1], stream=wst)
-            rec(ev["wgrad_done"].record, wst)
-        ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
+            if not self.defer_top:
+                rec(ev["wgrad_done"].record, wst)
+            elif self.world == 1:
+                ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
+                rec(ev["top_updated"].record, wst)
+        if self.cat:
+            # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
+            # derivative (the dot path applies it in the interaction backward's epilogue)
+            ops.act_bwd(dfeat[:, 0, :], feat[:, 0, :], self.bot[-1][1])
+        else:
+            ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
         rec(ev["interacted"].record, main)
         rec(side.wait_event, ev["interacted"])
-        ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], F * D, D, self.lr_embeds, emb_work, cg.touched,
+        ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work, cg.touched,
                              stream=side)
         emb_done = ev["emb_done"]
         rec(emb_done.record, side)
@@ -524,20 +607,26 @@ class TrainEngine:
             ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, None, None, 0,
                            buf["lin_work"], x_act=self.bot[i - 1][1])
             dY = dX
+        sgd_included = False
         if split is not None:
             split[0].set_x(0, X)
             ops.mlp_wgrad(split[0])
-            rec(main.wait_event, ev["wgrad_done"])
+            if not self.defer_top:
+                rec(main.wait_event, ev["wgrad_done"])
+            elif self.world == 1:
+                ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
+                sgd_included = True
         else:
             plan = buf["wgrad"]
             plan.set_x(0, X)
             ops.mlp_wgrad(plan)
         if self.world > 1:
-            return       # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
+            return False # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
         if next_idx is None:
             rec(main.wait_stream, side)      # full join
         else:
             rec(main.wait_event, emb_done)   # cache rows are updated; the prefetched probe keeps running
+        return sgd_included
 
     # ----------------------------------------------------------------------------------------------
     def evaluate(self, X: torch.Tensor, lS_i: torch.Tensor, lS_o: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -548,6 +637,7 @@ class TrainEngine:
         ctx = self.ctx
         B, n = X.shape[0], lS_i.shape[1]
         assert n <= ctx.aux, "test batch larger than the aux table (test_mini_batch_size <= aux_table_size)"
+        self.finish()
         buf = self._buffers(B)
         feat, R = buf["feat"], buf["R"]
         F, D = self.F, self.D
@@ -557,14 +647,28 @@ class TrainEngine:
             y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
             ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             cur = y
-        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], F * D, D, n_bags=B)
-        ops.interact_fwd(feat, self.itself, R)
+        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=B)
+        if not self.cat:
+            ops.interact_fwd(feat, self.itself, R)
         cur = R
         for i, (l, act) in enumerate(self.top):
             y = buf["top_y"][i]
             ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             cur = y
+        if self.loss_threshold > 0.0:       # DLRM_Net.forward returns the clamped prediction (model_no_ddp.py:311-314)
+            cur = torch.clamp(cur, min=self.loss_threshold, max=1.0 - self.loss_threshold)
         return cur
+
+    def finish(self):
+        """Order the current stream behind a deferred top-MLP update (defer_top_update): call before reading the top
+        MLP's weights, gradients or activation buffers outside step() / evaluate()."""
+        if self.defer_top:
+            S.current_stream(self.dev).wait_event(self._events["top_updated"])
+
+    def prediction(self, B: int) -> torch.Tensor:
+        """Z of the last step at batch size B as DLRM_Net.forward returns it (clamped under --loss-threshold)."""
+        buf = self._buffers(B)
+        return buf["Zc"] if buf["Zc"] is not None else buf["top_y"][-1]
 
     def _step_taped(self, X, lS_i, T, next_idx):
         """The same launch sequence as _fwd_bwd, replayed from a recording.  At small local batches the ~30 launches
@@ -587,8 +691,8 @@ class TrainEngine:
             calls = []
             _lib.start_recording(calls)
             try:
-                self._fwd_bwd(X, lS_i, T, None, None, next_idx)
-                if self.world == 1:         # no gradient exchange in between: the dense SGD rides on the tape too
+                included = self._fwd_bwd(X, lS_i, T, None, None, next_idx)
+                if self.world == 1 and not included:   # no gradient exchange in between: the dense SGD rides on the tape too
                     ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
             finally:
                 _lib.stop_recording()

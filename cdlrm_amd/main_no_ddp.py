@@ -304,9 +304,10 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     arch_interaction_itself=args.arch_interaction_itself, sync_dense_params=args.sync_dense_params,
                     sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_threshold=args.loss_threshold).to(dev)
     share_occupancy_tables(cache_group, occupancy_tables_fifos, rank)
-    if args.loss_function != "bce":
-        raise NotImplementedError("the fused engine implements --loss-function=bce (the north-star metric); "
-                                  "mse / wbce run through the autograd surface (model_no_ddp.DLRM_Net)")
+    if args.loss_function not in ("mse", "bce", "wbce"):
+        sys.exit("ERROR: --loss-function=" + args.loss_function + " is not supported")
+    # --loss-weights "w0-w1" (main_no_ddp.py:370); only read by wbce
+    loss_ws = [float(x) for x in str(args.loss_weights).split("-")] if args.loss_function == "wbce" else [1.0, 1.0]
     emb_tables.pin() if not getattr(emb_tables, "_pinned", False) else None
     if args.load_model:
         # counterpart of --save-model: MLPs + host tables of a previous run (the cache starts empty)
@@ -318,7 +319,8 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         if world > 1:
             dist.barrier()
     eng = TrainEngine(cache_group, dlrm, emb_tables, lr=args.learning_rate, lr_embeds=args.lr_embeds, world_size=world,
-                      rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op)
+                      rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op,
+                      loss=args.loss_function, loss_weights=loss_ws, defer_top_update=world > 1)
     L = args.lookahead
     pipe = WindowPipeline(cache_group, emb_tables, L * args.mini_batch_size * 2, parity_rng=not args.device_rng,
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
@@ -361,7 +363,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
             lossbuf = eng.step(Xr, Ir, Tr, j=j)
             t2 = time_wrap(rank)
             mbs = Tr.shape[0]
-            Z = eng._bufs[Xr.shape[0]]["top_y"][-1]
+            Z = eng.prediction(Xr.shape[0])
             stats = torch.stack([lossbuf[0] * mbs, (torch.round(Z) == Tr).sum().to(torch.float32),
                                  torch.tensor(float(mbs), device=dev)])
             if world > 1:
@@ -400,6 +402,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                         test_samp += Tn.shape[0]
                     print('Test accuracy = {}%'.format(100 * (total_test_acc / test_samp)), flush=True)
             j += 1
+    eng.finish()
     torch.cuda.synchronize()
     if args.save_model:
         # --save-model is parsed but never acted on by the reference (main_no_ddp.py:111); here: flush every valid

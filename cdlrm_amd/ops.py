@@ -398,6 +398,50 @@ def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, d
                                        1 if sigmoid_bwd else 0, stream_ptr(stream)))
 
 
+LOSS = {"bce": 0, "mse": 1, "wbce": 2}
+
+
+def loss_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, dZ: Optional[torch.Tensor], *,
+                 kind: int = 0, weights=(1.0, 1.0), threshold: float = 0.0, Zc: Optional[torch.Tensor] = None,
+                 sigmoid_bwd: bool = False, stream=None):
+    """loss_fn_wrap (main_no_ddp.py:212-221) with every arm + the --loss-threshold clamp (model_no_ddp.py:311-314)."""
+    check(_lib.lib().cdlrm_loss_fwd_bwd(Z.data_ptr(), target.data_ptr(), Z.numel(), int(kind), float(weights[0]),
+                                        float(weights[1]), float(threshold), loss_buf.data_ptr(), ptr(dZ), ptr(Zc),
+                                        1 if sigmoid_bwd else 0, stream_ptr(stream)))
+
+
+def head_scratch(device) -> torch.Tensor:
+    return torch.zeros(int(_lib.lib().cdlrm_head_scratch_floats()), dtype=torch.float32, device=device)
+
+
+def head_fwd_bwd(Y: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], target: torch.Tensor, Z: torch.Tensor,
+                 dZ: torch.Tensor, dY: Optional[torch.Tensor], loss_buf: torch.Tensor, scratch: torch.Tensor, *,
+                 x_act: int = 0, kind: int = 0, weights=(1.0, 1.0), threshold: float = 0.0,
+                 Zc: Optional[torch.Tensor] = None, stream=None):
+    """Last top layer (out_features 1, sigmoid) + loss + the layer's input gradient in one launch."""
+    B, K = Y.shape
+    assert Y.stride(1) == 1 and w.numel() >= K and Z.numel() == B and dZ.numel() == B and target.numel() == B
+    assert dY is None or (dY.shape == Y.shape and dY.stride(1) == 1)
+    check(_lib.lib().cdlrm_head_fwd_bwd(Y.data_ptr(), Y.stride(0), w.data_ptr(), ptr(bias), target.data_ptr(), B, K,
+                                        int(kind), float(weights[0]), float(weights[1]), float(threshold), int(x_act),
+                                        Z.data_ptr(), ptr(Zc), dZ.data_ptr(), ptr(dY), 0 if dY is None else dY.stride(0),
+                                        loss_buf.data_ptr(), scratch.data_ptr(), stream_ptr(stream)))
+
+
+def act_bwd(dX: torch.Tensor, X: torch.Tensor, act: int, stream=None):
+    """dX *= act'(X) in place over a 2-D block (views with row pitches allowed)."""
+    assert dX.shape == X.shape and dX.dim() == 2 and dX.stride(1) == 1 and X.stride(1) == 1
+    check(_lib.lib().cdlrm_act_bwd(dX.data_ptr(), dX.stride(0), X.data_ptr(), X.stride(0), X.shape[0], X.shape[1],
+                                   int(act), stream_ptr(stream)))
+
+
+def sgd_step2(param: torch.Tensor, grad: torch.Tensor, off0: int, n0: int, off1: int, n1: int, lr: float, stream=None):
+    assert param.is_contiguous() and grad.is_contiguous() and param.numel() == grad.numel()
+    assert 0 <= off0 and off0 + n0 <= param.numel() and 0 <= off1 and off1 + n1 <= param.numel()
+    check(_lib.lib().cdlrm_sgd_step2(param.data_ptr(), grad.data_ptr(), int(off0), int(n0), int(off1), int(n1), float(lr),
+                                     stream_ptr(stream)))
+
+
 def scale_div(x: torch.Tensor, divisor: float, stream=None):
     assert x.is_contiguous()
     check(_lib.lib().cdlrm_scale_div(x.data_ptr(), x.numel(), float(divisor), stream_ptr(stream)))

@@ -316,8 +316,37 @@ int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x
 int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* loss_out, float* dZ,
                       int32_t sigmoid_bwd, void* stream);
 
+/* The loss with all its arms (main_no_ddp.py:212-221, 364-372) and the --loss-threshold clamp of the prediction
+ * (model_no_ddp.py:311-314): kind 0 BCELoss(mean), 1 MSELoss(mean), 2 weighted BCE (w0 / w1 = --loss-weights for
+ * target 0 / 1, mean of w[t] * BCE(none)); 0 < threshold < 1: z = clamp(Z, threshold, 1 - threshold), gradient only
+ * where Z lies inside.  loss_out[0] = loss; dZ (may be NULL) = dL/dZ, times (1 - Z) Z when sigmoid_bwd != 0;
+ * Zc (may be NULL) = the clamped prediction the reference's DLRM_Net.forward returns. */
+int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t kind, float w0, float w1,
+                       float threshold, float* loss_out, float* dZ, float* Zc, int32_t sigmoid_bwd, void* stream);
+
+/* Output head in one launch: last top-MLP layer (out_features 1 + sigmoid, main_no_ddp.py:358; w [K], bias [1] or
+ * NULL), the loss above, and the layer's input gradient.  Y [B, K] (row pitch ldy) is the layer's input, produced
+ * by activation x_act (0 none, 1 ReLU, 2 sigmoid).  Outputs: Z [B] = sigmoid(Y w + b), Zc [B] (may be NULL) clamped
+ * prediction, dZ [B] = dL/d(pre-activation of the last layer), dY [B, K] (pitch lddy; may be NULL) = dZ w^T times
+ * the derivative of x_act, loss_out[0].  scratch: cdlrm_head_scratch_floats() floats, zeroed once by the caller. */
+int64_t cdlrm_head_scratch_floats(void);
+int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
+                       int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold, int32_t x_act,
+                       float* Z, float* Zc, float* dZ, float* dY, int64_t lddy, float* loss_out, float* scratch,
+                       void* stream);
+
 /* p -= lr * g over a flat fp32 buffer (optim.SGD without momentum, main_no_ddp.py:375, 415). */
 int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float lr, void* stream);
+
+/* dX *= act'(X) element-wise over an [M, N] block (row pitches lddx / ldx; act 1 ReLU output, 2 sigmoid output): the
+ * "cat" interaction (model_no_ddp.py:297-299) passes the top MLP's input gradient straight to the bottom MLP's
+ * output, whose activation derivative no other kernel applies. */
+int cdlrm_act_bwd(float* dX, int64_t lddx, const float* X, int64_t ldx, int64_t M, int32_t N, int32_t act, void* stream);
+
+/* The same update over two ranges [off0, off0 + n0) and [off1, off1 + n1) of one flat buffer in one launch (one
+ * sub-network's weights and its biases: the bottom and the top MLP are updated at different points of the step). */
+int cdlrm_sgd_step2(float* param, const float* grad, int64_t off0, int64_t n0, int64_t off1, int64_t n1, float lr,
+                    void* stream);
 
 /* x /= divisor (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239, 244). */
 int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream);

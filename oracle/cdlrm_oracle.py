@@ -468,12 +468,16 @@ class OracleTrainer:
     def __init__(self, ln_emb, m_spa, ln_bot, ln_top, *, cache_size, num_ways, mini_batch_size,
                  world_size=1, lr=0.1, lr_embeds=0.3, lookahead=2, table_agg_freq=1,
                  table_agg_op="mean", loss="bce", itself=False, op="dot", seed=123,
-                 average_on_writeback=False, host_tables=None, cache_init="normal"):
+                 average_on_writeback=False, host_tables=None, cache_init="normal", loss_weights=None,
+                 loss_threshold=0.0):
         self.ln_emb = [int(n) for n in ln_emb]
         self.W = world_size
         self.lr, self.lr_embeds = lr, lr_embeds
         self.L, self.agg_freq, self.agg_op = lookahead, table_agg_freq, table_agg_op
         self.loss_kind, self.itself, self.op = loss, itself, op
+        # --loss-weights as main_no_ddp.py:370 builds them (float64), --loss-threshold (model_no_ddp.py:311-314)
+        self.loss_ws = None if loss_weights is None else torch.tensor([float(w) for w in loss_weights], dtype=torch.float64)
+        self.loss_threshold = float(loss_threshold)
         self.avg_wb = average_on_writeback
         self.ways = num_ways
         self.B = mini_batch_size
@@ -515,7 +519,7 @@ class OracleTrainer:
         with torch.no_grad():
             ly, _ = cache_forward(self.occ, self.weights[0], self.cache_sizes, [lS_o[k] for k in range(len(self.ln_emb))],
                                   [lS_i[k] for k in range(len(self.ln_emb))], self.host)
-            return dlrm_forward(X, ly, self.bot[0], self.top[0], self.op, self.itself)
+            return dlrm_forward(X, ly, self.bot[0], self.top[0], self.op, self.itself, self.loss_threshold)
 
     def step(self, j, X, lS_o, lS_i, T):
         """One iteration of main_no_ddp.py:387-423 for all emulated ranks.  Returns per-rank losses."""
@@ -533,8 +537,8 @@ class OracleTrainer:
             bb = [b.detach().requires_grad_(True) for b in self.bot[r][1]]
             tw = [w.detach().requires_grad_(True) for w in self.top[r][0]]
             tb = [b.detach().requires_grad_(True) for b in self.top[r][1]]
-            Z = dlrm_forward(Xr, ly, (bw, bb), (tw, tb), self.op, self.itself)
-            E = loss_fn(Z, Tr, self.loss_kind)
+            Z = dlrm_forward(Xr, ly, (bw, bb), (tw, tb), self.op, self.itself, self.loss_threshold)
+            E = loss_fn(Z, Tr, self.loss_kind, self.loss_ws)
             E.backward()
             rank_loss.append(float(E.detach()))
             params.append((bw, bb, tw, tb))

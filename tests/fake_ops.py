@@ -264,3 +264,50 @@ def sgd_step(param, grad, lr, stream=None):
 
 def scale_div(x, divisor, stream=None):
     x.div_(divisor)
+
+
+LOSS = {"bce": 0, "mse": 1, "wbce": 2}
+
+
+def _loss(z, target, kind, weights, threshold):
+    zc = torch.clamp(z, min=threshold, max=1.0 - threshold) if 0.0 < threshold < 1.0 else z
+    name = {0: "bce", 1: "mse", 2: "wbce"}[int(kind)]
+    ws = torch.tensor([float(weights[0]), float(weights[1])], dtype=torch.float64)
+    return O.loss_fn(zc, target, name, ws), zc
+
+
+def loss_fwd_bwd(Z, target, loss_buf, dZ, *, kind=0, weights=(1.0, 1.0), threshold=0.0, Zc=None, sigmoid_bwd=False,
+                 stream=None):
+    z = Z.detach().clone().requires_grad_(True)
+    l, zc = _loss(z, target, kind, weights, threshold)
+    l.backward()
+    loss_buf[0] = l.detach().float()
+    if Zc is not None:
+        Zc.copy_(zc.detach())
+    if dZ is not None:
+        dZ.copy_(_act_bwd(z.grad, Z, 2) if sigmoid_bwd else z.grad)
+
+
+def head_scratch(device):
+    return torch.zeros(1)
+
+
+def head_fwd_bwd(Y, w, bias, target, Z, dZ, dY, loss_buf, scratch, *, x_act=0, kind=0, weights=(1.0, 1.0),
+                 threshold=0.0, Zc=None, stream=None):
+    K = Y.shape[1]
+    wrow = w.reshape(-1)[:K]
+    pre = Y @ wrow.view(K, 1) + (bias if bias is not None else 0.0)
+    Z.copy_(torch.sigmoid(pre).view_as(Z))
+    loss_fwd_bwd(Z, target.view_as(Z), loss_buf, dZ, kind=kind, weights=weights, threshold=threshold, Zc=Zc,
+                 sigmoid_bwd=True)
+    if dY is not None:
+        dY[:, :K].copy_(_act_bwd(dZ.view(-1, 1) * wrow.view(1, K), Y, x_act))
+
+
+def sgd_step2(param, grad, off0, n0, off1, n1, lr, stream=None):
+    param[off0:off0 + n0].add_(grad[off0:off0 + n0], alpha=-lr)
+    param[off1:off1 + n1].add_(grad[off1:off1 + n1], alpha=-lr)
+
+
+def act_bwd(dX, X, act, stream=None):
+    dX.copy_(_act_bwd(dX, X, act))

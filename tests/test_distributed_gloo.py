@@ -32,16 +32,16 @@ def _batches(g):
     return out
 
 
-def _worker(rank, world, port, name, host_shared, ret):
+def _worker(rank, world, port, name, host_shared, ret, defer=False):
     try:
-        _worker_body(rank, world, port, name, host_shared, ret)
+        _worker_body(rank, world, port, name, host_shared, ret, defer)
     except BaseException as e:      # a dead worker must fail the test, not hang it
         import traceback
         ret.put((rank, {"error": traceback.format_exc()}))
         raise
 
 
-def _worker_body(rank, world, port, name, host_shared, ret):
+def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.set_num_threads(1)
@@ -69,7 +69,7 @@ def _worker_body(rank, world, port, name, host_shared, ret):
     cg = M.Embedding_Table_Cache_Group(m_spa, ln_emb, int(g["cache_size"]), B, int(g["ways"]))
     dl = M.DLRM_Net(np.array(g["ln_bot"]), ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0)
     eng = engine.TrainEngine(cg, dl, eg, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), world_size=world, rank=rank,
-                             table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]))
+                             table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]), defer_top_update=defer)
     pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
     lbs = B // world
     losses = []
@@ -84,6 +84,7 @@ def _worker_body(rank, world, port, name, host_shared, ret):
         sl = slice(rank * lbs, (rank + 1) * lbs)
         loss = eng.step(X[sl], lS_i[:, sl].contiguous(), Tt[sl], j=j)
         losses.append(float(loss[0]))
+    eng.finish()
     lin = M._linears(dl.top_l)
     ret.put((rank, dict(losses=np.array(losses), occ=[o.clone().numpy() for o in cg.occupancy_tables],
                         top_w=[l.weight.data.clone().numpy() for l in lin],
@@ -92,15 +93,17 @@ def _worker_body(rank, world, port, name, host_shared, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,port", [("train_w2_mean", 29811), ("train_w2_freq1", 29812), ("train_w2_max", 29813)])
-def test_two_rank_training_matches_reference(golden, name, port):
+@pytest.mark.parametrize("name,port,defer", [("train_w2_mean", 29811, False), ("train_w2_freq1", 29812, False),
+                                             ("train_w2_max", 29813, False), ("train_w2_mean", 29814, True)])
+def test_two_rank_training_matches_reference(golden, name, port, defer):
+    """defer: the top / bottom MLP gradients travel as two exchanges (TrainEngine(defer_top_update=True))."""
     from oracle import cdlrm_oracle as O
     g = golden(name)
     np.random.seed(int(g["seed"]))
     host = [h.share_memory_() for h in O.init_host_tables([int(x) for x in g["ln_emb"]], int(g["m_spa"]))]
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret, defer)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}

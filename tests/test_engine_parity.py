@@ -165,3 +165,95 @@ def test_dropin_autograd_surface_matches_engine(golden):
     np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-5)
     for k in range(len(g["ln_emb"])):
         assert torch.equal(cg.occupancy_tables[k].cpu(), t(g[f"occ_{k}"]))
+
+
+@pytest.mark.parametrize("name,pipelined", [("train_c1", True), ("train_small", False), ("train_stream", True)])
+def test_deferred_top_update_same_trajectory(golden, name, pipelined):
+    """defer_top_update: the top MLP's weight gradients + SGD run on the side stream beside the rest of the backward
+    and the head of the next step.  A schedule change only: the reference's loss trajectory and final weights."""
+    g = golden(name)
+    from cdlrm_amd.engine import TrainEngine
+    host, cg, dl, eng0, pipe = build(g)
+    eng = TrainEngine(cg, dl, host, lr=eng0.lr, lr_embeds=eng0.lr_embeds, table_agg_freq=eng0.agg_freq,
+                      table_agg_op=eng0.agg_op, defer_top_update=True)
+    L = int(g["L"])
+    batches = make_batches(g)
+    dev_idx = [b[1].to(DEV) for b in batches]
+    losses = []
+    for j, (X, lS_i, Tt) in enumerate(batches):
+        if j % L == 0:
+            win = torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV)
+            if "reseed" not in g.files or bool(g["reseed"]):
+                torch.manual_seed(5000 + j)
+            pipe.plan_window(win)
+            pipe.commit()
+            pipe.wait_writeback()
+        nxt = dev_idx[j + 1] if pipelined and j + 1 < len(batches) and (j + 1) % L != 0 else None
+        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt)
+        losses.append(loss[0:1].clone())
+    eng.finish()
+    np.testing.assert_allclose(np.array([float(x) for x in losses]), g["losses"], rtol=1e-5)
+    for k in range(len(g["ln_emb"])):
+        assert torch.equal(cg.occupancy_tables[k].cpu(), t(g[f"occ_{k}"])), k
+    from cdlrm_amd.model_no_ddp import _linears
+    for i, l in enumerate(_linears(dl.top_l)):
+        np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("op,loss,ws,thr,defer", [("cat", "bce", None, 0.0, False), ("dot", "mse", None, 0.0, True),
+                                                  ("dot", "wbce", (0.4, 2.5), 0.0, False),
+                                                  ("cat", "wbce", (1.5, 0.7), 0.45, True),
+                                                  ("dot", "bce", None, 0.48, False)])
+def test_engine_loss_and_interaction_arms_vs_oracle(op, loss, ws, thr, defer):
+    """--arch-interaction-op=cat, --loss-function=mse|wbce, --loss-threshold through the fused engine: loss per
+    iteration, prediction and tag state against the oracle's trainer (itself pinned on the reference's DLRM_Net +
+    loss_fn_wrap by tests/golden/dense_*.npz)."""
+    from cdlrm_amd.engine import TrainEngine, WindowPipeline
+    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group
+    from oracle import cdlrm_oracle as O
+    ln_emb, m_spa, B, L, ways, cache_size, seed = [3000, 50, 7, 1200], 16, 48, 3, 4, 40, 17
+    ln_bot = np.array([13, 32, m_spa])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([(m_spa + nf * (nf - 1) // 2) if op == "dot" else nf * m_spa, 24, 1])
+    rng = np.random.RandomState(3)
+    batches = []
+    for j in range(9):
+        X = torch.from_numpy(rng.rand(B, 13).astype(np.float32))
+        idx = torch.stack([torch.from_numpy((rng.zipf(1.2, size=B).astype(np.int64) * 2654435761 % n)) for n in ln_emb])
+        Tt = torch.from_numpy(np.round(rng.rand(B, 1)).astype(np.float32))
+        batches.append((X, idx, Tt))
+    torch.set_num_threads(1)
+    otr = O.OracleTrainer(ln_emb, m_spa, ln_bot, ln_top, cache_size=cache_size, num_ways=ways, mini_batch_size=B,
+                          lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=10 ** 9, seed=seed, loss=loss, op=op,
+                          loss_weights=ws, loss_threshold=thr)
+    lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+    for j, (X, idx, Tt) in enumerate(batches):
+        if j % L == 0:
+            torch.manual_seed(700 + j)
+            otr.refill(torch.cat([b[1] for b in batches[j:j + L]], dim=1))
+        otr.step(j, X, lS_o, idx, Tt)
+    Zo = otr.evaluate(batches[-1][0], lS_o, batches[-1][1])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host = Embedding_Table_Group(m_spa, np.array(ln_emb)).pin()
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    cg = Embedding_Table_Cache_Group(m_spa, np.array(ln_emb), cache_size, B, ways).to(DEV)
+    dl = DLRM_Net(ln_bot, ln_top, op, False, True, -1, ln_top.size - 2, thr).to(DEV)
+    eng = TrainEngine(cg, dl, host, lr=0.1, lr_embeds=0.3, loss=loss, loss_weights=ws or (1.0, 1.0),
+                      defer_top_update=defer)
+    pipe = WindowPipeline(cg, host, L * B, parity_rng=True)
+    losses = []
+    for j, (X, idx, Tt) in enumerate(batches):
+        if j % L == 0:
+            torch.manual_seed(700 + j)
+            pipe.plan_window(torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV))
+            pipe.commit()
+            pipe.wait_writeback()
+        losses.append(float(eng.step(X.to(DEV), idx.to(DEV), Tt.to(DEV), j=j)[0]))
+    Zg = eng.evaluate(batches[-1][0].to(DEV), batches[-1][1].to(DEV))
+    cg.ctx.check()
+    np.testing.assert_allclose(np.array(losses), np.array([l[0] for l in otr.losses]), rtol=1e-5)
+    np.testing.assert_allclose(Zg.cpu().numpy(), Zo.numpy(), rtol=1e-5, atol=1e-6)
+    for k in range(len(ln_emb)):
+        assert torch.equal(cg.occupancy_tables[k].cpu(), otr.occ[k]), k

@@ -568,3 +568,144 @@ def test_sgd_and_agg(ops):
     want = before.clone()
     want[rows.to(DEV)] = before[rows.to(DEV)] / 2.0
     assert torch.equal(st.weight, want)
+
+
+DENSE_VARIANTS = ["cat_bce", "dot_mse", "dot_wbce", "dot_bce_thr", "cat_wbce_thr"]
+
+
+@pytest.mark.parametrize("name", DENSE_VARIANTS)
+def test_dense_variants_golden(ops, golden, name):
+    """The non-default arms of the dense path against the reference's DLRM_Net + loss_fn_wrap: "cat" interaction,
+    MSE / weighted BCE, --loss-threshold -- through the fused output head (last layer + loss + its input gradient)."""
+    g = golden("dense_" + name)
+    op, kind, thr = str(g["op"]), ops.LOSS[str(g["loss_kind"])], float(g["loss_threshold"])
+    ws = [float(x) for x in g["loss_weights"]]
+    nb, nt = len(g["ln_bot"]) - 1, len(g["ln_top"]) - 1
+    X, Tt = t(g["X"]).to(DEV), t(g["T"]).to(DEV)
+    B, F = X.shape[0], 6
+    ly = [t(g[f"ly_{k}"]) for k in range(5)]
+    D = ly[0].shape[1]
+    feat = torch.zeros(B, F, D, device=DEV)
+    for k in range(5):
+        feat[:, k + 1] = ly[k].to(DEV)
+    Wb = [t(g[f"bot_w{i}"]).to(DEV) for i in range(nb)]
+    bb = [t(g[f"bot_b{i}"]).to(DEV) for i in range(nb)]
+    Wt = [t(g[f"top_w{i}"]).to(DEV) for i in range(nt)]
+    bt = [t(g[f"top_b{i}"]).to(DEV) for i in range(nt)]
+    bot = [X]
+    for i in range(nb):
+        y = feat[:, 0, :] if i == nb - 1 else torch.empty(B, Wb[i].shape[0], device=DEV)
+        ops.linear_fwd(bot[-1], Wb[i], bb[i], y, 1)
+        bot.append(y)
+    if op == "dot":
+        R = torch.empty(B, D + F * (F - 1) // 2, device=DEV)
+        ops.interact_fwd(feat, False, R)
+    else:
+        R = feat.view(B, F * D)
+    top = [R]
+    for i in range(nt - 1):
+        y = torch.empty(B, Wt[i].shape[0], device=DEV)
+        ops.linear_fwd(top[-1], Wt[i], bt[i], y, 1)
+        top.append(y)
+    Z, Zc, dZ = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV)
+    dY = torch.empty_like(top[-1])
+    lossbuf = torch.zeros(65, device=DEV)
+    scratch = ops.head_scratch(DEV)
+    for _ in range(2):      # twice: the arrival counter in scratch must be left at zero
+        ops.head_fwd_bwd(top[-1], Wt[-1], bt[-1], Tt, Z, dZ, dY, lossbuf, scratch, x_act=1, kind=kind, weights=ws,
+                         threshold=thr, Zc=Zc)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Zc.cpu().numpy(), g["Z"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(lossbuf[0]), float(g["loss"]), rtol=2e-6)
+    # the same numbers from the stand-alone loss kernel on the head's Z
+    lb2, dZ2, Zc2 = torch.zeros(65, device=DEV), torch.empty_like(dZ), torch.empty_like(Z)
+    ops.loss_fwd_bwd(Z, Tt, lb2, dZ2, kind=kind, weights=ws, threshold=thr, Zc=Zc2, sigmoid_bwd=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(lb2[0]), float(g["loss"]), rtol=2e-6)
+    np.testing.assert_allclose(dZ2.cpu().numpy(), dZ.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    assert torch.equal(Zc2, Zc)
+    # backward: weight / bias gradients of every layer from the pre-activation gradients, feature gradients
+    dzs_top = [None] * nt
+    dzs_top[-1] = dZ
+    cur = dY
+    for i in reversed(range(nt - 1)):
+        dzs_top[i] = cur
+        dX = torch.empty(B, Wt[i].shape[1], device=DEV)
+        work = ops.linear_bwd_work(B, Wt[i].shape[0], Wt[i].shape[1], DEV)
+        ops.linear_bwd(top[i], Wt[i], top[i + 1], cur, dX, None, None, 0, work, x_act=(1 if i > 0 else 0))
+        cur = dX
+    dR = cur
+    dfeat = torch.empty_like(feat)
+    if op == "dot":
+        ops.interact_bwd(feat, dR, False, dfeat, x_act=1)
+    else:
+        dfeat.copy_(dR.view(B, F, D))
+        ops.act_bwd(dfeat[:, 0, :], feat[:, 0, :], 1)
+    dzs_bot = [None] * nb
+    cur = dfeat[:, 0, :]
+    for i in reversed(range(nb)):
+        dzs_bot[i] = cur
+        if i > 0:
+            dX = torch.empty(B, Wb[i].shape[1], device=DEV)
+            work = ops.linear_bwd_work(B, Wb[i].shape[0], Wb[i].shape[1], DEV)
+            ops.linear_bwd(bot[i], Wb[i], bot[i + 1], cur, dX, None, None, 0, work, x_act=1)
+            cur = dX
+    torch.cuda.synchronize()
+    for k in range(5):
+        np.testing.assert_allclose(dfeat[:, k + 1].cpu().numpy(), g[f"ly_grad_{k}"], rtol=2e-4, atol=1e-8)
+    for pre, acts, dzs, n in (("top", top, dzs_top, nt), ("bot", bot, dzs_bot, nb)):
+        for i in range(n):
+            dW = (dzs[i].t() @ acts[i]).cpu().numpy()       # plumbing check of the dZ buffers (wgrad kernels: own tests)
+            np.testing.assert_allclose(dW, g[f"{pre}_gw{i}"], rtol=3e-4, atol=1e-7)
+            np.testing.assert_allclose(dzs[i].sum(0).cpu().numpy(), g[f"{pre}_gb{i}"], rtol=3e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 777, 40000])
+@pytest.mark.parametrize("kind,thr", [("bce", 0.0), ("mse", 0.0), ("wbce", 0.0), ("bce", 0.3), ("wbce", 0.2), ("mse", 0.1)])
+def test_loss_kernel_vs_oracle(ops, n, kind, thr):
+    rng = np.random.RandomState(n + len(kind))
+    z = torch.from_numpy(rng.rand(n, 1).astype(np.float32))
+    z[0, 0] = 1e-9 if n > 0 else z[0, 0]            # log clamp at -100 / denominator floor
+    tt = torch.from_numpy(np.round(rng.rand(n, 1)).astype(np.float32))
+    ws = torch.tensor([0.3, 1.7], dtype=torch.float64)
+    zr = z.clone().requires_grad_(True)
+    zc = torch.clamp(zr, min=thr, max=1 - thr) if thr > 0 else zr
+    E = O.loss_fn(zc, tt, kind, ws)
+    E.backward()
+    lb, dZ, Zc = torch.zeros(65, device=DEV), torch.empty(n, 1, device=DEV), torch.empty(n, 1, device=DEV)
+    ops.loss_fwd_bwd(z.to(DEV), tt.to(DEV), lb, dZ, kind=ops.LOSS[kind], weights=(0.3, 1.7), threshold=thr, Zc=Zc)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(lb[0]), float(E), rtol=2e-5)
+    np.testing.assert_allclose(dZ.cpu().numpy(), zr.grad.numpy(), rtol=2e-5, atol=1e-12)
+    assert torch.equal(Zc.cpu(), zc.detach())
+
+
+@pytest.mark.parametrize("B,K,x_act", [(1, 8, 0), (1030, 256, 1), (8192, 256, 1), (333, 479, 2), (64, 5, 1)])
+def test_head_vs_torch_fp32(ops, B, K, x_act):
+    """Fused head against plain torch fp32: sigmoid(Y w + b), BCE, dZ and dY."""
+    g = torch.Generator().manual_seed(B + K)
+    Y = torch.rand(B, K, generator=g) - (0.3 if x_act == 1 else 0.0)
+    if x_act == 1:
+        Y = torch.relu(Y)
+    w, b = torch.randn(1, K, generator=g) * 0.2, torch.randn(1, generator=g)
+    tt = torch.round(torch.rand(B, 1, generator=g))
+    Yr = Y.clone().requires_grad_(True)
+    pre = torch.nn.functional.linear(Yr, w, b)
+    Zr = torch.sigmoid(pre)
+    E = torch.nn.functional.binary_cross_entropy(Zr, tt)
+    pre.retain_grad()
+    E.backward()
+    mask = (Y > 0).float() if x_act == 1 else ((1 - Y) * Y if x_act == 2 else torch.ones_like(Y))
+    Z, dZ = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV)
+    pitch = (K + 3) // 4 * 4
+    Yd = torch.zeros(B, pitch, device=DEV)
+    Yd[:, :K] = Y.to(DEV)
+    dYd = torch.zeros(B, pitch, device=DEV)
+    lb, scratch = torch.zeros(65, device=DEV), ops.head_scratch(DEV)
+    ops.head_fwd_bwd(Yd[:, :K], w.to(DEV), b.to(DEV), tt.to(DEV), Z, dZ, dYd[:, :K], lb, scratch, x_act=x_act)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Z.cpu().numpy(), Zr.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(lb[0]), float(E), rtol=1e-5)
+    np.testing.assert_allclose(dZ.cpu().numpy(), pre.grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(dYd[:, :K].cpu().numpy(), (Yr.grad * mask).numpy(), rtol=1e-4, atol=1e-9)
+    assert float(scratch[0]) == 0.0

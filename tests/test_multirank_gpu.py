@@ -14,18 +14,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, host_shared, ret):
+def _worker(rank, world, port, name, host_shared, ret, defer=False):
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)        # a stuck worker says where, instead of a silent time-out
     try:
-        _worker_body(rank, world, port, name, host_shared, ret)
+        _worker_body(rank, world, port, name, host_shared, ret, defer)
     except BaseException as e:      # a dead worker must fail the test, not hang it
         import traceback
         ret.put((rank, {"error": traceback.format_exc()}))
         raise
 
 
-def _worker_body(rank, world, port, name, host_shared, ret):
+def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -51,7 +51,7 @@ def _worker_body(rank, world, port, name, host_shared, ret):
     cg = M.Embedding_Table_Cache_Group(m_spa, ln_emb, int(g["cache_size"]), B, int(g["ways"])).to(dev)
     dl = M.DLRM_Net(np.array(g["ln_bot"]), ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
     eng = engine.TrainEngine(cg, dl, eg, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), world_size=world, rank=rank,
-                             table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]))
+                             table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]), defer_top_update=defer)
     pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
     lbs = B // world
     losses = []
@@ -73,6 +73,7 @@ def _worker_body(rank, world, port, name, host_shared, ret):
             nxt = dev_idx[j + 1]
         loss = eng.step(X[sl].to(dev), dev_idx[j], Tt[sl].to(dev), j=j, next_idx=nxt)
         losses.append(float(loss[0]))
+    eng.finish()
     cg.ctx.check()
     lin = M._linears(dl.top_l)
     ret.put((rank, dict(losses=np.array(losses), occ=[o.cpu().numpy() for o in cg.occupancy_tables],
@@ -81,15 +82,16 @@ def _worker_body(rank, world, port, name, host_shared, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,port", [("train_w2_mean", 29821), ("train_w2_max", 29822)])
-def test_two_ranks_one_gpu_match_reference(golden, name, port):
+@pytest.mark.parametrize("name,port,defer", [("train_w2_mean", 29821, False), ("train_w2_max", 29822, False),
+                                             ("train_w2_mean", 29823, True)])
+def test_two_ranks_one_gpu_match_reference(golden, name, port, defer):
     from oracle import cdlrm_oracle as O
     g = golden(name)
     np.random.seed(int(g["seed"]))
     host = [h.share_memory_() for h in O.init_host_tables([int(x) for x in g["ln_emb"]], int(g["m_spa"]))]
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret, defer)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
