@@ -16,6 +16,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef GBK
 #define GBK 32
@@ -363,6 +364,51 @@ __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&
     }
 }
 
+// The 4 partial tiles of a workgroup meet in LDS and are summed in wave order (fixed order: reproducible), then bias /
+// activation / mask and a row-contiguous store; the bias-gradient column sums likewise.
+template <bool A_KC>
+__device__ __forceinline__ void direct_finish(const GemmArgs& g, unsigned bx, unsigned bz, int64_t m0, int64_t n0, int wave,
+                                              int lr, int lk, const f32x16& acc, float cs, float (*red)[32][33],
+                                              float (*csr)[32]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[r];
+    if (!A_KC && g.colsum != nullptr && bx == 0) {
+        cs += __shfl_xor(cs, 32);
+        if (lk == 0) csr[wave][lr] = cs;
+    }
+    __syncthreads();
+    if (!A_KC && g.colsum != nullptr && bx == 0 && threadIdx.x < 32 && m0 + threadIdx.x < g.M)
+        g.colsum[(int64_t)bz * g.M + m0 + threadIdx.x] =
+            ((csr[0][threadIdx.x] + csr[1][threadIdx.x]) + csr[2][threadIdx.x]) + csr[3][threadIdx.x];
+    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const int64_t gm = m0 + row;
+    if (gm >= g.M) return;
+    float* C = g.C + (int64_t)bz * g.slab + gm * g.ldc;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t gn = n0 + c4 + u;
+        float x = ((red[0][row][c4 + u] + red[1][row][c4 + u]) + red[2][row][c4 + u]) + red[3][row][c4 + u];
+        if (gn < g.N) {
+            if (g.bias) x += g.bias[gn];
+            if (g.act == 1) x = x > 0.f ? x : 0.f;
+            else if (g.act == 2) x = 1.0f / (1.0f + expf(-x));
+            if (g.mask_act) {
+                const float y = g.mask[gm * g.ldmask + gn];
+                x = g.mask_act == 1 ? (y > 0.f ? x : 0.f) : x * ((1.0f - y) * y);
+            }
+        }
+        v[u] = x;
+    }
+    if (g.vecC && n0 + c4 + 3 < g.N) {
+        *reinterpret_cast<float4*>(C + n0 + c4) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (n0 + c4 + u < g.N) C[n0 + c4 + u] = v[u];
+    }
+}
+
 // MODE 0: each wave's share of the contraction is <= 64 (one batch of loads, no loop); 1: <= 128 (two batches, no
 // loop); 2: longer (two batches in flight around a loop, the last <= 128 indices peeled so that no batch is fetched
 // past the end: at K = 512 that trailing prefetch was a third of all the loads)
@@ -439,43 +485,7 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsi
     }
 #undef DIRECT_LOAD_A
 #undef DIRECT_LOAD_B
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[r];
-    if (!A_KC && g.colsum != nullptr && bx == 0) {
-        cs += __shfl_xor(cs, 32);
-        if (lk == 0) csr[wave][lr] = cs;
-    }
-    __syncthreads();
-    if (!A_KC && g.colsum != nullptr && bx == 0 && threadIdx.x < 32 && m0 + threadIdx.x < g.M)
-        g.colsum[(int64_t)bz * g.M + m0 + threadIdx.x] =
-            ((csr[0][threadIdx.x] + csr[1][threadIdx.x]) + csr[2][threadIdx.x]) + csr[3][threadIdx.x];
-    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
-    const int64_t gm = m0 + row;
-    if (gm >= g.M) return;
-    float* C = g.C + (int64_t)bz * g.slab + gm * g.ldc;
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t gn = n0 + c4 + u;
-        float x = ((red[0][row][c4 + u] + red[1][row][c4 + u]) + red[2][row][c4 + u]) + red[3][row][c4 + u];
-        if (gn < g.N) {
-            if (g.bias) x += g.bias[gn];
-            if (g.act == 1) x = x > 0.f ? x : 0.f;
-            else if (g.act == 2) x = 1.0f / (1.0f + expf(-x));
-            if (g.mask_act) {
-                const float y = g.mask[gm * g.ldmask + gn];
-                x = g.mask_act == 1 ? (y > 0.f ? x : 0.f) : x * ((1.0f - y) * y);
-            }
-        }
-        v[u] = x;
-    }
-    if (g.vecC && n0 + c4 + 3 < g.N) {
-        *reinterpret_cast<float4*>(C + n0 + c4) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (n0 + c4 + u < g.N) C[n0 + c4 + u] = v[u];
-    }
+    direct_finish<A_KC>(g, bx, bz, m0, n0, wave, lr, lk, acc, cs, red, csr);
 }
 
 template <bool A_KC, bool B_KC, bool VA, bool VB, int MODE, bool AL>
@@ -501,6 +511,178 @@ __global__ void __launch_bounds__(256) k_gemm_direct_group(GemmGroup grp) {
     const unsigned local = wgid - grp.first[p];
     const unsigned gx = (unsigned)((g.N + 31) / 32), gy = (unsigned)((g.M + 31) / 32);
     direct_body<A_KC, B_KC, VA, VB, MODE, AL>(g, local % gx, (local / gx) % gy, local / (gx * gy), red, csr);
+}
+
+// ---- small problems, staged: coalesced loads + a wave-private LDS transpose -------------------------------------
+// The LDS-free kernel reads a contraction-contiguous operand with lane = row: every 16-byte load instruction touches
+// 32 different 128-B lines, and the vector memory pipeline (address coalescer / L1 tag look-ups) -- not L2, not the
+// MFMAs -- bounds it (1024x512x512: 12.9 us with 3.4 us of MFMA work).  Here each wave fetches its 32 x 64 (rows x
+// contraction) sub-panels with fully coalesced 16-byte loads (a 256-B run of a row per 16 lanes), parks them in a
+// wave-PRIVATE LDS region and reads them back in the MFMA operand layout.  No workgroup barrier: the LDS pipeline
+// executes a wave's accesses in order, and the regions of the four waves are disjoint.  Same cut as the LDS-free
+// kernel otherwise (32x32 tile per workgroup, 4 waves split the contraction, partial tiles summed in wave order).
+// Requires the aligned conditions (K % 32 == 0, split boundaries on multiples of 32), K >= 64, 16-byte-loadable
+// operands, and non-contraction extents % 4 == 0 for contraction-strided operands.
+#define ST_KC_PITCH 68      // floats; 17 * 16 B: ds_write_b128 / ds_read_b128 conflict-free
+#define ST_KS_PITCH 36      // contraction-strided operand kept as [k][32 + 4]
+#define ST_OP_FLOATS 2304   // per operand per wave: max(32 * 68, 64 * 36)
+#define ST_LDS_BYTES (4 * 2 * ST_OP_FLOATS * 4)
+
+// global -> registers: 8 float4 per lane cover a 32 x 64 (KC) or 64 x 32 (contraction-strided) sub-panel
+template <bool KC>
+__device__ __forceinline__ void st_load(const float* __restrict__ base, int64_t ld, const unsigned (&voff)[8], int64_t ks,
+                                        f32x4 (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (KC) {       // lane: row (lane >> 4) + 4 i, contraction offset (lane & 15) * 4
+            const char* sb = reinterpret_cast<const char*>(base + ks);
+            v[i] = *reinterpret_cast<const f32x4*>(sb + voff[i]);
+        } else {        // lane: contraction row (lane >> 3) + 8 i, 4 consecutive non-contraction elements
+            const char* sb = reinterpret_cast<const char*>(base + (ks + 8 * i) * ld);
+            v[i] = *reinterpret_cast<const f32x4*>(sb + voff[0]);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void st_park(float* __restrict__ S, int lane, const f32x4 (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (KC) *reinterpret_cast<f32x4*>(S + ((lane >> 4) + 4 * i) * ST_KC_PITCH + (lane & 15) * 4) = v[i];
+        else *reinterpret_cast<f32x4*>(S + ((lane >> 3) + 8 * i) * ST_KS_PITCH + (lane & 7) * 4) = v[i];
+    }
+}
+
+// fragment of contraction group gq (8 indices; lane half lk owns 4 consecutive ones); shift: the panel in LDS starts
+// `shift` indices before this batch (a batch that would straddle the end of K is fetched from K - 64)
+template <bool KC>
+__device__ __forceinline__ f32x4 st_frag(const float* __restrict__ S, int lr, int lk, int gq, int shift) {
+    const int j0 = (8 * gq + 4 * lk + shift) & 63;
+    if (KC) return *reinterpret_cast<const f32x4*>(S + lr * ST_KC_PITCH + j0);
+    const float* q = S + j0 * ST_KS_PITCH + lr;
+    f32x4 r;
+    r.x = q[0]; r.y = q[ST_KS_PITCH]; r.z = q[2 * ST_KS_PITCH]; r.w = q[3 * ST_KS_PITCH];
+    return r;
+}
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void st_batch(const float* __restrict__ Sa, const float* __restrict__ Sb, int lr, int lk,
+                                         int shift, int64_t k, int64_t kw1, f32x16& acc, float& cs) {
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+        const f32x4 a = st_frag<A_KC>(Sa, lr, lk, gq, shift);
+        const f32x4 b = st_frag<B_KC>(Sb, lr, lk, gq, shift);
+        const int64_t kk = k + 8 * gq + 4 * lk;
+        // zeroing ONE operand past the end of this wave's contraction range is enough
+        const float ax = kk + 0 < kw1 ? a.x : 0.f, ay = kk + 1 < kw1 ? a.y : 0.f;
+        const float az = kk + 2 < kw1 ? a.z : 0.f, aw = kk + 3 < kw1 ? a.w : 0.f;
+        cs += (ax + ay) + (az + aw);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(az, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, b.w, acc, 0, 0, 0);
+    }
+}
+
+template <bool A_KC, bool B_KC, int MODE>
+__device__ __forceinline__ void staged_body(const GemmArgs& g, unsigned bx, unsigned by, unsigned bz, float* __restrict__ lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 31, lk = lane >> 5;
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const int64_t kbeg = (int64_t)bz * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+    const int64_t kq = ((kend - kbeg + 127) / 128) * 32;
+    const int64_t kw0 = kbeg + wave * kq, kw1 = min(kend, kw0 + kq);
+    float* Sa = lds + wave * (2 * ST_OP_FLOATS);
+    float* Sb = Sa + ST_OP_FLOATS;
+    // per-lane byte offsets of the coalesced loads (rows / columns past the edge are clamped to valid ones: their
+    // products land in output rows / columns that are never stored)
+    unsigned va[8], vb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (A_KC) va[i] = (unsigned)((min(m0 + (lane >> 4) + 4 * i, g.M - 1) * g.lda + (lane & 15) * 4) * 4);
+        else va[i] = (unsigned)(((lane >> 3) * g.lda + min(m0 + (lane & 7) * 4, g.M - 4)) * 4);
+        if (B_KC) vb[i] = (unsigned)((min(n0 + (lane >> 4) + 4 * i, (int64_t)g.N - 1) * g.ldb + (lane & 15) * 4) * 4);
+        else vb[i] = (unsigned)(((lane >> 3) * g.ldb + min(n0 + (lane & 7) * 4, (int64_t)g.N - 4)) * 4);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float cs = 0.f;
+    f32x4 ra0[8], rb0[8], ra1[8], rb1[8];
+    // a batch is fetched from ks = min(k, K - 64): `shift` = k - ks (0 or 32 inside the range) relocates the fragments
+    const int64_t klast = g.K - 64;
+#define ST_KS(k_) min((int64_t)(k_), klast)
+#define ST_SHIFT(k_) ((int)min((int64_t)(k_) - ST_KS(k_), (int64_t)32))
+    st_load<A_KC>(g.A, g.lda, va, ST_KS(kw0), ra0);
+    st_load<B_KC>(g.B, g.ldb, vb, ST_KS(kw0), rb0);
+    if (MODE >= 1) {
+        st_load<A_KC>(g.A, g.lda, va, ST_KS(kw0 + 64), ra1);
+        st_load<B_KC>(g.B, g.ldb, vb, ST_KS(kw0 + 64), rb1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int64_t k = kw0;
+    if (MODE == 2) {
+        // two batches in flight around the loop; the last <= 128 indices are peeled so that nothing is fetched past the end
+        for (; k + 128 < kw1; k += 128) {
+            st_park<A_KC>(Sa, lane, ra0);
+            st_park<B_KC>(Sb, lane, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            st_load<A_KC>(g.A, g.lda, va, ST_KS(k + 128), ra0);      // into the registers just parked
+            st_load<B_KC>(g.B, g.ldb, vb, ST_KS(k + 128), rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            st_batch<A_KC, B_KC>(Sa, Sb, lr, lk, ST_SHIFT(k), k, kw1, acc, cs);
+            __builtin_amdgcn_sched_barrier(0);
+            st_park<A_KC>(Sa, lane, ra1);
+            st_park<B_KC>(Sb, lane, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            st_load<A_KC>(g.A, g.lda, va, ST_KS(k + 192), ra1);
+            st_load<B_KC>(g.B, g.ldb, vb, ST_KS(k + 192), rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            st_batch<A_KC, B_KC>(Sa, Sb, lr, lk, ST_SHIFT(k + 64), k + 64, kw1, acc, cs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    st_park<A_KC>(Sa, lane, ra0);
+    st_park<B_KC>(Sb, lane, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    st_batch<A_KC, B_KC>(Sa, Sb, lr, lk, ST_SHIFT(k), k, kw1, acc, cs);
+    if (MODE >= 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        st_park<A_KC>(Sa, lane, ra1);
+        st_park<B_KC>(Sb, lane, rb1);
+        __builtin_amdgcn_sched_barrier(0);
+        st_batch<A_KC, B_KC>(Sa, Sb, lr, lk, ST_SHIFT(k + 64), k + 64, kw1, acc, cs);
+    }
+#undef ST_KS
+#undef ST_SHIFT
+    __syncthreads();        // every wave is done with its staging region: the reduction buffers alias it
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(lds);
+    float (*csr)[32] = reinterpret_cast<float (*)[32]>(lds + 4 * 32 * 33);
+    direct_finish<A_KC>(g, bx, bz, m0, n0, wave, lr, lk, acc, cs, red, csr);
+}
+
+template <bool A_KC, bool B_KC, int MODE>
+__global__ void __launch_bounds__(256) k_gemm_staged(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nwg);
+    staged_body<A_KC, B_KC, MODE>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y, wgid / (gridDim.x * gridDim.y), st_lds);
+}
+
+template <bool A_KC, bool B_KC, int MODE>
+__global__ void __launch_bounds__(256) k_gemm_staged_group(GemmGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+        if (q < grp.n && wgid >= grp.first[q]) p = q;
+    const GemmArgs& g = grp.g[p];
+    const unsigned local = wgid - grp.first[p];
+    const unsigned gx = (unsigned)((g.N + 31) / 32), gy = (unsigned)((g.M + 31) / 32);
+    staged_body<A_KC, B_KC, MODE>(g, local % gx, (local / gx) % gy, local / (gx * gy), st_lds);
 }
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -565,6 +747,42 @@ static inline bool direct_aligned(const GemmArgs& g, int64_t klen) {
     return true;
 }
 
+// the staged kernel applies: the aligned conditions, K >= 64, and 16-byte loads along the contiguous direction of
+// contraction-strided operands (extent and pitch multiples of 4)
+template <bool A_KC, bool B_KC>
+static inline bool direct_staged(const GemmArgs& g, int64_t klen) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("CDLRM_GEMM_STAGED");
+        off = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    if (off || !direct_aligned<A_KC, B_KC>(g, klen) || g.K < 64) return false;
+    if (!A_KC && (g.M % 4 != 0 || g.lda % 4 != 0 || !aligned16(g.A))) return false;
+    if (!B_KC && (g.N % 4 != 0 || g.ldb % 4 != 0 || !aligned16(g.B))) return false;
+    const int64_t lim = (int64_t)1 << 30;
+    if ((A_KC ? g.M * g.lda : 8 * g.lda + g.M) >= lim || (B_KC ? (int64_t)g.N * g.ldb : 8 * g.ldb + g.N) >= lim) return false;
+    return true;
+}
+
+template <typename KERN>
+static inline void staged_lds_attr(KERN kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
+}
+
+template <bool A_KC, bool B_KC>
+static void launch_gemm_staged(const GemmArgs& g, dim3 grid, int mode, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        staged_lds_attr(k_gemm_staged<A_KC, B_KC, 0>);
+        staged_lds_attr(k_gemm_staged<A_KC, B_KC, 1>);
+        staged_lds_attr(k_gemm_staged<A_KC, B_KC, 2>);
+        attr = true;
+    }
+    if (mode == 2) hipLaunchKernelGGL((k_gemm_staged<A_KC, B_KC, 2>), grid, dim3(256), ST_LDS_BYTES, s, g);
+    else if (mode == 1) hipLaunchKernelGGL((k_gemm_staged<A_KC, B_KC, 1>), grid, dim3(256), ST_LDS_BYTES, s, g);
+    else hipLaunchKernelGGL((k_gemm_staged<A_KC, B_KC, 0>), grid, dim3(256), ST_LDS_BYTES, s, g);
+}
+
 template <bool A_KC, bool B_KC>
 static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
     g.vecC = aligned16(g.C) && g.ldc % 4 == 0 && g.slab % 4 == 0;
@@ -573,6 +791,10 @@ static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
     const int64_t klen = g.kchunk < g.K ? g.kchunk : g.K;
     const bool al = direct_aligned<A_KC, B_KC>(g, klen);
     const int mode = direct_mode(klen, al);
+    if (direct_staged<A_KC, B_KC>(g, klen)) {
+        launch_gemm_staged<A_KC, B_KC>(g, grid, mode, s);
+        return;
+    }
     if (al) {
         if (mode == 2) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, A_KC, B_KC, 2, true>), grid, dim3(256), 0, s, g);
         else if (mode == 1) hipLaunchKernelGGL((k_gemm_direct<A_KC, B_KC, A_KC, B_KC, 1, true>), grid, dim3(256), 0, s, g);
@@ -594,9 +816,17 @@ static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
 
 // up to GEMM_GROUP_MAX un-split problems of the weight-gradient layout (both operands contraction-strided) per launch
 static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s) {
-    for (int want = 0; want < 6; ++want) {
+    static bool st_attr = false;
+    if (!st_attr) {
+        staged_lds_attr(k_gemm_staged_group<false, false, 0>);
+        staged_lds_attr(k_gemm_staged_group<false, false, 1>);
+        staged_lds_attr(k_gemm_staged_group<false, false, 2>);
+        st_attr = true;
+    }
+    for (int want = 0; want < 9; ++want) {
         const int want_mode = want % 3;
         const bool want_al = want >= 3;
+        const bool want_st = want >= 6;
         GemmGroup grp;
         memset(&grp, 0, sizeof(grp));
         unsigned blocks = 0;
@@ -605,7 +835,14 @@ static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s
             grp.first[grp.n] = blocks;
 #define CDLRM_DGROUP(MODE_, AL_) \
     hipLaunchKernelGGL((k_gemm_direct_group<false, false, false, false, MODE_, AL_>), dim3(blocks), dim3(256), 0, s, grp)
-            if (want_al) {
+            if (want_st) {
+                if (want_mode == 2)
+                    hipLaunchKernelGGL((k_gemm_staged_group<false, false, 2>), dim3(blocks), dim3(256), ST_LDS_BYTES, s, grp);
+                else if (want_mode == 1)
+                    hipLaunchKernelGGL((k_gemm_staged_group<false, false, 1>), dim3(blocks), dim3(256), ST_LDS_BYTES, s, grp);
+                else
+                    hipLaunchKernelGGL((k_gemm_staged_group<false, false, 0>), dim3(blocks), dim3(256), ST_LDS_BYTES, s, grp);
+            } else if (want_al) {
                 if (want_mode == 2) CDLRM_DGROUP(2, true);
                 else if (want_mode == 1) CDLRM_DGROUP(1, true);
                 else CDLRM_DGROUP(0, true);
@@ -624,7 +861,8 @@ static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s
             GemmArgs pg = probs[i];
             pg.kchunk = kc;
             const bool al = direct_aligned<false, false>(pg, kc);
-            if (al != want_al || direct_mode(kc, al) != want_mode) continue;
+            const bool st = direct_staged<false, false>(pg, kc);
+            if (st != want_st || (!st && al != (want_al && !want_st)) || direct_mode(kc, al) != want_mode) continue;
             if (grp.n == GEMM_GROUP_MAX) flush();
             grp.first[grp.n] = blocks;
             grp.g[grp.n] = probs[i];
