@@ -35,14 +35,21 @@ class WindowPipeline:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, host_tables: Embedding_Table_Group, max_window: int,
                  *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
                  world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None,
-                 victim_rows: Optional[int] = None, host_gather: bool = False, gather_threads: int = 16):
+                 victim_rows: Optional[int] = None, host_gather: bool = False, gather_threads: int = 16,
+                 shard_fetch: Optional[bool] = None, process_group=None):
         """victim_rows: capacity (rows) of each of the two HBM buffers that hold the host rows of a window's
         non-cached indices (None: every unique index of a window, at most 8 GiB per buffer; 0: off -- every miss
         reads the host table over PCIe as the reference does).
         host_gather: move the plan's bulk rows (winners, victims) the way the reference's Prefetcher does -- CPU threads
         gather them from the host tables into pinned staging, ONE DMA copy brings them to HBM -- from a background
         thread, instead of GPU waves reading host memory (which slows every kernel beside them ~2x while they run;
-        a DMA copy costs the training ~2 %).  Not with parity_rng (that path draws its random numbers in-line)."""
+        a DMA copy costs the training ~2 %).  Not with parity_rng (that path draws its random numbers in-line).
+        shard_fetch (host_gather plans at world_size > 1; default on): every rank's plan is the same list of rows, so
+        each rank fetches only its 1/world slice from the host tables (CPU gather + DMA over ITS PCIe link) and the
+        slices are exchanged over xGMI with one all-gather per list at the window boundary (commit(), main thread,
+        same point of the step sequence on every rank).  Host-DRAM and PCIe traffic per window drop from
+        world x (winners + victims) to 1 x; the reference instead broadcasts whole cache tables from rank 0
+        (main_no_ddp.py:318-319)."""
         self.cg, self.host = cache_group, host_tables
         self.ctx = cache_group.ctx
         self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
@@ -62,6 +69,11 @@ class WindowPipeline:
         self.last_offsets = None
         self.host_gather = bool(host_gather) and not parity_rng and S.is_hip(self.dev)
         self.gather_threads = int(gather_threads)
+        if shard_fetch is None:
+            shard_fetch = os.environ.get("CDLRM_SHARD_FETCH", "1") != "0"
+        self.shard = bool(shard_fetch) and self.host_gather and self.world > 1
+        self.pg = process_group
+        self._exchange = []          # (buffer, chunk rows) all-gathers commit() owes for the plan in flight
         self._worker = None          # background thread of a host-gather plan
         self._worker_err = None
         self._pin = {}               # pinned host staging, grown on demand
@@ -74,33 +86,65 @@ class WindowPipeline:
             self._pin[key] = t
         return t
 
+    def _shard_range(self, n, cap_rows):
+        """This rank's slice of a list of n rows that travels as `world` equal chunks: (chunk, lo, hi), or None when the
+        list is fetched whole (sharding off, empty list, or the padded length would not fit the buffer)."""
+        if not self.shard or n == 0:
+            return None
+        chunk = -(-n // self.world)
+        if chunk * self.world > cap_rows:
+            return None
+        lo = min(self.rank * chunk, n)
+        return chunk, lo, min(lo + chunk, n)
+
+    def _fetch_list(self, key, idx_dev, off, n, dst_dev, D):
+        """Rows of one plan list (n entries, `off` = per-table offsets into it) -> dst_dev[:n]: CPU-thread gather into
+        pinned staging + one DMA copy, of the whole list or of this rank's slice (the exchange is queued for commit())."""
+        side = self.side
+        sh = self._shard_range(n, dst_dev.shape[0])
+        chunk, lo, hi = sh if sh is not None else (0, 0, n)
+        m = hi - lo
+        idx_h = self._pinned(key + "_idx", (max(m, 1),), torch.int64)
+        idx_h[:m].copy_(idx_dev[lo:hi], non_blocking=True)
+        side.synchronize()
+        if m > 0:
+            rows_h = self._pinned(key + "_rows", (m, D), torch.float32)
+            off_r = [min(max(int(o), lo), hi) - lo for o in off]
+            ops.host_gather_rows(self.host_ptrs, idx_h, off_r, D, rows_h, self.gather_threads)
+            dst_dev[lo:hi].copy_(rows_h[:m], non_blocking=True)
+        if sh is not None:
+            self._exchange.append((dst_dev, chunk))
+
     def _plan_host_gather(self, window_idx, lists_ready):
         """Background half of a host-gather plan: wait for the winner / victim lists, copy them down, gather the rows on
         the CPU, issue the two DMA copies and the `planned` event on the plan stream."""
         try:
+            import time as _time
             torch.cuda.set_device(self.dev)
             plan, side, T, D = self.plan, self.side, self.ctx.T, self.ctx.D
             vic = self.victims[self._vnext] if self.victims is not None else None
+            t_0 = _time.perf_counter()
             lists_ready.synchronize()
+            t_lists = _time.perf_counter()
             _, _, wo = plan.offsets(stream=side)
             W = wo[T]
             with torch.cuda.stream(side):
-                win_h = self._pinned("win_idx", (max(W, 1),), torch.int64)
-                win_h[:W].copy_(plan.win_idx[:W], non_blocking=True)
+                t_g0 = _time.perf_counter()
+                self._fetch_list("win", plan.win_idx, wo, W, plan.stage, D)
+                t_g1 = _time.perf_counter()
+                V = 0
                 if vic is not None:
                     voff = vic.off.cpu().tolist()
                     V = min(voff[T], vic.cap)
                     voff = [min(o, V) for o in voff]
-                    vic_h = self._pinned("vic_idx", (max(V, 1),), torch.int64)
-                    vic_h[:V].copy_(vic.idx[:V], non_blocking=True)
-                side.synchronize()
-                stage_h = self._pinned("stage", (max(W, 1), D), torch.float32)
-                ops.host_gather_rows(self.host_ptrs, win_h, wo, D, stage_h, self.gather_threads)
-                plan.stage[:W].copy_(stage_h[:W], non_blocking=True)
-                if vic is not None:
-                    vrows_h = self._pinned("vic_rows", (max(V, 1), D), torch.float32)
-                    ops.host_gather_rows(self.host_ptrs, vic_h, voff, D, vrows_h, self.gather_threads)
-                    vic.rows[:V].copy_(vrows_h[:V], non_blocking=True)
+                    self._fetch_list("vic", vic.idx, voff, V, vic.rows, D)
+                t_g2 = _time.perf_counter()
+                if os.environ.get("CDLRM_PLAN_TIMING"):
+                    side.synchronize()
+                    print("[plan] rank %d lists %.0f ms | winners %d rows: %.0f ms | victims %d rows: %.0f ms | copies done "
+                          "+%.0f ms | threads %d | sharded %s" % (
+                              self.rank, (t_lists - t_0) * 1e3, W, (t_g1 - t_g0) * 1e3, V, (t_g2 - t_g1) * 1e3,
+                              (_time.perf_counter() - t_g2) * 1e3, self.gather_threads, bool(self._exchange)), flush=True)
                 if window_idx.is_cuda:
                     window_idx.record_stream(side)
                 self.planned = S.new_event(self.dev)
@@ -125,6 +169,7 @@ class WindowPipeline:
                 lists_ready.record(side)
             self.planned = None
             self._worker_err = None
+            self._exchange = []
             self._worker = threading.Thread(target=self._plan_host_gather, args=(window_idx, lists_ready), daemon=True)
             self._worker.start()
             self.window_no += 1
@@ -162,6 +207,13 @@ class WindowPipeline:
                 raise self._worker_err
         assert self.planned is not None, "plan_window() first"
         main.wait_event(self.planned)
+        # sharded fetch: every rank holds its slice of each list in place; one in-place all-gather per list (RCCL over
+        # xGMI) completes them.  Issued here, on the main thread and stream, at the same point of the step sequence on
+        # every rank, so it orders with the per-step gradient exchanges on the same communicator.
+        for buf, chunk in self._exchange:
+            full = buf[:chunk * self.world]
+            dist.all_gather_into_tensor(full, full[self.rank * chunk:(self.rank + 1) * chunk], group=self.pg)
+        self._exchange = []
         self.plan.commit(stream=main)
         if self.victims is not None:
             # from here on the per-iteration probe serves misses from this window's resident victim rows (the buffer

@@ -109,3 +109,81 @@ def test_two_ranks_one_gpu_match_reference(golden, name, port, defer):
             np.testing.assert_allclose(got[r]["top_w"][i], g[f"r{r}_top_w{i}"], rtol=1e-4, atol=1e-6)
     for k in range(len(g["ln_emb"])):
         np.testing.assert_allclose(float(host[k].double().sum()), float(g[f"host_sum_{k}"]), rtol=1e-6)
+
+
+def _shard_worker(rank, world, port, host_shared, ret):
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        import cdlrm_amd.engine as engine
+        import cdlrm_amd.model_no_ddp as M
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = "cuda:0"
+        torch.cuda.set_device(0)
+        ln_emb, m_spa, B, L, ways, cache = np.array([6000, 90, 11, 2500]), 16, 64, 6, 4, 60
+        eg = M.Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+        for k in range(len(ln_emb)):
+            eg.emb_l[k].weight.data = host_shared[k]
+        eg.register_shared()
+        rng = np.random.RandomState(9)
+        wins = [torch.stack([torch.from_numpy((rng.zipf(1.15, size=L * B).astype(np.int64) * 2654435761 % n)) for n in ln_emb])
+                for _ in range(4)]
+        out = {}
+        for shard in (True, False):
+            torch.manual_seed(3)
+            cg = M.Embedding_Table_Cache_Group(m_spa, ln_emb, cache, B, ways).to(dev)
+            pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=False, seed=77, rank=rank, world_size=world,
+                                         host_gather=True, gather_threads=2, shard_fetch=shard)
+            assert pipe.shard == shard and pipe.host_gather
+            snaps, exchanged = [], 0
+            for w in wins:
+                pipe.plan_window(w.to(dev))
+                pipe._worker.join()
+                exchanged += len(pipe._exchange)
+                pipe.commit()
+                pipe.wait_writeback()           # barrier: rank 0's evictions are in the host tables before the next plan
+                torch.cuda.synchronize()
+                vic = pipe.victims[pipe._vnext ^ 1]
+                nv = int(vic.off.cpu()[-1])
+                snaps.append((cg.tags.cpu().clone(), cg.weight.cpu().clone(), nv, vic.idx[:nv].cpu().clone(),
+                              vic.rows[:nv].cpu().clone()))
+            cg.ctx.check()
+            out[shard] = (snaps, exchanged)
+        assert out[True][1] == 2 * len(wins) and out[False][1] == 0, "winners + victims must travel as slices"
+        assert sum(s[2] for s in out[True][0]) > 0, "the fixture must produce victims"
+        for a, b in zip(out[True][0], out[False][0]):
+            assert torch.equal(a[0], b[0]), "tags"
+            assert a[2] == b[2] and torch.equal(a[3], b[3]), "victim list"
+            assert torch.equal(a[4], b[4]), "victim rows"
+            # rows of occupied slots (never-filled slots keep the N(0,1) init of each cache group: same seed, equal too)
+            assert torch.equal(a[1], b[1]), "cache rows"
+        ret.put((rank, {"ok": True}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        ret.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+def test_sharded_window_fetch_two_ranks():
+    """WindowPipeline(shard_fetch=True): each rank fetches half of the winners' / victims' rows from the host tables, the
+    halves meet in one all-gather per list at commit().  Same cache rows, tags and victim rows as the unsharded plan,
+    window after window (evictions written back by rank 0 in between)."""
+    from oracle import cdlrm_oracle as O
+    np.random.seed(4)
+    host = [h.share_memory_() for h in O.init_host_tables([6000, 90, 11, 2500], 16)]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, 29831, host, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for _ in range(2):
+        r, payload = ret.get(timeout=300)
+        assert "error" not in payload, payload["error"]
+    for p in procs:
+        p.join(timeout=60)
