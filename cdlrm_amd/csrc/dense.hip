@@ -7,10 +7,71 @@
 #include "gemm.h"
 
 
+// Linear forward with a short contraction (K <= 32: the first bottom layer reads the 13 dense features).  An MFMA
+// tile would be mostly padding -- the small-batch GEMM spends 13 us at M = 1024 fetching clamped indices for 13.6 MFLOP --
+// so this one runs on the vector ALU: a workgroup owns 32 rows x 128 columns, X tile and transposed W tile in LDS,
+// each thread 4 x 4 outputs (x values broadcast, w values one conflict-free 16-byte read), 16-byte row-contiguous stores.
+#define SK_KMAX 32
+__global__ void __launch_bounds__(256) k_linear_smallk(const float* __restrict__ X, int64_t ld_x, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, int64_t ld_y,
+                                                       int64_t M, int N, int K, int act) {
+    __shared__ float Xs[32][SK_KMAX + 1];
+    __shared__ __attribute__((aligned(16))) float Wt[SK_KMAX][128 + 4];
+    const int64_t m0 = (int64_t)blockIdx.y * 32;
+    const int n0 = blockIdx.x * 128;
+    for (int e = threadIdx.x; e < 32 * K; e += 256) {
+        const int r = e / K, k = e % K;
+        Xs[r][k] = X[min(m0 + r, M - 1) * ld_x + k];
+    }
+    for (int e = threadIdx.x; e < 128 * K; e += 256) {
+        const int n = e / K, k = e % K;
+        Wt[k][n] = W[(int64_t)min(n0 + n, N - 1) * K + k];
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(&Wt[k][4 * cg]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = Xs[rg * 4 + i][k];
+            acc[i][0] = fmaf(x, w.x, acc[i][0]); acc[i][1] = fmaf(x, w.y, acc[i][1]);
+            acc[i][2] = fmaf(x, w.z, acc[i][2]); acc[i][3] = fmaf(x, w.w, acc[i][3]);
+        }
+    }
+    const int n = n0 + 4 * cg;
+    if (n >= N) return;                 // N % 4 == 0: a column group is inside or outside as a whole
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = make_float4(bias[n], bias[n + 1], bias[n + 2], bias[n + 3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + rg * 4 + i;
+        if (m >= M) break;
+        float v[4] = {acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (act == 1) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            else if (act == 2) v[j] = 1.0f / (1.0f + expf(-v[j]));
+        }
+        *reinterpret_cast<float4*>(Y + m * ld_y + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y, int64_t ld_y,
                                 int64_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     CDLRM_REQUIRE(X && W && Y && M >= 0 && N >= 1 && K >= 1 && ld_x >= K && ld_y >= N, "bad argument");
     if (M == 0) return 0;
+    if (K <= SK_KMAX && N % 4 == 0 && ld_y % 4 == 0 && aligned16(Y) && cdiv(M, 32) <= 65535) {
+        dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 32));
+        hipLaunchKernelGGL(k_linear_smallk, grid, dim3(256), 0, (hipStream_t)stream, X, ld_x, W, bias, Y, ld_y, M, (int)N,
+                           (int)K, (int)act);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     GemmArgs g = gemm_args();
     g.A = X; g.lda = ld_x; g.B = W; g.ldb = K; g.C = Y; g.ldc = ld_y; g.slab = 0;
     g.M = M; g.N = N; g.K = K; g.kchunk = K; g.bias = bias; g.act = act;

@@ -304,6 +304,7 @@ class TrainEngine:
         # 8 % at 4096 (0.580 -> 0.534 ms) and at 8192 (0.853 -> 0.782 ms)
         self.split_wgrad_min = int(os.environ.get("CDLRM_SPLIT_WGRAD_MIN", "2049"))
         self.split_wgrad_max = int(os.environ.get("CDLRM_SPLIT_WGRAD_MAX", str(1 << 30)))
+        self.gather_alone_min = int(os.environ.get("CDLRM_GATHER_ALONE_MIN", "2049"))
         self._tapes = {}
         self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
 
@@ -551,10 +552,14 @@ class TrainEngine:
             # reads at c3) start right behind this batch's gather, on their own stream, into the OTHER aux region
             # (this batch still reads and updates its own aux rows).  The other region was last used by the previous
             # batch: its embedding update must have landed (emb_done).
-            ev_g = ev["gathered"]
-            rec(ev_g.record, main)
             pst = self.pref
-            rec(pst.wait_event, ev_g)
+            if B >= self.gather_alone_min:
+                # long batches: the gather is the HBM-roofline kernel and runs alone; the probe starts behind it
+                ev_g = ev["gathered"]
+                rec(ev_g.record, main)
+                rec(pst.wait_event, ev_g)
+            # short batches: every event recorded on the main queue costs a ~6 us bubble there (measured), more than the
+            # probe could take from a 6 us gather -- it starts as soon as the other aux region is free
             if self._emb_done is not None:
                 rec(pst.wait_event, self._emb_done)
             ph = 1 - self._phase

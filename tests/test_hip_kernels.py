@@ -371,7 +371,7 @@ def test_dense_golden(ops, golden, itself):
     back_mlp(bot, "bot", nb, False, dfeat[:, 0, :].contiguous(), False)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(8192, 512, 13, 1), (1000, 256, 512, 1), (777, 1, 256, 2), (4096, 512, 479, 1),
+@pytest.mark.parametrize("M,N,K,act", [(8192, 512, 13, 1), (1030, 200, 5, 2), (33, 132, 32, 0), (1000, 256, 512, 1), (777, 1, 256, 2), (4096, 512, 479, 1),
                                        (130, 70, 33, 0), (1024, 512, 480, 1), (2048, 128, 256, 1), (8192, 1, 256, 2),
                                        (5000, 512, 512, 1), (3, 5, 2, 0), (1024, 512, 13, 1)])
 def test_linear_vs_torch_fp32(ops, M, N, K, act):
