@@ -67,6 +67,16 @@ void cdlrm_set_error(const char* fmt, ...);
     } while (0)
 
 #define CDLRM_LAUNCH_CHECK() CDLRM_HIP_CHECK(hipGetLastError())
+// hipGetLastError() is sticky per host thread: an error some OTHER caller of the runtime left behind (the host
+// framework probes pointers and events with calls that are allowed to fail) would be reported by our next launch
+// check.  Entry points that launch without a preceding checked call drop such a stale error first
+// (CDLRM_DEBUG_STALE=1 prints it).
+#define CDLRM_CLEAR_STALE()                                                                                   \
+    do {                                                                                                      \
+        hipError_t stale_ = hipGetLastError();                                                                \
+        if (stale_ != hipSuccess && getenv("CDLRM_DEBUG_STALE"))                                              \
+            fprintf(stderr, "[cdlrm] stale HIP error before %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(stale_)); \
+    } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int64_t cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -69,14 +69,23 @@ extern "C" int cdlrm_ctx_create(const cdlrm_geometry* geo, cdlrm_ctx** out) {
 
 extern "C" int cdlrm_ctx_destroy(cdlrm_ctx* c) {
     if (!c) return 0;
-    (void)hipFree(c->d_tab);
-    (void)hipFree(c->d_host_rows);
-    (void)hipFree(c->d_ptr_fetch);
-    (void)hipFree(c->d_ptr_wb);
-    (void)hipFree(c->d_err);
-    (void)hipFree(c->d_small);
-    (void)hipFree(c->d_scan);
-    (void)hipHostFree(c->h_pinned);
+    // Called from the host language's garbage collector at arbitrary points, possibly between two launches of ANOTHER
+    // context's step: nothing may escape -- no C++ exception across the C ABI (the runtime threw
+    // std::bad_variant_access out of a free issued while a failed step was being unwound), no sticky error for
+    // somebody else's next launch check (hipGetLastError() is per thread, not per context).
+    try {
+        (void)hipDeviceSynchronize();          // kernels that still read the scratch buffers
+        if (c->d_tab) (void)hipFree(c->d_tab);
+        if (c->d_host_rows) (void)hipFree(c->d_host_rows);
+        if (c->d_ptr_fetch) (void)hipFree(c->d_ptr_fetch);
+        if (c->d_ptr_wb) (void)hipFree(c->d_ptr_wb);
+        if (c->d_err) (void)hipFree(c->d_err);
+        if (c->d_small) (void)hipFree(c->d_small);
+        if (c->d_scan) (void)hipFree(c->d_scan);
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        (void)hipGetLastError();
+    } catch (...) {
+    }
     delete c;
     return 0;
 }

@@ -65,6 +65,7 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
                                 int64_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     CDLRM_REQUIRE(X && W && Y && M >= 0 && N >= 1 && K >= 1 && ld_x >= K && ld_y >= N, "bad argument");
     if (M == 0) return 0;
+    CDLRM_CLEAR_STALE();
     if (K <= SK_KMAX && N % 4 == 0 && ld_y % 4 == 0 && aligned16(Y) && cdiv(M, 32) <= 65535) {
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 32));
         hipLaunchKernelGGL(k_linear_smallk, grid, dim3(256), 0, (hipStream_t)stream, X, ld_x, W, bias, Y, ld_y, M, (int)N,

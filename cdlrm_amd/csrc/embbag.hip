@@ -344,6 +344,7 @@ static int lanes_per_row(int D4) { int l = pow2ceil(D4); return l > 64 ? 64 : (l
 extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx,
                                   int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, int32_t aux_phase,
                                   void* stream) {
+    CDLRM_CLEAR_STALE();
     CDLRM_REQUIRE(ctx && idx && slots_out && miss_pos && miss_count, "null argument");
     CDLRM_REQUIRE(aux_phase >= 0 && aux_phase < ctx->aux_phases, "aux_phase outside the geometry's aux_phases");
     const int aux_first = aux_phase * ctx->aux;
@@ -408,6 +409,7 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
 extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,
                                 int64_t n_bags, int64_t ld_off, float* out, int64_t ld_bag, int64_t ld_table,
                                 void* stream) {
+    CDLRM_CLEAR_STALE();
     CDLRM_REQUIRE(ctx && slots && out, "null argument");
     CDLRM_REQUIRE(ctx->weight, "cdlrm_ctx_bind_cache first");
     CDLRM_REQUIRE(((uintptr_t)out & 15) == 0 && ld_bag % 4 == 0 && ld_table % 4 == 0, "16-byte aligned output rows");

@@ -31,6 +31,47 @@ from ._lib import record as rec
 from .model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group, _linears
 
 
+def square_bags(lS_o, lS_i, device=None, multiple: int = 256):
+    """Ragged multi-hot bags (the reference's random front end: T index lists of different lengths + T offset lists,
+    dlrm_data_pytorch.py:763-805) -> the rectangular layout the kernels take: (offsets int64 [T, n_bags + 1],
+    indices int64 [T, n]).  Tables are squared off with ONE extra bag: the padding lookups of table k repeat its first
+    index of the batch (no new row is touched, no new window index appears) and are pooled into bag n_bags, a scratch row
+    behind the batch whose gradient is zero -- adding lr * 0 leaves the cache rows bit-identical.  n is rounded up to
+    `multiple` so that a stream of batches reuses a few buffer shapes.  Rectangular inputs pass through unchanged."""
+    if isinstance(lS_i, torch.Tensor) and lS_i.dim() == 2:
+        off = lS_o if isinstance(lS_o, torch.Tensor) or lS_o is None else torch.stack(list(lS_o))
+        return (None if off is None else off.to(device) if device is not None else off,
+                lS_i.to(device) if device is not None else lS_i)
+    idx_l = [torch.as_tensor(x).reshape(-1).to(torch.int64) for x in lS_i]
+    off_l = [torch.as_tensor(x).reshape(-1).to(torch.int64) for x in lS_o]
+    T, nb = len(idx_l), int(off_l[0].numel())
+    lens = [int(x.numel()) for x in idx_l]
+    assert min(lens) >= 1 and all(int(o.numel()) == nb for o in off_l), "every table needs >= 1 lookup and n_bags offsets"
+    n = (max(lens) + multiple - 1) // multiple * multiple
+    idx = torch.empty(T, n, dtype=torch.int64)
+    off = torch.empty(T, nb + 1, dtype=torch.int64)
+    for k in range(T):
+        idx[k, :lens[k]] = idx_l[k]
+        idx[k, lens[k]:] = idx_l[k][0]
+        off[k, :nb] = off_l[k]
+        off[k, nb] = lens[k]
+    if device is not None:
+        idx, off = idx.to(device), off.to(device)
+    return off, idx
+
+
+def pad_window(lists, device=None):
+    """A look-ahead window of ragged per-table index lists -> int64 [T, n]: the plan only needs each table's SET of
+    indices, so short tables are padded with their own first index."""
+    lists = [torch.as_tensor(x).reshape(-1).to(torch.int64) for x in lists]
+    n = max(int(x.numel()) for x in lists)
+    out = torch.empty(len(lists), n, dtype=torch.int64)
+    for k, x in enumerate(lists):
+        out[k, :x.numel()] = x
+        out[k, x.numel():] = x[0]
+    return out.to(device) if device is not None else out
+
+
 class WindowPipeline:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, host_tables: Embedding_Table_Group, max_window: int,
                  *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
@@ -354,17 +395,19 @@ class TrainEngine:
         f32 = torch.float32
         npairs = F * (F + 1) // 2 if self.itself else F * (F - 1) // 2
         b = dict()
+        # one scratch row behind the batch in the feature blocks: the extra bag of squared-off ragged inputs
+        # (square_bags) pools into it; its gradient row stays zero
         if self.cat:
             # "cat" interaction (model_no_ddp.py:297-299): R = cat([x] + ly) IS the feature block the bottom MLP and
             # the gather write into -- no interaction kernel, no copy
             assert self.r_width >= F * D
-            b["R"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
-            b["dR"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
+            b["R"] = torch.zeros(B + 1, self.r_width, dtype=f32, device=dev)[:B]
+            b["dR"] = torch.zeros(B + 1, self.r_width, dtype=f32, device=dev)[:B]
             b["feat"] = b["R"].as_strided((B, F, D), (self.r_width, D, 1))
             b["dfeat"] = b["dR"].as_strided((B, F, D), (self.r_width, D, 1))
         else:
-            b["feat"] = torch.empty(B, F, D, dtype=f32, device=dev)
-            b["dfeat"] = torch.empty(B, F, D, dtype=f32, device=dev)
+            b["feat"] = torch.zeros(B + 1, F, D, dtype=f32, device=dev)[:B]
+            b["dfeat"] = torch.zeros(B + 1, F, D, dtype=f32, device=dev)[:B]
             assert self.r_width >= D + npairs
             b["R"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)      # pad column (if any) stays zero
             b["dR"] = torch.zeros(B, self.r_width, dtype=f32, device=dev)
@@ -451,9 +494,12 @@ class TrainEngine:
              j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None):
         """One training iteration on this rank's slice (next_idx: the NEXT batch's indices, if it belongs to the same
         window: its tag probe and aux fill are then issued behind this step's embedding backward).  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
-        on the device; lS_o None = Criteo layout; j = batch number inside the epoch (table-agg schedule).
+        on the device; lS_o None = Criteo layout (one lookup per bag), else int64 [T, B] offsets -- or [T, B + 1] from
+        square_bags() for ragged multi-hot tables; j = batch number inside the epoch (table-agg schedule).
         Returns the device loss buffer (element 0 = BCE loss)."""
         B, n = X.shape[0], lS_i.shape[1]
+        if lS_o is not None:
+            assert lS_o.shape[1] in (B, B + 1) and (self.world == 1 or lS_o.shape[1] == B)
         if j is None:
             j = self.iter
         if self.world > 1 and j > 0 and j % self.agg_freq == 0:
@@ -542,11 +588,11 @@ class TrainEngine:
         if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
             e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
             e0.record(main)
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=B)
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
             e1.record(main)
             gather_events.append((e0, e1))
         else:
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=B)
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
         if next_idx is not None and two_phase:
             # Software pipelining across iterations: the NEXT batch's tag probe and aux-row fill (~0.25 ms of PCIe
             # reads at c3) start right behind this batch's gather, on their own stream, into the OTHER aux region
@@ -704,7 +750,7 @@ class TrainEngine:
             y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
             ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             cur = y
-        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=B)
+        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
         if not self.cat:
             ops.interact_fwd(feat, self.itself, R)
         cur = R

@@ -528,8 +528,12 @@ class OracleTrainer:
         params = []
         for r in range(Wn):
             Xr = X[r * lbs:(r + 1) * lbs]
-            Ir = [lS_i[k][r * lbs:(r + 1) * lbs] for k in range(len(self.ln_emb))]
-            Or = [lS_o[k][:lbs] for k in range(len(self.ln_emb))]
+            if Wn == 1:         # whole batch: multi-hot / ragged bags pass through as they are
+                Ir = [lS_i[k] for k in range(len(self.ln_emb))]
+                Or = [lS_o[k] for k in range(len(self.ln_emb))]
+            else:               # the rank slice of the Criteo layout (one lookup per sample)
+                Ir = [lS_i[k][r * lbs:(r + 1) * lbs] for k in range(len(self.ln_emb))]
+                Or = [lS_o[k][:lbs] for k in range(len(self.ln_emb))]
             Tr = T[r * lbs:(r + 1) * lbs]
             ly, cg = cache_forward(self.occ, self.weights[r], self.cache_sizes, Or, Ir, self.host)
             ly = [v.detach().requires_grad_(True) for v in ly]
@@ -545,7 +549,7 @@ class OracleTrainer:
             # embedding SGD (optimizer_embeds.step, :413)
             for k in range(len(self.ln_emb)):
                 embbag_bwd_sgd(self.weights[r][k], cg[k].long(), Or[k], ly[k].grad, self.lr_embeds)
-            self.touched[r].append(torch.stack(cg))
+            self.touched[r].append(list(cg))      # per-table lists (ragged for multi-hot bags)
         # aggregate_gradients (:234-247): weight grads averaged, bias grads NOT reduced
         for li in range(len(params[0][0])):
             g = sum(params[r][0][li].grad / Wn for r in range(Wn))

@@ -257,3 +257,60 @@ def test_engine_loss_and_interaction_arms_vs_oracle(op, loss, ws, thr, defer):
     np.testing.assert_allclose(Zg.cpu().numpy(), Zo.numpy(), rtol=1e-5, atol=1e-6)
     for k in range(len(ln_emb)):
         assert torch.equal(cg.occupancy_tables[k].cpu(), otr.occ[k]), k
+
+
+@pytest.mark.parametrize("fixed,op", [(False, "dot"), (True, "cat")])
+def test_ragged_multihot_bags_vs_oracle(fixed, op):
+    """The reference's default data mode (--data-generation=random: uniform multi-hot bags, tables ragged against each
+    other, dlrm_data_pytorch.py:763-805) through the fused engine: engine.square_bags() squares the tables off with one
+    scratch bag; loss per iteration, prediction and tag state against the oracle's trainer on the raw ragged lists."""
+    from types import SimpleNamespace
+    from cdlrm_amd import dlrm_data_pytorch as DP
+    from cdlrm_amd.engine import TrainEngine, WindowPipeline, pad_window, square_bags
+    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group
+    from oracle import cdlrm_oracle as O
+    ln_emb, m_spa, B, L, ways, cache_size, seed = [900, 40, 6, 2500], 16, 32, 3, 4, 300, 23
+    aux = 512                       # >= lookups per table and batch (the squared-off width): misses get their own aux row
+    ln_bot = np.array([5, 32, m_spa])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([(m_spa + nf * (nf - 1) // 2) if op == "dot" else nf * m_spa, 24, 1])
+    args = SimpleNamespace(data_size=0, num_batches=9, mini_batch_size=B, num_indices_per_lookup=7,
+                           num_indices_per_lookup_fixed=fixed, round_targets=True, data_generation="random",
+                           numpy_rand_seed=seed)
+    _, loader = DP.make_random_data_and_loader(args, np.array(ln_emb), 5)
+    batches = [(X, [o for o in lS_o], lS_i, Tt) for X, lS_o, lS_i, Tt in loader]
+    assert len({int(x.numel()) for x in batches[0][2]}) > 1, "ragged tables expected"
+    torch.set_num_threads(1)
+    otr = O.OracleTrainer(ln_emb, m_spa, ln_bot, ln_top, cache_size=cache_size, num_ways=ways, mini_batch_size=aux,
+                          lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=10 ** 9, seed=seed, op=op)
+    for j, (X, lS_o, lS_i, Tt) in enumerate(batches):
+        if j % L == 0:
+            torch.manual_seed(800 + j)
+            otr.refill([torch.cat([b[2][k] for b in batches[j:j + L]]) for k in range(len(ln_emb))])
+        otr.step(j, X, lS_o, lS_i, Tt)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host = Embedding_Table_Group(m_spa, np.array(ln_emb)).pin()
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    cg = Embedding_Table_Cache_Group(m_spa, np.array(ln_emb), cache_size, aux, ways).to(DEV)
+    dl = DLRM_Net(ln_bot, ln_top, op, False, True, -1, ln_top.size - 2, 0.0).to(DEV)
+    eng = TrainEngine(cg, dl, host, lr=0.1, lr_embeds=0.3)
+    pipe = WindowPipeline(cg, host, 4096, parity_rng=True)
+    losses = []
+    for j, (X, lS_o, lS_i, Tt) in enumerate(batches):
+        if j % L == 0:
+            torch.manual_seed(800 + j)
+            pipe.plan_window(pad_window([torch.cat([b[2][k] for b in batches[j:j + L]]) for k in range(len(ln_emb))], DEV))
+            pipe.commit()
+            pipe.wait_writeback()
+        off, idx = square_bags(lS_o, lS_i, DEV)
+        assert off.shape == (len(ln_emb), B + 1) and idx.shape[1] % 256 == 0
+        losses.append(float(eng.step(X.to(DEV), idx, Tt.to(DEV), lS_o=off, j=j)[0]))
+    cg.ctx.check()
+    np.testing.assert_allclose(np.array(losses), np.array([l[0] for l in otr.losses]), rtol=1e-5)
+    for k in range(len(ln_emb)):
+        assert torch.equal(cg.occupancy_tables[k].cpu(), otr.occ[k]), k
+        nrow = ways * cg.cache_sizes[k]
+        np.testing.assert_allclose(cg.emb_l[k].weight[:nrow].cpu().numpy(), otr.weights[0][k][:nrow].numpy(),
+                                   rtol=2e-5, atol=1e-6)

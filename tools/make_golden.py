@@ -354,6 +354,24 @@ def g_dense_variants(M, MD, CM, QR):
         save("dense_" + name, **out)
 
 
+def g_random_data(M, MD, CM, QR):
+    """The reference's random front end (dlrm_data_pytorch.py:551-684, 752-805): three consecutive batches of a
+    RandomDataset (seed reset on the access to item 0), non-fixed and fixed bag sizes."""
+    import dlrm_data_pytorch as DP
+    out = {}
+    for tag, fixed in (("var", False), ("fix", True)):
+        ln_emb = np.array([60, 7, 1500, 3])
+        ds = DP.RandomDataset(5, ln_emb, 0, 3, 12, 6, fixed, 1, True, "random", "", False, reset_seed_on_access=True,
+                              rand_seed=31)
+        out[tag + "_ln_emb"] = ln_emb
+        for j in range(3):
+            X, lS_o, lS_i, T = ds[j]
+            out[f"{tag}_X{j}"], out[f"{tag}_T{j}"] = X, T
+            for k in range(len(ln_emb)):
+                out[f"{tag}_o{j}_{k}"], out[f"{tag}_i{j}_{k}"] = lS_o[k], lS_i[k]
+    save("random_data", **out)
+
+
 def g_embbag_sgd(M, MD, CM, QR):
     """nn.EmbeddingBag(sum, sparse) backward + optim.SGD step on cache rows (a-7), with repeated
     slots and a multi-hot case."""
@@ -680,7 +698,7 @@ def g_criteo_loader(M, MD, CM, QR):
 
 
 GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
-            dense_variants=g_dense_variants,
+            dense_variants=g_dense_variants, random_data=g_random_data,
             embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_w2=g_train_w2, qr=g_qr,
             window_groups=g_window_groups)
 
