@@ -278,7 +278,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         emb_tables, args):
     """main_no_ddp.py:324-502 on the fused engine.  One process per GPU; `rank` is the device index and the
     distributed rank.  train_ld yields (X, lS_o, lS_i, T) global batches; every rank takes its slice."""
-    from .engine import TrainEngine, WindowPipeline
+    from .engine import TrainEngine, WindowPipeline, pad_window, square_bags
     try:
         from setproctitle import setproctitle
         setproctitle("DlrmTrainer:" + str(rank))
@@ -298,8 +298,19 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         dist.init_process_group("nccl", rank=rank, world_size=world)
     local_batch_size = math.ceil(args.mini_batch_size / world)
 
+    # multi-hot bags (--data-generation=random): a batch has up to mini_batch_size * num_indices_per_lookup lookups per
+    # table, each miss takes its own aux row (model_no_ddp.py:176-179) -- the reference sizes the aux region for one
+    # lookup per sample and would index past it; here the region covers the squared-off width (slot ids of the first
+    # mini_batch_size misses are the reference's)
+    multi_hot = getattr(train_ld, "multi_hot", False)
+    aux_rows = args.mini_batch_size
+    if multi_hot:
+        if world > 1:
+            sys.exit("ERROR: multi-hot bags (--data-generation=random) run on one rank; the rank slice "
+                     "(main_no_ddp.py:388-391) is defined for one lookup per sample")
+        aux_rows = (args.mini_batch_size * max(1, args.num_indices_per_lookup) + 255) // 256 * 256
     cache_group = Embedding_Table_Cache_Group(m_spa, ln_emb, max_cache_size=args.cache_size,
-                                              aux_table_size=args.mini_batch_size, num_ways=args.num_ways).to(dev)
+                                              aux_table_size=aux_rows, num_ways=args.num_ways).to(dev)
     dlrm = DLRM_Net(ln_bot, ln_top, arch_interaction_op=args.arch_interaction_op,
                     arch_interaction_itself=args.arch_interaction_itself, sync_dense_params=args.sync_dense_params,
                     sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_threshold=args.loss_threshold).to(dev)
@@ -322,7 +333,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                       rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op,
                       loss=args.loss_function, loss_weights=loss_ws, defer_top_update=world > 1)
     L = args.lookahead
-    pipe = WindowPipeline(cache_group, emb_tables, L * args.mini_batch_size * 2, parity_rng=not args.device_rng,
+    pipe = WindowPipeline(cache_group, emb_tables, L * aux_rows * 2, parity_rng=not args.device_rng,
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
                           world_size=world)
 
@@ -344,8 +355,12 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 if not window:
                     break
                 start = timer()
-                win_idx = torch.cat([torch.as_tensor(b[2]) if not isinstance(b[2], (list, tuple)) else
-                                     torch.stack([torch.as_tensor(s).reshape(-1) for s in b[2]]) for b in window], dim=1)
+                if multi_hot:       # ragged per-table lists: the plan only needs each table's set of indices
+                    win_idx = pad_window([torch.cat([torch.as_tensor(b[2][k]).reshape(-1) for b in window])
+                                          for k in range(len(ln_emb))])
+                else:
+                    win_idx = torch.cat([torch.as_tensor(b[2]) if not isinstance(b[2], (list, tuple)) else
+                                         torch.stack([torch.as_tensor(s).reshape(-1) for s in b[2]]) for b in window], dim=1)
                 if world > 1:
                     eng.sync_touched_to_rank0()
                 pipe.plan_window(win_idx.to(dev))
@@ -353,14 +368,19 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 pipe.wait_writeback()
                 caching_overhead.append(timer() - start)
             X, lS_o, lS_i, T = window.pop(0)
-            lS_i = torch.as_tensor(lS_i) if not isinstance(lS_i, (list, tuple)) else torch.stack(
-                [torch.as_tensor(s).reshape(-1) for s in lS_i])
-            sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
-            Xr = X[sl, :].to(dev)
-            Ir = lS_i[:, sl].contiguous().to(dev)      # the day-file loader hands out X_cat^T (a strided view)
-            Tr = T[sl, :].to(dev)
+            Or = None
+            if multi_hot:
+                Or, Ir = square_bags([lS_o[k] for k in range(len(ln_emb))], lS_i, dev)
+                Xr, Tr = X.to(dev), T.to(dev)
+            else:
+                lS_i = torch.as_tensor(lS_i) if not isinstance(lS_i, (list, tuple)) else torch.stack(
+                    [torch.as_tensor(s).reshape(-1) for s in lS_i])
+                sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
+                Xr = X[sl, :].to(dev)
+                Ir = lS_i[:, sl].contiguous().to(dev)      # the day-file loader hands out X_cat^T (a strided view)
+                Tr = T[sl, :].to(dev)
             t1 = time_wrap(rank)
-            lossbuf = eng.step(Xr, Ir, Tr, j=j)
+            lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j)
             t2 = time_wrap(rank)
             mbs = Tr.shape[0]
             Z = eng.prediction(Xr.shape[0])
@@ -490,6 +510,11 @@ def main(argv=None):
     emb_tables = make_host_tables(ln_emb, m_spa, device=dev, seed=args.numpy_rand_seed, rank=rank, world=args.world_size,
                                   shm_name="cdlrm_run_%d" % args.master_port,
                                   barrier=(dist.barrier if args.world_size > 1 else (lambda: None)))
+    if train_ld is None and args.data_generation == "random":
+        # the reference's random front end (dlrm_data_pytorch.py:658-684): uniform multi-hot bags, ragged tables
+        from .dlrm_data_pytorch import make_random_data_and_loader
+        _, train_ld = make_random_data_and_loader(args, ln_emb, m_den)
+        train_ld.multi_hot = True
     if train_ld is None:
         nb = args.num_batches if args.num_batches > 0 else max(1, args.data_size // args.mini_batch_size)
         syn = synth.CriteoSynth(ln_emb, int(m_den), args.mini_batch_size, seed=args.numpy_rand_seed,

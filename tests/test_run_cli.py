@@ -193,3 +193,67 @@ def test_main_cli_synthetic(capsys):
     losses = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", out)]
     assert all(np.isfinite(losses)) and 0.3 < losses[-1] < 1.0
     assert "Caching overhead" in lines[0] and "Train Acc" in lines[0]
+
+
+def test_run_random_multihot_matches_oracle_trainer(capsys):
+    """--data-generation=random (the reference CLI's default front end: uniform multi-hot bags, ragged tables) with the
+    CLI's default loss (mse) through `Run`: printed loss per iteration and final tags against the oracle's trainer fed
+    the same RandomDataset batches."""
+    from cdlrm_amd import dlrm_data_pytorch as DP
+    from cdlrm_amd.main_no_ddp import ProcessArgs, Run
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    flags = [f for f in FLAGS if not f.startswith(("--loss-function", "--arch-embedding-size", "--mini-batch-size",
+                                                    "--cache-size", "--arch-mlp-bot"))]
+    args = ProcessArgs(flags + ["--arch-embedding-size=900-40-6-2500", "--mini-batch-size=32", "--cache-size=300",
+                                "--arch-mlp-bot=5-32-16", "--data-generation=random", "--num-batches=10",
+                                "--num-indices-per-lookup=6"])
+    assert args.loss_function == "mse"                   # the reference's default (main_no_ddp.py:48)
+    ln_emb = np.array([900, 40, 6, 2500])
+    m_spa, B, L, nb, seed = 16, 32, 4, 10, 11
+    ln_bot = np.array([5, 32, 16])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+    _, loader = DP.make_random_data_and_loader(args, ln_emb, 5)
+    loader.multi_hot = True
+    batches = [(X, [o for o in lS_o], lS_i, T) for X, lS_o, lS_i, T in loader]
+    aux = (B * 6 + 255) // 256 * 256
+    torch.set_num_threads(1)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host_o = O.init_host_tables([int(n) for n in ln_emb], m_spa)
+    otr = O.OracleTrainer([int(n) for n in ln_emb], m_spa, ln_bot, ln_top, cache_size=300, num_ways=4,
+                          mini_batch_size=aux, lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=5, seed=seed,
+                          host_tables=[h.clone() for h in host_o], loss="mse")
+    # `for ... in train_ld` on a torch DataLoader draws the iterator's base seed from the global torch generator
+    # (one int64 random_()), in the reference's loop as in Run's: the way choices of the refills come after that draw
+    torch.empty((), dtype=torch.int64).random_()
+    for j, (X, lS_o, lS_i, T) in enumerate(batches):
+        if j % L == 0:
+            otr.refill([torch.cat([b[2][k] for b in batches[j:j + L]]) for k in range(len(ln_emb))])
+        otr.step(j, X, lS_o, lS_i, T)
+    eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+    for k in range(len(ln_emb)):
+        eg.emb_l[k].weight.data = host_o[k].clone()
+    eg.pin()
+    capsys.readouterr()
+    eng = Run(0, m_spa, ln_emb, ln_bot, ln_top, loader, None, None, None, None, eg, args)
+    printed = capsys.readouterr().out
+    got = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", printed)]
+    want = np.array([l[0] for l in otr.losses])
+    assert len(got) == nb - 1
+    # multi-hot bags: the pooled sums (up to 6 rows) and their gradients accumulate in another order than ATen's, and
+    # the differences compound over the iterations -- 3e-5 here; the 1e-5 bar is the Criteo layout's (one row per bag)
+    np.testing.assert_allclose(np.array(got), np.concatenate([[(want[0] + want[1]) / 2], want[2:]]), rtol=3e-5)
+    eng.cg.ctx.check()
+    for k in range(len(ln_emb)):
+        assert torch.equal(eng.cg.occupancy_tables[k].cpu(), otr.occ[k]), k
+
+
+def test_main_cli_random_default_front_end(capsys):
+    """python -m cdlrm_amd.main_no_ddp with the reference's DEFAULT data mode and loss (random multi-hot, mse)."""
+    from cdlrm_amd import main_no_ddp
+    flags = [f for f in FLAGS if not f.startswith(("--loss-function", "--cache-size"))]
+    main_no_ddp.main(flags + ["--num-batches=9", "--cache-size=4000", "--num-indices-per-lookup=4"])
+    out = capsys.readouterr().out
+    losses = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", out)]
+    assert len(losses) == 8 and all(np.isfinite(losses)) and 0.0 < losses[-1] < 1.0
