@@ -174,12 +174,21 @@ def main():
     n_windows = (total_steps + L - 1) // L + 1
     win_bytes = len(ln_emb) * L * B * 8
     pregen = {}
+    # Windows that fit neither the pre-generation budget nor HBM as ONE tensor (c5: 8000 batches x 65536 = 109 GB) are
+    # STREAMED: the index stream is defined in chunks of C batches (C | L, <= 4 GB each), the plan folds chunk after
+    # chunk into its bitmap (cdlrm_window_unique_add / _finish), the training steps keep the current chunk only.
+    C = 0
     if n_windows * win_bytes <= (64 << 30):
         for w in range(n_windows):
             pregen[w] = syn.window(w, L)
         torch.cuda.synchronize()
+    elif win_bytes > (16 << 30):
+        per_batch = len(ln_emb) * B * 8
+        C = max(c for c in range(1, L + 1) if L % c == 0 and c * per_batch <= (4 << 30))
 
     def get_window(w):
+        if C:
+            return lambda: (syn.window(c, C) for c in range(w * (L // C), (w + 1) * (L // C)))
         return pregen[w] if w in pregen else syn.window(w, L)
 
     state = {"win": None, "next": None, "w": -1}
@@ -203,15 +212,22 @@ def main():
             pipe.wait_writeback()
             state["next"] = get_window(w + 1)
             pipe.plan_window(state["next"])
-        col = jj * B + rank * lbs
-        idx = state["win"][:, col:col + lbs]
+        if C:       # streamed windows: the steps read from the current chunk
+            cid, jc = divmod(j, C)
+            if state.get("cid") != cid:
+                state["chunk"], state["cid"] = syn.window(cid, C), cid
+            win_t, jloc, nloc = state["chunk"], jc, C
+        else:
+            win_t, jloc, nloc = state["win"], jj, L
+        col = jloc * B + rank * lbs
+        idx = win_t[:, col:col + lbs]
         X, T = syn.dense(j)
         X, T = X[rank * lbs:(rank + 1) * lbs], T[rank * lbs:(rank + 1) * lbs]
         sample = timed and a.gather_sample > 0 and (j % a.gather_sample == 0)
         # eager mode: hand the next batch's indices over so its tag probe / aux fill run behind this step's backward
         nxt = None
-        if jj + 1 < L and jj + 1 != plan_at:
-            nxt = state["win"][:, col + B:col + B + lbs]
+        if jj + 1 < L and jj + 1 != plan_at and jloc + 1 < nloc:
+            nxt = win_t[:, col + B:col + B + lbs]
         eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
 
     for j in range(a.warmup):
@@ -254,7 +270,8 @@ def main():
             "value": B * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["name"], "config_id": a.config, "global_batch": B, "local_batch": lbs,
+            "config": {"workload": cfg["name"] + (" [windows streamed to the plan in chunks of %d batches]" % C if C else ""),
+                       "config_id": a.config, "global_batch": B, "local_batch": lbs,
                        "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
                        "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1)},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",

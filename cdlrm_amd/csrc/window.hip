@@ -82,20 +82,30 @@ __global__ void __launch_bounds__(256) k_bm_emit(const TableDesc* __restrict__ t
     }
 }
 
-extern "C" int cdlrm_window_unique(cdlrm_ctx* ctx, const cdlrm_plan* plan, const int64_t* idx, int64_t n,
-                                   int64_t ld_idx, void* stream) {
+// Streamed form of K1 for windows that do not fit HBM as one tensor (config c5: 8000 batches x 65536 = 109 GB of
+// indices): the bitmap accumulates any number of chunks, then ONE count + emit turns it into the sorted unique lists
+// (and leaves the bitmap zero for the next window).
+extern "C" int cdlrm_window_unique_add(cdlrm_ctx* ctx, const cdlrm_plan* plan, const int64_t* idx, int64_t n,
+                                       int64_t ld_idx, void* stream) {
     CDLRM_REQUIRE(ctx && plan && idx, "null argument");
-    CDLRM_REQUIRE(plan->bitmap && plan->uniq && plan->uniq_off, "plan buffers missing");
+    CDLRM_REQUIRE(plan->bitmap, "plan buffers missing");
     CDLRM_REQUIRE(n >= 1 && ld_idx >= n, "bad n / ld_idx");
     CDLRM_REQUIRE(((uintptr_t)plan->bitmap & 15) == 0, "bitmap must be 16-byte aligned");
+    int64_t gx = cdiv(n, WIN_THREADS);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_bm_set, dim3((unsigned)gx, (unsigned)ctx->T), dim3(WIN_THREADS), 0, (hipStream_t)stream, ctx->d_tab,
+                       idx, n, ld_idx, (unsigned long long*)plan->bitmap, ctx->d_err);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdlrm_window_unique_finish(cdlrm_ctx* ctx, const cdlrm_plan* plan, void* stream) {
+    CDLRM_REQUIRE(ctx && plan, "null argument");
+    CDLRM_REQUIRE(plan->bitmap && plan->uniq && plan->uniq_off, "plan buffers missing");
     hipStream_t s = (hipStream_t)stream;
     const int64_t nblocks = ctx->total_bm_words / BM_WPB;
     int rc = cdlrm_scan_reserve(ctx, nblocks);
     if (rc) return rc;
-    int64_t gx = cdiv(n, WIN_THREADS);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_bm_set, dim3((unsigned)gx, (unsigned)ctx->T), dim3(WIN_THREADS), 0, s, ctx->d_tab, idx, n,
-                       ld_idx, (unsigned long long*)plan->bitmap, ctx->d_err);
     hipLaunchKernelGGL(k_bm_count, dim3((unsigned)nblocks), dim3(256), 0, s, (const unsigned long long*)plan->bitmap,
                        ctx->d_scan);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, ctx->d_scan, nblocks, plan->uniq_off + ctx->T);
@@ -104,6 +114,13 @@ extern "C" int cdlrm_window_unique(cdlrm_ctx* ctx, const cdlrm_plan* plan, const
                        ctx->d_err);
     CDLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdlrm_window_unique(cdlrm_ctx* ctx, const cdlrm_plan* plan, const int64_t* idx, int64_t n,
+                                   int64_t ld_idx, void* stream) {
+    int rc = cdlrm_window_unique_add(ctx, plan, idx, n, ld_idx, stream);
+    if (rc) return rc;
+    return cdlrm_window_unique_finish(ctx, plan, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -186,22 +186,35 @@ class WindowPipeline:
                           "+%.0f ms | threads %d | sharded %s" % (
                               self.rank, (t_lists - t_0) * 1e3, W, (t_g1 - t_g0) * 1e3, V, (t_g2 - t_g1) * 1e3,
                               (_time.perf_counter() - t_g2) * 1e3, self.gather_threads, bool(self._exchange)), flush=True)
-                if window_idx.is_cuda:
+                if isinstance(window_idx, torch.Tensor) and window_idx.is_cuda:
                     window_idx.record_stream(side)
                 self.planned = S.new_event(self.dev)
                 self.planned.record(side)
         except BaseException as e:          # surfaced by commit()
             self._worker_err = e
 
-    def plan_window(self, window_idx: torch.Tensor, q_source=None):
-        """Launch the plan of one window ([T, n] int64 on device) on the side stream."""
+    def _unique(self, window_idx, side):
+        """K1 on the plan stream: one [T, n] tensor, or a window streamed as chunks (a callable returning an iterator
+        of [T, n_c] tensors, produced on the plan stream: a window that does not fit HBM in one piece)."""
+        plan = self.plan
+        if callable(window_idx):
+            for chunk in window_idx():
+                plan.unique_add(chunk, stream=side)
+                del chunk
+            plan.unique_finish(stream=side)
+        else:
+            plan.unique(window_idx, stream=side)
+
+    def plan_window(self, window_idx, q_source=None):
+        """Launch the plan of one window on the side stream.  window_idx: [T, n] int64 on the device, or a callable
+        that yields the window's chunks (called under the plan stream; see _unique)."""
         plan, side = self.plan, self.side
         side.wait_stream(S.current_stream(self.dev))          # window_idx may have been produced there
         if self.host_gather:
             import threading
             assert self._worker is None, "the previous plan was never committed"
             with S.on_stream(side):
-                plan.unique(window_idx, stream=side)
+                self._unique(window_idx, side)
                 plan.probe(stream=side)
                 plan.assign(None, seed=self.seed * 1000003 + self.window_no, stream=side)
                 if self.victims is not None:
@@ -216,7 +229,7 @@ class WindowPipeline:
             self.window_no += 1
             return
         with S.on_stream(side):
-            plan.unique(window_idx, stream=side)
+            self._unique(window_idx, side)
             plan.probe(stream=side)
             if self.parity_rng:
                 # Categorical.sample() draws from the torch CPU generator, table by table (main_no_ddp.py:184-185)
@@ -224,15 +237,15 @@ class WindowPipeline:
                 T, ways = self.ctx.T, self.ctx.ways
                 src = q_source if q_source is not None else (lambda M, w: torch.empty(M, w).exponential_(1) if M else torch.empty(0, w))
                 qs = [src(ko[k + 1] - ko[k], ways) for k in range(T)]
-                q = torch.cat(qs).contiguous().to(window_idx.device, non_blocking=False) if ko[T] else None
+                q = torch.cat(qs).contiguous().to(self.dev, non_blocking=False) if ko[T] else None
                 self.last_offsets = (uo, ko)
-                plan.assign(q if q is not None else torch.empty(1, ways, device=window_idx.device), stream=side)
+                plan.assign(q if q is not None else torch.empty(1, ways, device=self.dev), stream=side)
             else:
                 plan.assign(None, seed=self.seed * 1000003 + self.window_no, stream=side)
             plan.fetch(self.host_ptrs, False, stream=side)
             if self.victims is not None:
                 plan.victims(self.victims[self._vnext], stream=side)
-            if window_idx.is_cuda:
+            if isinstance(window_idx, torch.Tensor) and window_idx.is_cuda:
                 window_idx.record_stream(side)
             self.planned = S.new_event(self.dev)
             self.planned.record(side)

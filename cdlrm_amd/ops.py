@@ -193,6 +193,16 @@ class WindowPlan:
         check(_lib.lib().cdlrm_window_unique(self.ctx.handle, C.byref(self.c), idx.data_ptr(), idx.shape[1],
                                              idx.stride(0), stream_ptr(stream)))
 
+    def unique_add(self, idx: torch.Tensor, stream=None):
+        """Streamed K1: fold one chunk [T, n] of the window into the bitmap (any number of chunks, then unique_finish)."""
+        _require_cuda(idx, "window indices")
+        assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.shape[0] == self.ctx.T and idx.stride(1) == 1
+        check(_lib.lib().cdlrm_window_unique_add(self.ctx.handle, C.byref(self.c), idx.data_ptr(), idx.shape[1],
+                                                 idx.stride(0), stream_ptr(stream)))
+
+    def unique_finish(self, stream=None):
+        check(_lib.lib().cdlrm_window_unique_finish(self.ctx.handle, C.byref(self.c), stream_ptr(stream)))
+
     def set_unique(self, uniqs: Sequence[torch.Tensor]):
         """CacheEmbeddings drop-in entry: the caller already has the sorted unique lists."""
         off = [0]

@@ -157,6 +157,12 @@ typedef struct {
  * popcount scan.  idx: device int64 [T, n] (row stride ld_idx).  Fills plan->uniq / uniq_off. */
 int cdlrm_window_unique(cdlrm_ctx* ctx, const cdlrm_plan* plan, const int64_t* idx, int64_t n,
                         int64_t ld_idx, void* stream);
+/* K1 streamed (cache_manager.py:85-110 collects a window batch by batch): _add folds one chunk [T, n] of the window
+ * into the plan's bitmap, any number of times; _finish emits uniq / uniq_off for everything added since the last
+ * finish and leaves the bitmap zero.  cdlrm_window_unique == one _add + _finish. */
+int cdlrm_window_unique_add(cdlrm_ctx* ctx, const cdlrm_plan* plan, const int64_t* idx, int64_t n,
+                            int64_t ld_idx, void* stream);
+int cdlrm_window_unique_finish(cdlrm_ctx* ctx, const cdlrm_plan* plan, void* stream);
 
 /* K2: tag probe of the unique list + full-set filter (main_no_ddp.py:155-180).
  * Fills hit / prot / kept / kept_off.  uniq and uniq_off must be valid (from cdlrm_window_unique or

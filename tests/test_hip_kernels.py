@@ -709,3 +709,30 @@ def test_head_vs_torch_fp32(ops, B, K, x_act):
     np.testing.assert_allclose(dZ.cpu().numpy(), pre.grad.numpy(), rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(dYd[:, :K].cpu().numpy(), (Yr.grad * mask).numpy(), rtol=1e-4, atol=1e-9)
     assert float(scratch[0]) == 0.0
+
+
+def test_streamed_window_unique_equals_one_shot(ops):
+    """cdlrm_window_unique_add x k + _finish (a window fed in chunks) gives the sorted unique lists of the one-shot
+    scan over the concatenated window, and leaves the bitmap ready for the next window."""
+    rng = np.random.RandomState(12)
+    ln_emb = [5000, 64, 70000, 3]
+    D, ways, aux, cache_sizes = 8, 4, 64, [100, 64, 100, 3]
+    st = DevState(ops, ln_emb, cache_sizes, D, ways, aux,
+                  [torch.full((p, ways), -1, dtype=torch.int64) for p in cache_sizes],
+                  [torch.zeros(ways * p + aux, D) for p in cache_sizes], [torch.zeros(n, D) for n in ln_emb])
+    plan = ops.WindowPlan(st.ctx, 6000)
+    for rep in range(2):
+        chunks = [torch.stack([torch.from_numpy(rng.randint(0, n, size=m).astype(np.int64)) for n in ln_emb]).to(DEV)
+                  for m in (700, 1, 2048, 333)]
+        for c in chunks:
+            plan.unique_add(c)
+        plan.unique_finish()
+        uo, _, _ = plan.offsets()
+        got = plan.uniq[:uo[-1]].cpu().clone()
+        plan.unique(torch.cat(chunks, dim=1))
+        uo2, _, _ = plan.offsets()
+        assert uo == uo2 and torch.equal(got, plan.uniq[:uo2[-1]].cpu())
+        full = torch.cat(chunks, dim=1).cpu()
+        for k in range(len(ln_emb)):
+            assert torch.equal(got[uo[k]:uo[k + 1]], torch.unique(full[k]))
+    st.ctx.check()
