@@ -238,6 +238,7 @@ def main():
     t0 = time.perf_counter()
     for j in range(a.warmup, total_steps):
         run_step(j, True)
+    t_issued = time.perf_counter() - t0        # host time to ISSUE the steps (== dt when the host is the bottleneck)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -273,7 +274,8 @@ def main():
             "config": {"workload": cfg["name"] + (" [windows streamed to the plan in chunks of %d batches]" % C if C else ""),
                        "config_id": a.config, "global_batch": B, "local_batch": lbs,
                        "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
-                       "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1)},
+                       "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1),
+                       "host_issue_ms_per_step": t_issued / a.steps * 1e3},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

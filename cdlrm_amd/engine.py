@@ -382,6 +382,8 @@ class TrainEngine:
         # (weights offset, count, biases offset, count) of the bottom / top MLP inside the flat buffers
         self.rng_bot = (0, nw_bot, nw, nb_bot)
         self.rng_top = (nw_bot, nw - nw_bot, nw + nb_bot, nb - nb_bot)
+        # the weight-gradient ranges the two exchanges at world > 1 carry (top MLP's, bottom MLP's)
+        self._grad_views = (self.grad_flat[nw_bot:nw], self.grad_flat[0:nw_bot])
         off_w, off_b = 0, nw
         self.W, self.gW, self.gb = {}, {}, {}
         for l in lin:
@@ -528,19 +530,16 @@ class TrainEngine:
             # on the side stream right after the top dgrad chain) runs beside the rest of this step's backward and the
             # head of the next step; the bottom MLP's is the only one on the critical path
             wst, W = self.wst, float(self.world)
-            o, n_, ob, nb_ = self.rng_top
+            gt, gb = self._grad_views
             with S.on_stream(wst):
-                gt = self.grad_flat[o:o + n_]
                 ops.scale_div(gt, W, stream=wst)                 # layer.weight.grad /= world (:239); biases untouched
                 dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.pg)
-                ops.sgd_step2(self.param_flat, self.grad_flat, o, n_, ob, nb_, self.lr, stream=wst)
+                ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
                 self._events["top_updated"].record(wst)
-            o, n_, ob, nb_ = self.rng_bot
-            gb = self.grad_flat[o:o + n_]
             ops.scale_div(gb, W)
             dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=self.pg)
             S.current_stream(self.dev).wait_event(self._events["emb_done"])
-            ops.sgd_step2(self.param_flat, self.grad_flat, o, n_, ob, nb_, self.lr)
+            ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
             sgd_done = True
         elif self.world > 1:
             gw = self.grad_flat[:self.n_weight]
