@@ -151,6 +151,10 @@ def lib():
             raise CdlrmLibraryError(
                 "%s not found: build it with `make -C cdlrm_amd/csrc` (or __graft_entry__.build()). "
                 "cdlrm_amd has no CPU fallback for the cached training path." % LIB_PATH)
+        # torch first: it ships its own copy of the HIP runtime, and the process must end up with ONE runtime.  With
+        # libcdlrm_hip.so (linked against /opt/rocm's libamdhip64) loaded before torch, the library's first
+        # hipSetDevice() reported "no ROCm-capable device" (seen with build() followed by smoke() in one process).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
