@@ -970,6 +970,7 @@ extern "C" int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n
 // workgroup that arrives last (reproducible).  scratch: [0] arrival counter (zero before the first call; the kernel
 // leaves it zero), [1 .. grid] partial sums.
 // -------------------------------------------------------------------------------------------------
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ w,
                                               const float* __restrict__ bias, const float* __restrict__ T, int64_t B,
@@ -981,54 +982,90 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float b0 = bias ? bias[0] : 0.f;
     float lsum = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < B; row += (int64_t)gridDim.x * 4) {
-        const float* y = Y + row * ldy;
-        float acc = 0.f;
-        if (VEC) {
-            for (int k = lane * 4; k < K; k += 256) {
-                const float4 a = *reinterpret_cast<const float4*>(y + k);
-                const float4 ww = *reinterpret_cast<const float4*>(w + k);
-                acc = fmaf(a.x, ww.x, acc); acc = fmaf(a.y, ww.y, acc);
-                acc = fmaf(a.z, ww.z, acc); acc = fmaf(a.w, ww.w, acc);
-            }
-        } else {
-            for (int k = lane; k < K; k += 64) acc = fmaf(y[k], w[k], acc);
-        }
+    constexpr int R = 4;                            // rows a wave works on at once: R independent load chains in flight
+    const bool one = VEC && K <= 256;               // a row is one float4 per lane: kept in registers for the dY pass
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+    float4 w1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (one && lane * 4 < K) w1 = *reinterpret_cast<const float4*>(w + lane * 4);
+    for (int64_t r0 = wid * R; r0 < B; r0 += nw * R) {
+        float4 y1[R];
+        float acc[R], tt[R];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-        const float pre = acc + b0;
-        const float p = 1.0f / (1.0f + expf(-pre));
-        float zc, d;
-        const float l = loss_elem(p, T[row], c, B, &zc, &d);
-        d = d * ((1.0f - p) * p);                       // sigmoid backward: gradient w.r.t. the pre-activation
-        if (lane == 0) {
-            lsum += l;
-            Zout[row] = p;
-            if (Zc) Zc[row] = zc;
-            dZ[row] = d;
-        }
-        if (dY) {
-            float* dy = dY + row * lddy;
-            if (VEC) {
+        for (int i = 0; i < R; ++i) {               // all loads of the R rows first (clamped rows: results discarded)
+            const int64_t row = min(r0 + i, B - 1);
+            const float* y = Y + row * ldy;
+            tt[i] = T[row];
+            acc[i] = 0.f;
+            y1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (one) {
+                if (lane * 4 < K) y1[i] = *reinterpret_cast<const float4*>(y + lane * 4);
+            } else if (VEC) {
                 for (int k = lane * 4; k < K; k += 256) {
                     const float4 a = *reinterpret_cast<const float4*>(y + k);
                     const float4 ww = *reinterpret_cast<const float4*>(w + k);
+                    acc[i] = fmaf(a.x, ww.x, acc[i]); acc[i] = fmaf(a.y, ww.y, acc[i]);
+                    acc[i] = fmaf(a.z, ww.z, acc[i]); acc[i] = fmaf(a.w, ww.w, acc[i]);
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) acc[i] = fmaf(y[k], w[k], acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int64_t row = r0 + i;
+            if (one) {
+                acc[i] = fmaf(y1[i].x, w1.x, acc[i]); acc[i] = fmaf(y1[i].y, w1.y, acc[i]);
+                acc[i] = fmaf(y1[i].z, w1.z, acc[i]); acc[i] = fmaf(y1[i].w, w1.w, acc[i]);
+            }
+            float a = acc[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+            if (row >= B) continue;                 // wave-uniform
+            const float p = 1.0f / (1.0f + expf(-(a + b0)));
+            float zc, d;
+            const float l = loss_elem(p, tt[i], c, B, &zc, &d);
+            d = d * ((1.0f - p) * p);                   // sigmoid backward: gradient w.r.t. the pre-activation
+            if (lane == 0) {
+                lsum += l;
+                Zout[row] = p;
+                if (Zc) Zc[row] = zc;
+                dZ[row] = d;
+            }
+            if (!dY) continue;
+            const float* y = Y + row * ldy;
+            float* dy = dY + row * lddy;
+            if (one) {
+                if (lane * 4 < K) {
+                    float4 o = make_float4(d * w1.x, d * w1.y, d * w1.z, d * w1.w);
+                    if (x_act == 1) {
+                        o.x = y1[i].x > 0.f ? o.x : 0.f; o.y = y1[i].y > 0.f ? o.y : 0.f;
+                        o.z = y1[i].z > 0.f ? o.z : 0.f; o.w = y1[i].w > 0.f ? o.w : 0.f;
+                    } else if (x_act == 2) {
+                        o.x *= (1.0f - y1[i].x) * y1[i].x; o.y *= (1.0f - y1[i].y) * y1[i].y;
+                        o.z *= (1.0f - y1[i].z) * y1[i].z; o.w *= (1.0f - y1[i].w) * y1[i].w;
+                    }
+                    *reinterpret_cast<float4*>(dy + lane * 4) = o;
+                }
+            } else if (VEC) {
+                for (int k = lane * 4; k < K; k += 256) {
+                    const float4 av = *reinterpret_cast<const float4*>(y + k);
+                    const float4 ww = *reinterpret_cast<const float4*>(w + k);
                     float4 o = make_float4(d * ww.x, d * ww.y, d * ww.z, d * ww.w);
                     if (x_act == 1) {
-                        o.x = a.x > 0.f ? o.x : 0.f; o.y = a.y > 0.f ? o.y : 0.f;
-                        o.z = a.z > 0.f ? o.z : 0.f; o.w = a.w > 0.f ? o.w : 0.f;
+                        o.x = av.x > 0.f ? o.x : 0.f; o.y = av.y > 0.f ? o.y : 0.f;
+                        o.z = av.z > 0.f ? o.z : 0.f; o.w = av.w > 0.f ? o.w : 0.f;
                     } else if (x_act == 2) {
-                        o.x *= (1.0f - a.x) * a.x; o.y *= (1.0f - a.y) * a.y;
-                        o.z *= (1.0f - a.z) * a.z; o.w *= (1.0f - a.w) * a.w;
+                        o.x *= (1.0f - av.x) * av.x; o.y *= (1.0f - av.y) * av.y;
+                        o.z *= (1.0f - av.z) * av.z; o.w *= (1.0f - av.w) * av.w;
                     }
                     *reinterpret_cast<float4*>(dy + k) = o;
                 }
             } else {
                 for (int k = lane; k < K; k += 64) {
-                    const float a = y[k];
+                    const float av = y[k];
                     float o = d * w[k];
-                    if (x_act == 1) o = a > 0.f ? o : 0.f;
-                    else if (x_act == 2) o *= (1.0f - a) * a;
+                    if (x_act == 1) o = av > 0.f ? o : 0.f;
+                    else if (x_act == 2) o *= (1.0f - av) * av;
                     dy[k] = o;
                 }
             }
@@ -1056,6 +1093,8 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
     }
 }
 
+// <= 256 workgroups: every workgroup ends with one atomic on the arrival counter, and 2048 of them serialised there
+// cost more (78 us at B = 8192) than the rows; a wave takes 4 rows per pass instead (independent load chains)
 #define HEAD_MAX_BLOCKS 256
 extern "C" int64_t cdlrm_head_scratch_floats(void) { return 1 + HEAD_MAX_BLOCKS; }
 
@@ -1067,7 +1106,7 @@ extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, c
     CDLRM_REQUIRE(kind >= 0 && kind <= 2 && x_act >= 0 && x_act <= 2, "bad loss kind / activation");
     LossCfg c;
     c.kind = kind; c.w0 = w0; c.w1 = w1; c.thr = threshold;
-    int64_t gx = cdiv(B, 4);
+    int64_t gx = cdiv(B, 16);                       // 4 waves x 4 rows per pass
     if (gx > HEAD_MAX_BLOCKS) gx = HEAD_MAX_BLOCKS;
     const bool vec = K % 4 == 0 && ldy % 4 == 0 && (!dY || lddy % 4 == 0) && (((uintptr_t)Y | (uintptr_t)w | (uintptr_t)dY) & 15) == 0;
     if (vec)
