@@ -167,3 +167,28 @@ def test_synthetic_is_counter_based():
     # skew: the hottest id of the big table covers far more than 1/n of the lookups
     big = CriteoSynth([50000], 13, 4096, seed=1, alpha=1.05, device="cpu").window(0, 4)[0]
     assert torch.bincount(big).max().item() > 50 * big.numel() / 50000
+
+
+def test_square_bags_and_pad_window():
+    """engine.square_bags: ragged per-table index lists -> rectangular [T, n] + offsets [T, B + 1]; the pooled sums of
+    the real bags are unchanged, the padding lands in the extra bag and only repeats indices the batch already has."""
+    import torch
+    from cdlrm_amd.engine import pad_window, square_bags
+    lS_i = [torch.tensor([5, 9, 9, 2, 7]), torch.tensor([1, 4]), torch.tensor([3, 3, 3])]
+    lS_o = [torch.tensor([0, 2, 3]), torch.tensor([0, 1, 1]), torch.tensor([0, 1, 2])]     # table 1: bag 1 is empty
+    off, idx = square_bags(lS_o, lS_i, multiple=4)
+    assert off.shape == (3, 4) and idx.shape == (3, 8) and idx.dtype == torch.int64
+    for k in range(3):
+        n = lS_i[k].numel()
+        assert torch.equal(idx[k, :n], lS_i[k]) and bool((idx[k, n:] == lS_i[k][0]).all())
+        assert torch.equal(off[k, :3], lS_o[k]) and int(off[k, 3]) == n
+        W = torch.arange(40, dtype=torch.float32).view(10, 4)
+        want = torch.nn.functional.embedding_bag(lS_i[k], W, lS_o[k], mode="sum")
+        got = torch.nn.functional.embedding_bag(idx[k], W, off[k], mode="sum")
+        assert torch.equal(got[:3], want)                      # the real bags
+        assert set(idx[k].tolist()) == set(lS_i[k].tolist())   # no new index enters the batch / the window
+    # rectangular inputs pass through
+    o2, i2 = square_bags(torch.zeros(2, 3, dtype=torch.int64), torch.ones(2, 3, dtype=torch.int64))
+    assert o2.shape == (2, 3) and i2.shape == (2, 3)
+    win = pad_window([torch.tensor([4, 4, 1]), torch.tensor([7])])
+    assert win.shape == (2, 3) and win[1].tolist() == [7, 7, 7] and win[0].tolist() == [4, 4, 1]
