@@ -588,6 +588,26 @@ class TrainEngine:
                                                            out=self._probe_bufs(n, self._phase))
             probed = ev["probed_inline"]
             rec(probed.record, side)
+        n_bags = B if lS_o is None else lS_o.shape[1]
+
+        def gather(st):
+            if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
+                e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
+                e0.record(st)
+                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
+                e1.record(st)
+                gather_events.append((e0, e1))
+            else:
+                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
+
+        # Short local batches: the gather (6 us at 1024) goes to the SIDE stream, beside the bottom MLP's forward -- it
+        # needs the probe result and the previous step's embedding update, which ran on that very stream (in order: no
+        # event), not the bottom MLP.  Long batches: it is the HBM-roofline kernel and runs alone on the main stream.
+        side_gather = B < self.gather_alone_min and not (self.defer_top and self.cat)
+        if side_gather:
+            rec(side.wait_event, probed)
+            gather(side)
+            rec(ev["gathered"].record, side)
         cur = X
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
@@ -595,16 +615,12 @@ class TrainEngine:
             ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             bot_acts.append(y)
             cur = y
-        # the gather runs alone on the main stream (it is the HBM-roofline kernel: nothing competes for bandwidth)
-        rec(main.wait_event, probed)
-        if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
-            e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
-            e0.record(main)
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
-            e1.record(main)
-            gather_events.append((e0, e1))
+        if side_gather:
+            rec(main.wait_event, ev["gathered"])
         else:
-            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
+            # the gather runs alone on the main stream (it is the HBM-roofline kernel: nothing competes for bandwidth)
+            rec(main.wait_event, probed)
+            gather(main)
         if next_idx is not None and two_phase:
             # Software pipelining across iterations: the NEXT batch's tag probe and aux-row fill (~0.25 ms of PCIe
             # reads at c3) start right behind this batch's gather, on their own stream, into the OTHER aux region
@@ -628,7 +644,8 @@ class TrainEngine:
                               res=(res[0], res[1], res[2], evp))
         # the backward's sort of the slot ids needs nothing but the probe result: run it on the side, under the MLPs
         emb_work = self._emb_work(n)
-        rec(side.wait_event, probed)
+        if not side_gather:
+            rec(side.wait_event, probed)
         ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         if self.defer_top and not self.cat:
             # the previous step's top-MLP update (weight gradients read R / top_y / top_dy, then all-reduce and SGD on
