@@ -407,6 +407,18 @@ class TrainEngine:
             off_b += m
         self.r_width = kp[top0]
 
+    def _reduce_avg(self) -> bool:
+        """grad /= W followed by all-reduce(SUM) (main_no_ddp.py:239-244) as ONE all-reduce(AVG): on RCCL, for a
+        power-of-two world size -- dividing by 2, 4, 8 is exact in fp32 and commutes with every rounding of the sum, so the
+        result is bit-identical while one kernel launch per exchange disappears.  Other sizes / backends (gloo in the
+        tests) keep the reference's two steps."""
+        r = getattr(self, "_avg_ok", None)
+        if r is None:
+            W = self.world
+            r = (W & (W - 1)) == 0 and dist.get_backend(self.pg) == "nccl" and os.environ.get("CDLRM_REDUCE_AVG", "1") != "0"
+            self._avg_ok = r
+        return r
+
     def _buffers(self, B):
         if B in self._bufs:
             return self._bufs[B]
@@ -535,20 +547,30 @@ class TrainEngine:
             # head of the next step; the bottom MLP's is the only one on the critical path
             wst, W = self.wst, float(self.world)
             gt, gb = self._grad_views
+            avg = self._reduce_avg()
             with S.on_stream(wst):
-                ops.scale_div(gt, W, stream=wst)                 # layer.weight.grad /= world (:239); biases untouched
-                dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.pg)
+                if avg:
+                    dist.all_reduce(gt, op=dist.ReduceOp.AVG, group=self.pg)
+                else:
+                    ops.scale_div(gt, W, stream=wst)             # layer.weight.grad /= world (:239); biases untouched
+                    dist.all_reduce(gt, op=dist.ReduceOp.SUM, group=self.pg)
                 ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
                 self._events["top_updated"].record(wst)
-            ops.scale_div(gb, W)
-            dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=self.pg)
+            if avg:
+                dist.all_reduce(gb, op=dist.ReduceOp.AVG, group=self.pg)
+            else:
+                ops.scale_div(gb, W)
+                dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=self.pg)
             S.current_stream(self.dev).wait_event(self._events["emb_done"])
             ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
             sgd_done = True
         elif self.world > 1:
             gw = self.grad_flat[:self.n_weight]
-            ops.scale_div(gw, float(self.world))                 # layer.weight.grad /= world (:239); biases untouched
-            dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
+            if self._reduce_avg():
+                dist.all_reduce(gw, op=dist.ReduceOp.AVG, group=self.pg)
+            else:
+                ops.scale_div(gw, float(self.world))             # layer.weight.grad /= world (:239); biases untouched
+                dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=self.pg)
             # the join _fwd_bwd left out: the embedding backward / sparse SGD on the side stream ran beside the
             # all-reduce (the reference overlaps optimizer_embeds.step() with it the same way, :412-414)
             S.current_stream(self.dev).wait_event(self._events["emb_done"])
