@@ -314,3 +314,60 @@ def test_ragged_multihot_bags_vs_oracle(fixed, op):
         nrow = ways * cg.cache_sizes[k]
         np.testing.assert_allclose(cg.emb_l[k].weight[:nrow].cpu().numpy(), otr.weights[0][k][:nrow].numpy(),
                                    rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("m_spa", [256, 64])
+def test_embed_dim_256_engine_vs_oracle(m_spa):
+    """BASELINE config c4's embedding width (256; 64 for the middle template) through every kernel of the step: probe,
+    gather, interaction (MFMA), MLPs, embedding backward + sparse SGD, window insert / evict -- loss per iteration,
+    tags, cache rows against the oracle's trainer."""
+    from cdlrm_amd.engine import TrainEngine, WindowPipeline
+    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group, Embedding_Table_Group
+    from oracle import cdlrm_oracle as O
+    ln_emb, B, L, ways, cache_size, seed = [2000, 30, 5, 900, 20000, 64], 96, 3, 4, 48, 29
+    ln_bot = np.array([13, 64, m_spa])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 64, 1])
+    rng = np.random.RandomState(8)
+    batches = []
+    for j in range(9):
+        X = torch.from_numpy(rng.rand(B, 13).astype(np.float32))
+        idx = torch.stack([torch.from_numpy((rng.zipf(1.2, size=B).astype(np.int64) * 2654435761 % n)) for n in ln_emb])
+        Tt = torch.from_numpy(np.round(rng.rand(B, 1)).astype(np.float32))
+        batches.append((X, idx, Tt))
+    torch.set_num_threads(1)
+    otr = O.OracleTrainer(ln_emb, m_spa, ln_bot, ln_top, cache_size=cache_size, num_ways=ways, mini_batch_size=B,
+                          lr=0.05, lr_embeds=0.2, lookahead=L, table_agg_freq=10 ** 9, seed=seed)
+    lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+    for j, (X, idx, Tt) in enumerate(batches):
+        if j % L == 0:
+            torch.manual_seed(600 + j)
+            otr.refill(torch.cat([b[1] for b in batches[j:j + L]], dim=1))
+        otr.step(j, X, lS_o, idx, Tt)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host = Embedding_Table_Group(m_spa, np.array(ln_emb)).pin()
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    cg = Embedding_Table_Cache_Group(m_spa, np.array(ln_emb), cache_size, B, ways).to(DEV)
+    dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(DEV)
+    eng = TrainEngine(cg, dl, host, lr=0.05, lr_embeds=0.2)
+    pipe = WindowPipeline(cg, host, L * B, parity_rng=True)
+    losses = []
+    dev_idx = [b[1].to(DEV) for b in batches]
+    for j, (X, idx, Tt) in enumerate(batches):
+        if j % L == 0:
+            torch.manual_seed(600 + j)
+            pipe.plan_window(torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV))
+            pipe.commit()
+            pipe.wait_writeback()
+        nxt = dev_idx[j + 1] if j + 1 < len(batches) and (j + 1) % L != 0 else None
+        losses.append(eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt)[0:1].clone())
+    cg.ctx.check()
+    np.testing.assert_allclose(np.array([float(x) for x in losses]), np.array([l[0] for l in otr.losses]), rtol=1e-5)
+    for k in range(len(ln_emb)):
+        assert torch.equal(cg.occupancy_tables[k].cpu(), otr.occ[k]), k
+        nrow = ways * cg.cache_sizes[k]
+        np.testing.assert_allclose(cg.emb_l[k].weight[:nrow].cpu().numpy(), otr.weights[0][k][:nrow].numpy(),
+                                   rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(host.emb_l[k].weight.data.numpy(), otr.host[k].numpy(), rtol=2e-5, atol=1e-7)
