@@ -39,7 +39,7 @@ CONFIGS = {
                tables="kaggle", D=32, bot=[13, 512, 256, 32], top=[512, 256, 1], B=2048, L=200, cache=50000, ways=8,
                agg=100, lr=0.1, lr_emb=0.3),
     # BASELINE.json configs[3] (embed-dim 256) is NOT a bench configuration: its host tables are 192 GB of pinned memory
-    # -- more than the one-GPU box has (a full-size attempt took the box down) -- and BASELINE.json lists it as a
+    # (the one full-size attempt ended with the box lost before the first step; not repeated) and BASELINE.json lists it as a
     # parity case: tests/test_engine_parity.py::test_embed_dim_256_engine_vs_oracle covers the 256-wide path.
     # BASELINE.json configs[4]
     "c5": dict(name="criteo-terabyte-shape synthetic large batch, D=128, B=65536, L=8000, cache 500k x 16-way",
