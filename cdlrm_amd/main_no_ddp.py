@@ -413,9 +413,13 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     test_samp = 0
                     total_test_acc = 0
                     for Xt, lS_ot, lS_it, Tt in test_ld:
-                        lS_it = torch.as_tensor(lS_it) if not isinstance(lS_it, (list, tuple)) else torch.stack(
-                            [torch.as_tensor(s).reshape(-1) for s in lS_it])
-                        Zt = eng.evaluate(Xt.to(dev), lS_it.contiguous().to(dev))
+                        if getattr(test_ld, "multi_hot", False):        # ragged multi-hot test batches
+                            Ot, It = square_bags([lS_ot[k] for k in range(len(ln_emb))], lS_it, dev)
+                            Zt = eng.evaluate(Xt.to(dev), It, Ot)
+                        else:
+                            lS_it = torch.as_tensor(lS_it) if not isinstance(lS_it, (list, tuple)) else torch.stack(
+                                [torch.as_tensor(s).reshape(-1) for s in lS_it])
+                            Zt = eng.evaluate(Xt.to(dev), lS_it.contiguous().to(dev))
                         S_ = Zt.cpu().numpy()
                         Tn = Tt.cpu().numpy()
                         total_test_acc += np.sum((np.round(S_, 0) == Tn).astype(np.uint32))
