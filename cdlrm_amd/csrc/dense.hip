@@ -293,7 +293,12 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
         int64_t kchunk = M;
         int zs = 1;
         if (!tiled.empty()) {
-            int64_t splits = cdiv(1024, tiles);
+            static int64_t target_wgs = 0;      // workgroups the grouped launch aims at (slabs = target / tiles)
+            if (target_wgs == 0) {
+                const char* e = getenv("CDLRM_WGRAD_WGS");
+                target_wgs = e && atol(e) > 0 ? atol(e) : 1024;
+            }
+            int64_t splits = cdiv(target_wgs, tiles);
             const int64_t smax = cdiv(M, 4 * GBK);
             if (splits > smax) splits = smax;
             if (splits < 1) splits = 1;
