@@ -103,7 +103,12 @@ PROTOTYPES = {
 
 _lib: Optional[C.CDLL] = None
 _proxy = None
-_tape: Optional[list] = None        # when a list: every library call is appended as (function, args) before it is made
+# Recording state is PER THREAD: while the trainer thread records a step, the window plan's background thread makes
+# library calls of its own (host gather, offsets), and the garbage collector may run a context's destructor -- none of
+# those may land on the step's tape (a recorded cdlrm_ctx_destroy would be replayed on a dangling handle every step).
+import threading as _threading
+
+_rec = _threading.local()           # _rec.tape: a list while this thread records, else absent / None
 
 
 class _Recording:
@@ -117,8 +122,9 @@ class _Recording:
         fn = getattr(self._cdll, name)          # AttributeError for an unknown symbol
 
         def call(*args):
-            if _tape is not None:
-                _tape.append((fn, args))
+            tape = getattr(_rec, "tape", None)
+            if tape is not None:
+                tape.append((fn, args))
             return fn(*args)
 
         call.__name__ = name
@@ -127,20 +133,25 @@ class _Recording:
 
 
 def start_recording(tape: list) -> None:
-    global _tape
-    _tape = tape
+    _rec.tape = tape
 
 
 def stop_recording() -> None:
-    global _tape
-    _tape = None
+    _rec.tape = None
 
 
 def record(fn, *args):
     """Run a non-library call (event record / stream wait) and, while recording, put it on the tape as well."""
-    if _tape is not None:
-        _tape.append((fn, args))
+    tape = getattr(_rec, "tape", None)
+    if tape is not None:
+        tape.append((fn, args))
     return fn(*args)
+
+
+def raw():
+    """The library WITHOUT the recording view: destructors and other calls that must never land on a step's tape."""
+    lib()
+    return _lib
 
 
 def lib():

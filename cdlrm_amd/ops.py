@@ -54,7 +54,8 @@ class CacheCtx:
     def __del__(self):
         try:
             if getattr(self, "handle", None):
-                _lib.lib().cdlrm_ctx_destroy(self.handle)
+                # straight to the library: the garbage collector may run this while a step is being recorded
+                _lib.raw().cdlrm_ctx_destroy(self.handle)
                 self.handle = None
         except Exception:
             pass

@@ -192,3 +192,27 @@ def test_square_bags_and_pad_window():
     assert o2.shape == (2, 3) and i2.shape == (2, 3)
     win = pad_window([torch.tensor([4, 4, 1]), torch.tensor([7])])
     assert win.shape == (2, 3) and win[1].tolist() == [7, 7, 7] and win[0].tolist() == [4, 4, 1]
+
+
+def test_tape_recording_is_per_thread_and_destructors_bypass_it():
+    """A step's launch tape must only see the recording thread's own calls: the window plan's background thread and
+    the garbage collector (CacheCtx.__del__ -> cdlrm_ctx_destroy) make library calls at arbitrary times; a destroy
+    recorded on a tape would be replayed on a dangling handle at every step."""
+    import threading
+    from cdlrm_amd import _lib, ops
+    tape = []
+    _lib.start_recording(tape)
+    try:
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(_lib.record(lambda: 7)))
+        t.start()
+        t.join()
+        assert seen == [7] and tape == [], "another thread's call landed on this thread's tape"
+        assert _lib.record(lambda: 3) == 3 and len(tape) == 1
+        # the proxy records, the raw library does not
+        assert _lib.lib().cdlrm_abi_version() == 1 and len(tape) == 2
+        assert _lib.raw().cdlrm_abi_version() == 1 and len(tape) == 2
+    finally:
+        _lib.stop_recording()
+    import inspect
+    assert "_lib.raw()" in inspect.getsource(ops.CacheCtx.__del__)
