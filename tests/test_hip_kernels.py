@@ -736,3 +736,46 @@ def test_streamed_window_unique_equals_one_shot(ops):
         for k in range(len(ln_emb)):
             assert torch.equal(got[uo[k]:uo[k + 1]], torch.unique(full[k]))
     st.ctx.check()
+
+
+@pytest.mark.parametrize("T,nb,D", [(3, 33, 16), (2, 129, 128)])
+def test_embbag_multihot_empty_bags_and_scratch_bag(ops, T, nb, D):
+    """The layout engine.square_bags() hands the kernels: per-table offsets with EMPTY bags in the middle, a trailing
+    extra bag that holds padding lookups and a zero gradient row -- forward against torch's embedding_bag, fused
+    backward + SGD against the oracle (the padding must leave every row bit-identical to the unpadded update)."""
+    rng = np.random.RandomState(T * 100 + nb)
+    P = 200
+    rows = 2 * P + 8
+    w0 = [torch.from_numpy(rng.randn(rows, D).astype(np.float32)) for _ in range(T)]
+    st = DevState(ops, [rows] * T, [P] * T, D, 2, 8, [torch.full((P, 2), -1, dtype=torch.int64)] * T, w0,
+                  [torch.zeros(rows, D)] * T)
+    real_b = nb - 1
+    lens = rng.randint(0, 6, size=(T, real_b))
+    lens[:, 0] = np.maximum(lens[:, 0], 1)                      # every table has at least one lookup
+    n_real = lens.sum(1)
+    n = int((n_real.max() + 31) // 32 * 32 + 32)                # squared-off width: every table gets padding
+    slots = np.zeros((T, n), dtype=np.int32)
+    offs = np.zeros((T, nb), dtype=np.int64)
+    for k in range(T):
+        s = rng.randint(0, 2 * P, size=n_real[k])
+        slots[k, :n_real[k]] = s
+        slots[k, n_real[k]:] = s[0]                             # padding repeats the table's first lookup
+        offs[k, :real_b] = np.concatenate([[0], np.cumsum(lens[k])[:-1]])
+        offs[k, real_b] = n_real[k]                             # the scratch bag
+    slots_t, offs_t = torch.from_numpy(slots).to(DEV), torch.from_numpy(offs).to(DEV)
+    out = torch.zeros(nb, T, D, device=DEV)
+    ops.embbag_fwd(st.ctx, slots_t, offs_t, out, T * D, D)
+    grad = torch.from_numpy(rng.randn(nb, T, D).astype(np.float32))
+    grad[real_b] = 0.0                                          # the scratch bag's gradient row is zero
+    work = ops.embbag_bwd_work(st.ctx, n, DEV)
+    ops.embbag_bwd_sgd(st.ctx, slots_t, offs_t, grad.to(DEV), T * D, D, 0.3, work, None)
+    torch.cuda.synchronize()
+    for k in range(T):
+        real_slots = torch.from_numpy(slots[k, :n_real[k]].astype(np.int64))
+        real_offs = torch.from_numpy(offs[k, :real_b])
+        want = torch.nn.functional.embedding_bag(real_slots, w0[k], real_offs, mode="sum")
+        np.testing.assert_allclose(out[:real_b, k].cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+        assert bool((want[lens[k] == 0] == 0).all())            # empty bags pool to zero
+        w = w0[k].clone()
+        O.embbag_bwd_sgd(w, real_slots, real_offs, grad[:real_b, k, :], 0.3)
+        np.testing.assert_allclose(st.w(k).numpy(), w.numpy(), rtol=2e-5, atol=2e-6)
