@@ -407,6 +407,10 @@ class TrainEngine:
             off_b += m
         self.r_width = kp[top0]
 
+    def _side_gather(self, B: int) -> bool:
+        """Short local batches run the gather on the side stream (see _fwd_bwd)."""
+        return B < self.gather_alone_min and not (self.defer_top and self.cat)
+
     def _reduce_avg(self) -> bool:
         """grad /= W followed by all-reduce(SUM) (main_no_ddp.py:239-244) as ONE all-reduce(AVG): on RCCL, for a
         power-of-two world size -- dividing by 2, 4, 8 is exact in fp32 and commutes with every rounding of the sum, so the
@@ -561,7 +565,8 @@ class TrainEngine:
             else:
                 ops.scale_div(gb, W)
                 dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=self.pg)
-            S.current_stream(self.dev).wait_event(self._events["emb_done"])
+            if next_idx is None or not (self._side_gather(B) and self.ctx.aux_phases >= 2):
+                S.current_stream(self.dev).wait_event(self._events["emb_done"])
             ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
             sgd_done = True
         elif self.world > 1:
@@ -580,6 +585,8 @@ class TrainEngine:
         if j is None:
             j = self.iter
         if j > 0 and j % self.agg_freq == 0:
+            if self._emb_done is not None:      # the merge reads (and the flag reset races with) this step's row updates
+                S.current_stream(self.dev).wait_event(self._emb_done)
             self.table_aggregate()
         self.iter += 1
         return self._buffers(B)["loss"]
@@ -629,7 +636,7 @@ class TrainEngine:
         # Short local batches: the gather (6 us at 1024) goes to the SIDE stream, beside the bottom MLP's forward -- it
         # needs the probe result and the previous step's embedding update, which ran on that very stream (in order: no
         # event), not the bottom MLP.  Long batches: it is the HBM-roofline kernel and runs alone on the main stream.
-        side_gather = B < self.gather_alone_min and not (self.defer_top and self.cat)
+        side_gather = self._side_gather(B)
         if side_gather:
             rec(side.wait_event, probed)
             gather(side)
@@ -782,8 +789,11 @@ class TrainEngine:
             return False # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
         if next_idx is None:
             rec(main.wait_stream, side)      # full join
-        else:
+        elif not (side_gather and two_phase):
             rec(main.wait_event, emb_done)   # cache rows are updated; the prefetched probe keeps running
+        # else: the next step's gather runs on the side stream, in order behind this embedding update, and its probe waits
+        # for emb_done on its own stream -- nothing on the main stream reads the cache rows before the next full join
+        # (window boundary, row merge, evaluate(), finish()), so the main queue is spared one more wait (6-8 us bubble)
         return sgd_included
 
     # ----------------------------------------------------------------------------------------------
@@ -822,6 +832,8 @@ class TrainEngine:
         MLP's weights, gradients or activation buffers outside step() / evaluate()."""
         if self.defer_top:
             S.current_stream(self.dev).wait_event(self._events["top_updated"])
+        if self._emb_done is not None:          # a pipelined short-batch step leaves the embedding update un-joined
+            S.current_stream(self.dev).wait_event(self._emb_done)
 
     def prediction(self, B: int) -> torch.Tensor:
         """Z of the last step at batch size B as DLRM_Net.forward returns it (clamped under --loss-threshold)."""
