@@ -343,6 +343,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
     for epoch in range(args.nepochs):
         it = iter(train_ld)
         window = []
+        carried_idx = None          # device indices of the batch whose probe the previous step already issued
         j = 0
         while True:
             if not window:
@@ -368,19 +369,27 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 pipe.wait_writeback()
                 caching_overhead.append(timer() - start)
             X, lS_o, lS_i, T = window.pop(0)
-            Or = None
+            Or = nxt = None
+            sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
+
+            def rank_indices(li):       # this rank's slice of a batch's indices, on the device
+                li = torch.as_tensor(li) if not isinstance(li, (list, tuple)) else torch.stack(
+                    [torch.as_tensor(s).reshape(-1) for s in li])
+                return li[:, sl].contiguous().to(dev)      # the day-file loader hands out X_cat^T (a strided view)
+
             if multi_hot:
                 Or, Ir = square_bags([lS_o[k] for k in range(len(ln_emb))], lS_i, dev)
                 Xr, Tr = X.to(dev), T.to(dev)
             else:
-                lS_i = torch.as_tensor(lS_i) if not isinstance(lS_i, (list, tuple)) else torch.stack(
-                    [torch.as_tensor(s).reshape(-1) for s in lS_i])
-                sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
                 Xr = X[sl, :].to(dev)
-                Ir = lS_i[:, sl].contiguous().to(dev)      # the day-file loader hands out X_cat^T (a strided view)
+                Ir = carried_idx if carried_idx is not None else rank_indices(lS_i)
                 Tr = T[sl, :].to(dev)
+                # the next batch of the SAME window (the look-ahead already holds it): its tag probe and aux-row fill run
+                # during this step instead of at the head of the next one
+                nxt = rank_indices(window[0][2]) if window else None
+                carried_idx = nxt
             t1 = time_wrap(rank)
-            lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j)
+            lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j, next_idx=nxt)
             t2 = time_wrap(rank)
             mbs = Tr.shape[0]
             Z = eng.prediction(Xr.shape[0])
