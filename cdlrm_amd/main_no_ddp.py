@@ -333,9 +333,14 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                       rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op,
                       loss=args.loss_function, loss_weights=loss_ws, defer_top_update=world > 1)
     L = args.lookahead
+    # --device-rng (performance mode): the plan of window w+1 is made while window w trains -- what the reference's
+    # Prefetcher process is for (cache_manager.py:66-115) -- with its rows gathered by CPU threads in the background.  The
+    # plan reads the tag state and the host rows as the previous commit left them, nothing the training changes, so the
+    # result is the synchronous plan's.  Parity mode draws the way choices in line at the boundary, as the reference does.
+    lookahead_plan = bool(args.device_rng) and os.environ.get("CDLRM_RUN_LOOKAHEAD", "1") != "0"
     pipe = WindowPipeline(cache_group, emb_tables, L * aux_rows * 2, parity_rng=not args.device_rng,
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
-                          world_size=world)
+                          world_size=world, host_gather=lookahead_plan)
 
     total_time = total_iter = total_samp = 0
     total_loss = total_accu = 0.0
@@ -343,31 +348,45 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
     for epoch in range(args.nepochs):
         it = iter(train_ld)
         window = []
+        next_window = None          # look-ahead plan: the window whose plan is already in flight
         carried_idx = None          # device indices of the batch whose probe the previous step already issued
         j = 0
+
+        def read_window():
+            win = []
+            for _ in range(L):
+                try:
+                    win.append(next(it))
+                except StopIteration:
+                    break
+            return win
+
+        def window_indices(win):
+            if multi_hot:           # ragged per-table lists: the plan only needs each table's set of indices
+                return pad_window([torch.cat([torch.as_tensor(b[2][k]).reshape(-1) for b in win])
+                                   for k in range(len(ln_emb))]).to(dev)
+            return torch.cat([torch.as_tensor(b[2]) if not isinstance(b[2], (list, tuple)) else
+                              torch.stack([torch.as_tensor(s).reshape(-1) for s in b[2]]) for b in win], dim=1).to(dev)
+
         while True:
             if not window:
-                # look-ahead: read the next L batches, plan their insert while nothing else is pending
-                for _ in range(L):
-                    try:
-                        window.append(next(it))
-                    except StopIteration:
-                        break
+                # look-ahead: the next L batches; their insert plan is made now, or was made while the last window trained
+                planned = next_window is not None
+                window, next_window = (next_window, None) if planned else (read_window(), None)
                 if not window:
                     break
                 start = timer()
-                if multi_hot:       # ragged per-table lists: the plan only needs each table's set of indices
-                    win_idx = pad_window([torch.cat([torch.as_tensor(b[2][k]).reshape(-1) for b in window])
-                                          for k in range(len(ln_emb))])
-                else:
-                    win_idx = torch.cat([torch.as_tensor(b[2]) if not isinstance(b[2], (list, tuple)) else
-                                         torch.stack([torch.as_tensor(s).reshape(-1) for s in b[2]]) for b in window], dim=1)
+                if not planned:
+                    pipe.plan_window(window_indices(window))
                 if world > 1:
                     eng.sync_touched_to_rank0()
-                pipe.plan_window(win_idx.to(dev))
                 pipe.commit()
                 pipe.wait_writeback()
                 caching_overhead.append(timer() - start)
+                if lookahead_plan:
+                    next_window = read_window() or None
+                    if next_window is not None:     # evictions are in the host tables: the next plan may read them
+                        pipe.plan_window(window_indices(next_window))
             X, lS_o, lS_i, T = window.pop(0)
             Or = nxt = None
             sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)

@@ -257,3 +257,35 @@ def test_main_cli_random_default_front_end(capsys):
     out = capsys.readouterr().out
     losses = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", out)]
     assert len(losses) == 8 and all(np.isfinite(losses)) and 0.0 < losses[-1] < 1.0
+
+
+def test_run_device_rng_lookahead_plan_equals_boundary_plan(capsys, monkeypatch):
+    """--device-rng: Run plans window w+1 in the background while window w trains (the reference's Prefetcher role).
+    Same printed losses and final tags as planning every window at its boundary."""
+    from cdlrm_amd.main_no_ddp import ProcessArgs, Run
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    ln_emb = np.array([3000, 50, 7, 1200, 40000])
+    m_spa, B, nb, seed = 16, 64, 14, 11
+    ln_bot = np.array([13, 32, 16])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+    args = ProcessArgs(FLAGS + ["--device-rng"])
+    np.random.seed(seed)
+    host0 = O.init_host_tables([int(n) for n in ln_emb], m_spa)
+    outs = []
+    for look in ("1", "0"):
+        monkeypatch.setenv("CDLRM_RUN_LOOKAHEAD", look)
+        eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+        for k in range(len(ln_emb)):
+            eg.emb_l[k].weight.data = host0[k].clone()
+        eg.pin()
+        capsys.readouterr()
+        eng = Run(0, m_spa, ln_emb, ln_bot, ln_top, _Loader(_loader(ln_emb, B, nb, 5)), None, None, None, None, eg, args)
+        printed = capsys.readouterr().out
+        eng.cg.ctx.check()
+        outs.append(([float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", printed)], eng.cg.tags.cpu().clone(),
+                     [e.weight.data.clone() for e in eg.emb_l]))
+    assert len(outs[0][0]) == nb - 1 and outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
