@@ -102,6 +102,72 @@ def cpu_baseline(cfg, ln_emb_full, seed):
                       "at 200k rows, cache %d x %d-way; %.1f s" % (L, L, B, D, min(cfg["cache"], 20000), cfg["ways"], dt)}
 
 
+def config_tables(cfg, max_ind_range=-1):
+    from cdlrm_amd import synth
+    tables = cfg["tables"]
+    ln_emb = list(synth.TERABYTE_COUNTS if tables == "terabyte" else synth.KAGGLE_COUNTS if tables == "kaggle" else tables)
+    if max_ind_range > 0:
+        ln_emb = [min(n, max_ind_range) for n in ln_emb]
+    return ln_emb
+
+
+def build_host_tables(config, *, seed, dev, rank=0, world=1, barrier=None, max_ind_range=-1):
+    """The host master tables of a bench configuration (pinned; /dev/shm-shared at world > 1)."""
+    from cdlrm_amd.hostmem import make_host_tables
+    cfg = CONFIGS[config]
+    return make_host_tables(config_tables(cfg, max_ind_range), cfg["D"], device=dev, seed=seed, rank=rank, world=world,
+                            shm_name="cdlrm_bench_%s" % os.environ.get("MASTER_PORT", "0"),
+                            barrier=barrier or (lambda: None))
+
+
+def build_workload(config, *, lookahead=-1, batch=-1, host=None, seed=123, dev=None, rank=0, world=1, barrier=None,
+                   alpha=1.05, max_ind_range=-1, cache_init="empty", write_back=True, defer_top=None):
+    """Everything one rank of a bench configuration trains with -- host tables, cache group, MLPs, engine, look-ahead
+    pipeline, synthetic input stream -- built exactly once here so that tests/test_config_shapes.py runs its full-size
+    property checks on the SAME objects the bench times."""
+    from cdlrm_amd import synth
+    from cdlrm_amd.engine import TrainEngine, WindowPipeline
+    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group
+    dev = dev or torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(CONFIGS[config])
+    if lookahead > 0:
+        cfg["L"] = lookahead
+    if batch > 0:          # development: emulate the per-rank batch of an N-GPU run on one GPU
+        cfg["B"] = batch
+        cfg["name"] += " [batch overridden to %d]" % batch
+    ln_emb = config_tables(cfg, max_ind_range)
+    D, B, L = cfg["D"], cfg["B"], cfg["L"]
+    nf = len(ln_emb) + 1
+    ln_bot = np.array(cfg["bot"])
+    ln_top = np.array([D + nf * (nf - 1) // 2] + cfg["top"])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if host is None:
+        host = build_host_tables(config, seed=seed, dev=dev, rank=rank, world=world, barrier=barrier,
+                                 max_ind_range=max_ind_range)
+    cg = Embedding_Table_Cache_Group(D, np.array(ln_emb), cfg["cache"], B, cfg["ways"], cache_init=cache_init,
+                                     device=dev).to(dev)
+    np.random.seed(seed)
+    dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
+    if defer_top is None:
+        # measured on one GPU: no gain (the side-stream weight gradients slow the main chain by what they save); with
+        # more ranks it takes the top MLP's all-reduce off the critical path
+        defer_top = os.environ.get("CDLRM_DEFER_TOP", "1" if world > 1 else "0") != "0"
+    eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
+                      table_agg_freq=cfg["agg"], table_agg_op="mean", defer_top_update=defer_top)
+    # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
+    # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
+    pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=seed, rank=rank, world_size=world,
+                          host_gather=os.environ.get("CDLRM_HOST_GATHER", "1") != "0",
+                          gather_threads=max(4, min(32, (os.cpu_count() or 8) // max(1, world))), write_back=write_back)
+    syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=seed, alpha=alpha, device=dev)
+    return dict(cfg=cfg, ln_emb=ln_emb, host=host, cg=cg, dl=dl, eng=eng, pipe=pipe, syn=syn, B=B, L=L, D=D)
+
+
+def pct(xs, q):
+    return float(np.percentile(np.asarray(xs, dtype=np.float64), q)) if len(xs) else None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,46 +193,12 @@ def main():
         if world > 1:
             dist.barrier()
 
-    from cdlrm_amd import synth
-    from cdlrm_amd.engine import TrainEngine, WindowPipeline
-    from cdlrm_amd.hostmem import make_host_tables
-    from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group
-
-    cfg = dict(CONFIGS[a.config])
-    if a.lookahead > 0:
-        cfg["L"] = a.lookahead
-    if a.batch > 0:          # development: emulate the per-rank batch of an N-GPU run on one GPU
-        cfg["B"] = a.batch
-        cfg["name"] += " [batch overridden to %d]" % a.batch
-    tables = cfg["tables"]
-    ln_emb = list(synth.TERABYTE_COUNTS if tables == "terabyte" else synth.KAGGLE_COUNTS if tables == "kaggle" else tables)
-    if a.max_ind_range > 0:
-        ln_emb = [min(n, a.max_ind_range) for n in ln_emb]
-    D, B, L = cfg["D"], cfg["B"], cfg["L"]
-    lbs = math.ceil(B / world)
-    nf = len(ln_emb) + 1
-    ln_bot = np.array(cfg["bot"])
-    ln_top = np.array([D + nf * (nf - 1) // 2] + cfg["top"])
-
     t_setup = time.perf_counter()
-    np.random.seed(a.seed)
-    torch.manual_seed(a.seed)
-    host = make_host_tables(ln_emb, D, device=dev, seed=a.seed, rank=rank, world=world,
-                            shm_name="cdlrm_bench_%s" % os.environ.get("MASTER_PORT", "0"), barrier=barrier)
-    cg = Embedding_Table_Cache_Group(D, np.array(ln_emb), cfg["cache"], B, cfg["ways"], cache_init="empty").to(dev)
-    np.random.seed(a.seed)
-    dl = DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
-    eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
-                      table_agg_freq=cfg["agg"], table_agg_op="mean",
-                      # measured on one GPU: no gain (the side-stream weight gradients slow the main chain by what they
-                      # save); with more ranks it takes the top MLP's all-reduce off the critical path
-                      defer_top_update=os.environ.get("CDLRM_DEFER_TOP", "1" if world > 1 else "0") != "0")
-    # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
-    # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
-    pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=a.seed, rank=rank, world_size=world,
-                          host_gather=os.environ.get("CDLRM_HOST_GATHER", "1") != "0",
-                          gather_threads=max(4, min(32, (os.cpu_count() or 8) // max(1, world))))
-    syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=a.seed, alpha=a.alpha, device=dev)
+    wl = build_workload(a.config, lookahead=a.lookahead, batch=a.batch, seed=a.seed, dev=dev, rank=rank, world=world,
+                        barrier=barrier, alpha=a.alpha, max_ind_range=a.max_ind_range)
+    cfg, ln_emb, cg, eng, pipe, syn = wl["cfg"], wl["ln_emb"], wl["cg"], wl["eng"], wl["pipe"], wl["syn"]
+    D, B, L = wl["D"], wl["B"], wl["L"]
+    lbs = math.ceil(B / world)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
@@ -197,24 +229,42 @@ def main():
     state = {"win": None, "next": None, "w": -1}
     plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
     ev_pairs = []
+    ev_flags = []                           # per sampled launch: did a window plan run beside it?
+    refills = {"commits": 0, "plans": 0, "merges": 0, "first_plan_ms": None, "first_commit_ms": None}
+    # the roofline kernel is sampled with HIP events on its own stream: every launch of a short run (the driver's
+    # 20-step run would otherwise keep 3 samples), every k-th of a long one
+    sample_every = 1 if a.steps < 64 else max(1, a.gather_sample)
 
-    def begin_window(w):
+    def begin_window(w, timed):
         if state["next"] is None:           # very first window: plan it synchronously
             state["next"] = get_window(w)
+            t_p = time.perf_counter()
             pipe.plan_window(state["next"])
+            if pipe._worker is not None:
+                pipe._worker.join()
+            torch.cuda.synchronize()
+            refills["first_plan_ms"] = (time.perf_counter() - t_p) * 1e3
         if world > 1:
             eng.sync_touched_to_rank0()
+        t_c = time.perf_counter() if refills["first_commit_ms"] is None else None
         pipe.commit()
+        if t_c is not None:
+            torch.cuda.synchronize()
+            refills["first_commit_ms"] = (time.perf_counter() - t_c) * 1e3
+        if timed:
+            refills["commits"] += 1
         state["win"], state["next"], state["w"] = state["next"], None, w
 
     def run_step(j, timed):
         w, jj = divmod(j, L)
         if jj == 0:
-            begin_window(w)
+            begin_window(w, timed)
         if jj == plan_at or (L == 1):
             pipe.wait_writeback()
             state["next"] = get_window(w + 1)
             pipe.plan_window(state["next"])
+            if timed:
+                refills["plans"] += 1
         if C:       # streamed windows: the steps read from the current chunk
             cid, jc = divmod(j, C)
             if state.get("cid") != cid:
@@ -226,11 +276,15 @@ def main():
         idx = win_t[:, col:col + lbs]
         X, T = syn.dense(j)
         X, T = X[rank * lbs:(rank + 1) * lbs], T[rank * lbs:(rank + 1) * lbs]
-        sample = timed and a.gather_sample > 0 and (j % a.gather_sample == 0)
+        sample = timed and a.gather_sample > 0 and (j % sample_every == 0)
         # eager mode: hand the next batch's indices over so its tag probe / aux fill run behind this step's backward
         nxt = None
         if jj + 1 < L and jj + 1 != plan_at and jloc + 1 < nloc:
             nxt = win_t[:, col + B:col + B + lbs]
+        if sample:
+            ev_flags.append(pipe.plan_in_flight())
+        if timed and world > 1 and jj > 0 and jj % cfg["agg"] == 0:
+            refills["merges"] += 1
         eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
 
     for j in range(a.warmup):
@@ -255,22 +309,27 @@ def main():
     loss = float(eng._bufs[lbs]["loss"][0])
 
     if rank == 0:
-        gather_ms = [e0.elapsed_time(e1) for e0, e1 in ev_pairs]
-        gather_ms = float(np.mean(gather_ms)) if gather_ms else float("nan")
+        g_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in ev_pairs]
+        gather_ms = float(np.mean(g_us)) * 1e-3 if g_us else float("nan")
         lookups = lbs * len(ln_emb)
         alg_bytes = lookups * (8 * D + 16)          # fp32 row read + fp32 row write + int64 index + int64 offset
         achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms == gather_ms and gather_ms > 0 else None
         # HBM traffic of the gather kernel comes from separate rocprofv3 --pmc passes of this same command (PMC
-        # counters cannot be read from inside the process); the committed summary applies only to its own workload
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if (pmc.get("workload") == a.config and pmc.get("n_gpus") == world and a.alpha == 1.05 and a.batch <= 0
-                    and a.max_ind_range <= 0):
-                traffic = pmc.get("hbm_bytes_per_launch")
+        # counters cannot be read from inside the process); a committed summary applies only to its own workload
+        traffic = traffic_src = None
+        for name in ("r02_gather_pmc_%s_a%s.json" % (a.config, ("%g" % a.alpha).replace(".", "p")), "r01_gather_pmc.json"):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                if (pmc.get("workload") == a.config and pmc.get("n_gpus") == world and pmc.get("alpha", 1.05) == a.alpha
+                        and a.batch <= 0 and a.max_ind_range <= 0):
+                    traffic, traffic_src = pmc.get("hbm_bytes_per_launch"), "profiles/" + name
+                    break
+        counter_rate = traffic / (gather_ms * 1e-3) / 1e9 if traffic and achieved else None
+        quiet = [u for u, f in zip(g_us, ev_flags) if not f]
         out = {
-            "metric": "training samples/sec, Criteo-Terabyte-shape synthetic (cached data-parallel DLRM step, refills included)",
+            "metric": "training samples/sec, Criteo-Terabyte-shape synthetic (cached data-parallel DLRM step; look-ahead "
+                      "refills that fall into the timed region included: see config.refills_in_timed_region)",
             "value": B * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -278,13 +337,34 @@ def main():
                        "config_id": a.config, "global_batch": B, "local_batch": lbs,
                        "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
                        "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1),
-                       "host_issue_ms_per_step": t_issued / a.steps * 1e3},
+                       "host_issue_ms_per_step": t_issued / a.steps * 1e3,
+                       # what of the look-ahead side fell INTO the timed steps (a 20-step run of a 3000-step window holds
+                       # none; the default 3000-step run crosses one boundary and one background plan)
+                       "refills_in_timed_region": {"window_commits": refills["commits"], "plans_launched": refills["plans"],
+                                                   "row_merges": refills["merges"]},
+                       # stand-alone cost of the first window's plan (unique scan, tag probe, way choice, row fetch:
+                       # runs in the background of the previous window in steady state) and of its commit (row swap +
+                       # tag write on the main stream: the only part on the critical path), for amortising over L
+                       "refill_cost": {"plan_ms_standalone": refills["first_plan_ms"],
+                                       "commit_ms": refills["first_commit_ms"],
+                                       "commit_ms_per_step_amortised": (refills["first_commit_ms"] / L)
+                                       if refills["first_commit_ms"] is not None else None}},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_gather_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         # `achieved` / `frac` count ALGORITHMIC bytes (every lookup reads a row); `traffic` is what the
+                         # HBM counters saw per launch (repeated rows of a skewed batch hit L2 / MALL), `frac_counter`
+                         # the same launch time priced on those bytes -- the true HBM rate
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_counter": counter_rate,
+                         "frac_counter": (counter_rate / HBM_PEAK_GBS) if counter_rate else None,
                          "bytes_per_launch": alg_bytes, "avg_launch_us": gather_ms * 1e3 if gather_ms == gather_ms else None,
-                         "launches_timed": len(ev_pairs)},
+                         "launch_us": {"p10": pct(g_us, 10), "p50": pct(g_us, 50), "p90": pct(g_us, 90),
+                                       "min": float(np.min(g_us)) if g_us else None,
+                                       "max": float(np.max(g_us)) if g_us else None,
+                                       "beside_a_window_plan": int(sum(ev_flags)),
+                                       "mean_without_those": float(np.mean(quiet)) if quiet else None},
+                         "launches_timed": len(ev_pairs), "sampled_every": sample_every},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ln_emb, a.seed)

@@ -41,8 +41,12 @@ struct cdlrm_ctx {
     const int64_t* vict_off = nullptr;
     const float* vict_rows = nullptr;
     int* d_err = nullptr;                // device error word
-    int64_t* d_scan = nullptr;           // block sums for the scans
+    int64_t* d_scan = nullptr;           // block sums for the scans of the window plan (plan stream)
     int64_t scan_cap = 0;
+    // block sums for the table-agg / sync-to-rank-0 compaction: those run on the MAIN stream while the plan of the
+    // next window may be scanning on the plan stream -- one scratch per path, never shared across streams
+    int64_t* d_scan_agg = nullptr;
+    int64_t scan_agg_cap = 0;
     int64_t* d_small = nullptr;          // small device scratch (counters), 256 int64
     int64_t* h_pinned = nullptr;         // pinned host staging for _sync reads, 1024 int64
 };
@@ -149,3 +153,4 @@ __device__ __forceinline__ int table_of(const int64_t* off, int T, int64_t p) {
 
 // scan utilities implemented in scan.hip
 int cdlrm_scan_reserve(cdlrm_ctx* ctx, int64_t nblocks);
+int cdlrm_scan_reserve_agg(cdlrm_ctx* ctx, int64_t nblocks);

@@ -82,6 +82,7 @@ extern "C" int cdlrm_ctx_destroy(cdlrm_ctx* c) {
         if (c->d_err) (void)hipFree(c->d_err);
         if (c->d_small) (void)hipFree(c->d_small);
         if (c->d_scan) (void)hipFree(c->d_scan);
+        if (c->d_scan_agg) (void)hipFree(c->d_scan_agg);
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
         (void)hipGetLastError();
     } catch (...) {

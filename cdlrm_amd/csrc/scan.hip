@@ -16,6 +16,16 @@ int cdlrm_scan_reserve(cdlrm_ctx* ctx, int64_t nblocks) {
     return 0;
 }
 
+int cdlrm_scan_reserve_agg(cdlrm_ctx* ctx, int64_t nblocks) {
+    if (nblocks <= ctx->scan_agg_cap) return 0;
+    if (ctx->d_scan_agg) (void)hipFree(ctx->d_scan_agg);      // hipFree waits for the kernels still reading it
+    ctx->d_scan_agg = nullptr;
+    ctx->scan_agg_cap = 0;
+    CDLRM_HIP_CHECK(hipMalloc(&ctx->d_scan_agg, sizeof(int64_t) * (nblocks + 1)));
+    ctx->scan_agg_cap = nblocks;
+    return 0;
+}
+
 __device__ __forceinline__ int load_flags16(const uint8_t* flags, int64_t base, int64_t n, uint8_t f[CF_PER_THREAD]) {
     int cnt = 0;
     if (base + CF_PER_THREAD <= n) {
@@ -113,17 +123,19 @@ __global__ void __launch_bounds__(CF_THREADS) k_cf_emit(uint8_t* flags, const in
 }
 
 int cdlrm_compact_flags(cdlrm_ctx* ctx, uint8_t* flags, const int64_t* d_n, int64_t n_max, int32_t* out32,
-                        int64_t* out64, int64_t cap, int64_t* d_count, int clear, hipStream_t s) {
+                        int64_t* out64, int64_t cap, int64_t* d_count, int clear, hipStream_t s, int64_t* scratch,
+                        int64_t scratch_cap) {
     if (n_max <= 0) {
         if (d_count) CDLRM_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
         return 0;
     }
     CDLRM_REQUIRE(((uintptr_t)flags & 15) == 0, "flags must be 16-byte aligned");
     const int64_t nblocks = cdiv(n_max, CF_PER_BLOCK);
-    CDLRM_REQUIRE(nblocks <= ctx->scan_cap, "scan scratch too small (cdlrm_scan_reserve)");
-    hipLaunchKernelGGL(k_cf_count, dim3((unsigned)nblocks), dim3(CF_THREADS), 0, s, flags, d_n, n_max, ctx->d_scan);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, ctx->d_scan, nblocks, d_count);
-    hipLaunchKernelGGL(k_cf_emit, dim3((unsigned)nblocks), dim3(CF_THREADS), 0, s, flags, d_n, n_max, ctx->d_scan,
+    if (!scratch) { scratch = ctx->d_scan; scratch_cap = ctx->scan_cap; }
+    CDLRM_REQUIRE(nblocks <= scratch_cap, "scan scratch too small (cdlrm_scan_reserve)");
+    hipLaunchKernelGGL(k_cf_count, dim3((unsigned)nblocks), dim3(CF_THREADS), 0, s, flags, d_n, n_max, scratch);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, scratch, nblocks, d_count);
+    hipLaunchKernelGGL(k_cf_emit, dim3((unsigned)nblocks), dim3(CF_THREADS), 0, s, flags, d_n, n_max, scratch,
                        out32, out64, cap, clear, ctx->d_err);
     CDLRM_LAUNCH_CHECK();
     return 0;

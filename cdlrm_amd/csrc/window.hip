@@ -743,10 +743,12 @@ __global__ void __launch_bounds__(256) k_agg_scatter(float4* __restrict__ weight
 extern "C" int cdlrm_agg_compact(cdlrm_ctx* ctx, uint8_t* touched, int64_t total_rows, int64_t* rows_out, int64_t cap,
                                  int64_t* count_out, void* stream) {
     CDLRM_REQUIRE(ctx && touched && rows_out && count_out, "null argument");
-    int rc = cdlrm_scan_reserve(ctx, cdiv(total_rows, 4096) + 1);
+    // own scratch: this runs on the caller's (main) stream while the next window's plan may be compacting on the
+    // plan stream with ctx->d_scan
+    int rc = cdlrm_scan_reserve_agg(ctx, cdiv(total_rows, 4096) + 1);
     if (rc) return rc;
     return cdlrm_compact_flags(ctx, touched, nullptr, total_rows, nullptr, rows_out, cap, count_out, 1,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, ctx->d_scan_agg, ctx->scan_agg_cap);
 }
 
 extern "C" int cdlrm_agg_gather(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, float scale, float* buf,

@@ -77,7 +77,7 @@ class WindowPipeline:
                  *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
                  world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None,
                  victim_rows: Optional[int] = None, host_gather: bool = False, gather_threads: int = 16,
-                 shard_fetch: Optional[bool] = None, process_group=None):
+                 shard_fetch: Optional[bool] = None, process_group=None, write_back: bool = True):
         """victim_rows: capacity (rows) of each of the two HBM buffers that hold the host rows of a window's
         non-cached indices (None: every unique index of a window, at most 8 GiB per buffer; 0: off -- every miss
         reads the host table over PCIe as the reference does).
@@ -90,8 +90,11 @@ class WindowPipeline:
         slices are exchanged over xGMI with one all-gather per list at the window boundary (commit(), main thread,
         same point of the step sequence on every rank).  Host-DRAM and PCIe traffic per window drop from
         world x (winners + victims) to 1 x; the reference instead broadcasts whole cache tables from rank 0
-        (main_no_ddp.py:318-319)."""
+        (main_no_ddp.py:318-319).
+        write_back=False: evicted rows are dropped instead of written to the host tables (repeatability tests that must
+        leave the host tables as they found them; never in training)."""
         self.cg, self.host = cache_group, host_tables
+        self.write_back = bool(write_back)
         self.ctx = cache_group.ctx
         self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
         if victim_rows is None:
@@ -278,11 +281,18 @@ class WindowPipeline:
         done.record(main)
         with S.on_stream(self.side):
             self.side.wait_event(done)
-            if self.rank == 0:      # evictions come from rank 0's copy only (main_no_ddp.py:208, 312-315)
+            if self.rank == 0 and self.write_back:   # evictions come from rank 0's copy only (main_no_ddp.py:208, 312-315)
                 self.plan.writeback(self.host_ptrs, self.avg, stream=self.side)
             self.written_back = S.new_event(self.dev)
             self.written_back.record(self.side)
         self.planned = None
+
+    def plan_in_flight(self) -> bool:
+        """Is the plan of the next window running right now (its kernels / DMA copies / CPU gather)?  bench.py flags the
+        roofline-kernel samples taken beside one."""
+        if self._worker is not None and self._worker.is_alive():
+            return True
+        return self.planned is not None and S.is_hip(self.dev) and not self.planned.query()
 
     def wait_writeback(self):
         """Host-side: the evicted rows are in the host tables (all ranks may read them afterwards)."""

@@ -222,10 +222,15 @@ class Embedding_Table_Cache_Group(nn.Module):
     Here both are views of two flat device buffers (`tags`, `weight`).
     """
 
-    def __init__(self, m_spa, ln_emb, max_cache_size, aux_table_size, num_ways, cache_init="normal", aux_phases=2):
+    def __init__(self, m_spa, ln_emb, max_cache_size, aux_table_size, num_ways, cache_init="normal", aux_phases=2,
+                 device=None):
         """aux_phases = 2 (default) appends a second aux region to every table so that the fused engine can fill the
         NEXT batch's miss rows while the current batch still trains on its own (engine.py); callers that never pass
-        aux_phase see exactly the reference's tables."""
+        aux_phase see exactly the reference's tables.
+        Build-only keywords (not in the reference's signature, model_no_ddp.py:102): cache_init ("normal" = the
+        reference's nn.EmbeddingBag default init drawn from the torch CPU generator; "zeros" / "empty" for synthetic
+        runs), aux_phases, device (allocate the "zeros" / "empty" buffers directly in HBM instead of moving 10-34 GB
+        through host memory with .to(device))."""
         super().__init__()
         self.aux_phases = max(1, int(aux_phases))
         self.ln_emb = np.asarray(ln_emb)
@@ -240,7 +245,8 @@ class Embedding_Table_Cache_Group(nn.Module):
         for k, r in enumerate(rows):
             self.row_base.append(self.row_base[-1] + r)
             self.tag_base.append(self.tag_base[-1] + self.cache_sizes[k] * self.num_ways)
-        w = torch.empty(self.row_base[-1], self.m_spa, dtype=torch.float32)
+        on_dev = device if (device is not None and cache_init in ("zeros", "empty")) else None
+        w = torch.empty(self.row_base[-1], self.m_spa, dtype=torch.float32, device=on_dev)
         if cache_init == "normal":
             # nn.EmbeddingBag default init, table by table, from the torch CPU generator (:138)
             # (only the reference's rows draw from the generator -- the insert's Exp(1) draws come from the same
@@ -254,7 +260,7 @@ class Embedding_Table_Cache_Group(nn.Module):
         elif cache_init != "empty":
             raise ValueError(cache_init)
         self.weight = nn.Parameter(w, requires_grad=False)
-        self.register_buffer("tags", torch.full((self.tag_base[-1],), -1, dtype=torch.int64))
+        self.register_buffer("tags", torch.full((self.tag_base[-1],), -1, dtype=torch.int64, device=on_dev))
         self.emb_l = [_CacheTable(self, k) for k in range(len(rows))]
         self.victim_cache_entries = _VictimEntries(len(rows))
         self._ctx: Optional[ops.CacheCtx] = None

@@ -247,6 +247,27 @@ def test_loss_trajectory_w1(golden, name):
         np.testing.assert_allclose(tr.top[0][0][i].numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["train_c3shape", "train_c2shape", "train_c5shape"])
+def test_loss_trajectory_config_shapes(golden, name):
+    """The oracle at the bench configurations' SHAPES (26 Criteo-cardinality tables, D = 128 / 32, 16- / 8-way, the
+    configs' MLP widths; tools/make_golden.py:g_train_shapes) against the imported reference's run."""
+    g = golden(name)
+    torch.set_num_threads(4)
+    try:
+        tr = run_oracle_training(g, 1)
+    finally:
+        torch.set_num_threads(1)
+    losses = np.array([l[0] for l in tr.losses])
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for k in range(len(g["ln_emb"])):
+        assert torch.equal(tr.occ[k], t(g[f"occ_{k}"]).to(torch.int64)), k         # tag state bit-exact
+        # (sums of ~1e6 values of magnitude 1e-2 that nearly cancel: absolute tolerance)
+        np.testing.assert_allclose(float(tr.host[k].double().sum()), float(g[f"host_sum_{k}"]), rtol=1e-6, atol=1e-4)
+        nrow = int(g["ways"]) * tr.cache_sizes[k]
+        np.testing.assert_allclose(float(tr.weights[0][k][:nrow].double().sum()), float(g[f"weight_sum_{k}"]),
+                                   rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("name", ["train_w2_mean", "train_w2_freq1", "train_w2_max"])
 def test_loss_trajectory_w2(golden, name):
     g = golden(name)

@@ -485,6 +485,51 @@ def g_train_w1(M, MD, CM, QR):
         save(name, **out)
 
 
+
+def g_train_shapes(M, MD, CM, QR):
+    """BASELINE.json configs c2 / c3 / c5 at the SHAPE the bench runs them -- 26 tables with the public Criteo
+    cardinalities (capped so the host tables fit this container), the config's embedding width, way count, MLP widths --
+    through the reference's own objects (ref_train).  These reach the kernel instantiations the headline bench uses
+    (16-lane / 16-way probes, the 26-table gather, D = 128 / 32 rows, the multi-pass slot sort at > 8192 lookups per
+    table) that the small fixtures above do not."""
+    KAGGLE = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992,
+              5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+    TERABYTE = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208,
+                11938, 155, 4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+    cap = lambda c, m: [min(n, m) for n in c]
+    cfgs = {
+        # c3 (README.md:7): D=128, 16-way, bot 13-512-256-128, top 512-512-256-1; B / L / cache scaled down
+        "train_c3shape": dict(ln_emb=cap(TERABYTE, 50000), m_spa=128, ln_bot=[13, 512, 256, 128], top=[512, 512, 256, 1],
+                              cache_size=1500, ways=16, B=1024, L=3, nbatch=9, seed=31, lr=0.8, lr_emb=0.8, alpha=1.05),
+        # c2: Kaggle cardinalities, D=32, 8-way, B=2048
+        "train_c2shape": dict(ln_emb=cap(KAGGLE, 50000), m_spa=32, ln_bot=[13, 512, 256, 32], top=[512, 256, 1],
+                              cache_size=1000, ways=8, B=2048, L=4, nbatch=12, seed=32, lr=0.1, lr_emb=0.3, alpha=1.1),
+        # c5: more than 8192 lookups per table and step (the slot sort takes its merge passes), 16-way
+        "train_c5shape": dict(ln_emb=cap(TERABYTE, 40000), m_spa=128, ln_bot=[13, 512, 256, 128], top=[512, 512, 256, 1],
+                              cache_size=4000, ways=16, B=12288, L=2, nbatch=6, seed=33, lr=0.8, lr_emb=0.8, alpha=1.05),
+    }
+    torch.set_num_threads(1)
+    for name, c in cfgs.items():
+        r = ref_train(M, MD, CM, QR, **c)
+        out = {k: np.array(v) for k, v in c.items()}
+        out["losses"] = r["losses"]
+        out["ln_top"] = r["ln_top"]
+        for k in range(len(c["ln_emb"])):
+            occ = r["cg"].occupancy_tables[k]
+            assert int(occ.max()) < 2 ** 31
+            out[f"occ_{k}"] = occ.to(torch.int32)           # ids < 2^31: int32 keeps the fixture small
+            w = r["cg"].emb_l[k].weight.data
+            out[f"weight_sum_{k}"] = w[: c["ways"] * r["cg"].cache_sizes[k]].double().sum()
+            out[f"host_sum_{k}"] = r["eg"].emb_l[k].weight.data.double().sum()
+        i = 0
+        for l in r["dl"].top_l:
+            if isinstance(l, torch.nn.Linear):
+                if l.weight.numel() <= 4096:                  # the narrow last layers only (fixture size)
+                    out[f"top_w{i}"] = l.weight.data.clone()
+                i += 1
+        save(name, **out)
+
+
 # ---- world-size-2 harness over gloo with the reference's own collective call sites -----------------
 
 
@@ -699,7 +744,7 @@ def g_criteo_loader(M, MD, CM, QR):
 
 GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
             dense_variants=g_dense_variants, random_data=g_random_data,
-            embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_w2=g_train_w2, qr=g_qr,
+            embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_shapes=g_train_shapes, train_w2=g_train_w2, qr=g_qr,
             window_groups=g_window_groups)
 
 
