@@ -234,6 +234,9 @@ def main():
     # the roofline kernel is sampled with HIP events on its own stream: every launch of a short run (the driver's
     # 20-step run would otherwise keep 3 samples), every k-th of a long one
     sample_every = 1 if a.steps < 64 else max(1, a.gather_sample)
+    # the timing events exist before the timed region starts; the two records per sampled step ride on the engine's tape
+    ev_pool = {j: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for j in range(a.warmup, total_steps) if a.gather_sample > 0 and j % sample_every == 0}
 
     def begin_window(w, timed):
         if state["next"] is None:           # very first window: plan it synchronously
@@ -283,9 +286,10 @@ def main():
             nxt = win_t[:, col + B:col + B + lbs]
         if sample:
             ev_flags.append(pipe.plan_in_flight())
+            ev_pairs.append(ev_pool[j])
         if timed and world > 1 and jj > 0 and jj % cfg["agg"] == 0:
             refills["merges"] += 1
-        eng.step(X, idx, T, j=jj, gather_events=ev_pairs if sample else None, next_idx=nxt)
+        eng.step(X, idx, T, j=jj, gather_events=ev_pool[j] if sample else None, next_idx=nxt)
 
     for j in range(a.warmup):
         run_step(j, False)

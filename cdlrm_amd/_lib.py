@@ -78,8 +78,8 @@ PROTOTYPES = {
     "cdlrm_ctx_bind_victims": (C.c_int, [vp, C.POINTER(Victims)]),
     "cdlrm_gather_rows": (C.c_int, [vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_agg_compact": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, vp]),
-    "cdlrm_agg_gather": (C.c_int, [vp, vp, vp, c_f32, vp, c_i64, vp]),
-    "cdlrm_agg_scatter": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
+    "cdlrm_agg_gather": (C.c_int, [vp, vp, vp, c_f32, vp, c_i64, c_i64, vp]),
+    "cdlrm_agg_scatter": (C.c_int, [vp, vp, vp, vp, c_i64, c_i64, vp]),
     "cdlrm_interact_fwd": (C.c_int, [vp, c_i64, c_i32, c_i32, c_i32, vp, c_i64, vp]),
     "cdlrm_interact_bwd": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp]),
     "cdlrm_linear_fwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp]),
@@ -98,6 +98,7 @@ PROTOTYPES = {
     "cdlrm_sgd_step": (C.c_int, [vp, vp, c_i64, c_f32, vp]),
     "cdlrm_scale_div": (C.c_int, [vp, c_i64, c_f32, vp]),
     "cdlrm_scatter_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, C.c_int, vp]),
+    "cdlrm_blend_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_mark_rows": (C.c_int, [vp, vp, c_i64, vp, vp]),
 }
 

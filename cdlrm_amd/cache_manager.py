@@ -161,8 +161,14 @@ class Prefetcher:
                         continue
                     dev = embeddings.device if embeddings.is_cuda else torch.device("cuda", torch.cuda.current_device())
                     ops.scatter_rows(ptrs[k], idxs.to(dev, torch.int64).contiguous(),
-                                     embeddings.to(dev, torch.float32).contiguous(), average_on_writeback)
+                                     embeddings.to(dev, torch.float32).contiguous(), average_on_writeback,
+                                     distinct=False)
                 torch.cuda.synchronize()
+                # queue.Queue / Manager().Queue: lets a caller wait until the host tables hold the rows
+                # (`eviction_fifo.join()`); the reference offers no such point and reads whatever has landed
+                done = getattr(eviction_fifo, "task_done", None)
+                if done is not None:
+                    done()
         except queue.Empty:
             print('Eviction queue empty longer than expected. Exiting eviction manager...')
 

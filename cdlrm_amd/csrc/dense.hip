@@ -933,24 +933,31 @@ __global__ void __launch_bounds__(1024) k_loss_one(const float* __restrict__ Z, 
                                                    LossCfg c, float* __restrict__ loss, float* __restrict__ dZ,
                                                    float* __restrict__ Zc, int sigmoid_bwd) {
     __shared__ float red[16];
+    __shared__ int redc[16];
     float s = 0.f;
+    int ok = 0;
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const float p = Z[i];
+        const float t = T[i];
         float zc, d;
-        s += loss_elem(p, T[i], c, n, &zc, &d);
+        s += loss_elem(p, t, c, n, &zc, &d);
+        ok += rintf(zc) == t;                        // main_no_ddp.py:431: (np.round(S, 0) == T), half to even
         if (sigmoid_bwd) d = d * ((1.0f - p) * p);
         if (dZ) dZ[i] = d;
         if (Zc) Zc[i] = zc;
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_down(s, d, 64); ok += __shfl_down(ok, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redc[threadIdx.x >> 6] = ok; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float tot = 0.f;
+        int cnt = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) tot += red[w];
+        for (int w = 0; w < 16; ++w) { tot += red[w]; cnt += redc[w]; }
         loss[0] = tot / (float)n;
+        loss[1] = (float)cnt;                        // correct predictions of this batch
+        loss[2] = (tot / (float)n) * (float)n;       // L * mbs as the reference accumulates it (:433), in fp32
     }
 }
 
@@ -976,6 +983,10 @@ extern "C" int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n
 // leaves it zero), [1 .. grid] partial sums.
 // -------------------------------------------------------------------------------------------------
 
+// <= 256 workgroups: every workgroup ends with one atomic on the arrival counter, and 2048 of them serialised there
+// cost more (78 us at B = 8192) than the rows; a wave takes 4 rows per pass instead (independent load chains)
+#define HEAD_MAX_BLOCKS 256
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ w,
                                               const float* __restrict__ bias, const float* __restrict__ T, int64_t B,
@@ -983,10 +994,12 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
                                               float* __restrict__ Zc, float* __restrict__ dZ, float* __restrict__ dY,
                                               int64_t lddy, float* __restrict__ loss, float* __restrict__ scratch) {
     __shared__ float red[4];
+    __shared__ int redc[4];
     __shared__ unsigned last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float b0 = bias ? bias[0] : 0.f;
     float lsum = 0.f;
+    int nok = 0;
     constexpr int R = 4;                            // rows a wave works on at once: R independent load chains in flight
     const bool one = VEC && K <= 256;               // a row is one float4 per lane: kept in registers for the dY pass
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
@@ -1032,6 +1045,7 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
             d = d * ((1.0f - p) * p);                   // sigmoid backward: gradient w.r.t. the pre-activation
             if (lane == 0) {
                 lsum += l;
+                nok += rintf(zc) == tt[i];              // main_no_ddp.py:431: (np.round(S, 0) == T)
                 Zout[row] = p;
                 if (Zc) Zc[row] = zc;
                 dZ[row] = d;
@@ -1076,10 +1090,11 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
             }
         }
     }
-    if (lane == 0) red[wave] = lsum;
+    if (lane == 0) { red[wave] = lsum; redc[wave] = nok; }
     __syncthreads();
     if (threadIdx.x == 0) {
         scratch[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        scratch[1 + HEAD_MAX_BLOCKS + blockIdx.x] = (float)(redc[0] + redc[1] + redc[2] + redc[3]);
         __threadfence();
         last = atomicAdd(reinterpret_cast<unsigned*>(scratch), 1u);
     }
@@ -1087,21 +1102,23 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
     if (last == gridDim.x - 1 && wave == 0) {
         // fixed order for a given grid: lane i sums partials i, i + 64, ..., then a butterfly over the lanes
         __threadfence();
-        float s = 0.f;
-        for (unsigned i = lane; i < gridDim.x; i += 64) s += __builtin_nontemporal_load(scratch + 1 + i);
+        float s = 0.f, cnt = 0.f;
+        for (unsigned i = lane; i < gridDim.x; i += 64) {
+            s += __builtin_nontemporal_load(scratch + 1 + i);
+            cnt += __builtin_nontemporal_load(scratch + 1 + HEAD_MAX_BLOCKS + i);     // integers < 2^24: exact
+        }
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d, 64); cnt += __shfl_xor(cnt, d, 64); }
         if (lane == 0) {
             loss[0] = s / (float)B;
+            loss[1] = cnt;                              // correct predictions of this batch
+            loss[2] = (s / (float)B) * (float)B;        // L * mbs as the reference accumulates it (:433), in fp32
             *reinterpret_cast<unsigned*>(scratch) = 0u;
         }
     }
 }
 
-// <= 256 workgroups: every workgroup ends with one atomic on the arrival counter, and 2048 of them serialised there
-// cost more (78 us at B = 8192) than the rows; a wave takes 4 rows per pass instead (independent load chains)
-#define HEAD_MAX_BLOCKS 256
-extern "C" int64_t cdlrm_head_scratch_floats(void) { return 1 + HEAD_MAX_BLOCKS; }
+extern "C" int64_t cdlrm_head_scratch_floats(void) { return 1 + 2 * HEAD_MAX_BLOCKS; }
 
 extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
                                   int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold,

@@ -118,10 +118,14 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
                                                     int64_t ld_off, const float* __restrict__ grad, int64_t ld_bag,
                                                     int64_t ld_table, float lr, float4* __restrict__ partials,
                                                     int64_t pstride, int64_t* __restrict__ longlist,
-                                                    int32_t* __restrict__ longcount, uint8_t* __restrict__ touched) {
+                                                    int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
+                                                    int64_t aux_total) {
     constexpr int KM = (SEG_CH + LPR - 1) / LPR;
     const int t = blockIdx.y;
     const int64_t row_base = tab[t].row_base;
+    // aux rows (transient copies of host rows, rewritten by every forward) are never flagged: the cross-rank row merge
+    // leaves them alone, so it cannot collide with the NEXT batch's aux fill running ahead in the other aux region
+    const uint32_t first_aux = (uint32_t)(tab[t].rows - aux_total);
     const int c = threadIdx.x % LPR;
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
         }
         if (c == 0) {
             if (single) {
-                if (touched) touched[row_base + slot] = 1;
+                if (touched && slot < first_aux) touched[row_base + slot] = 1;
             } else if (head) {
                 const int li = atomicAdd(longcount, 1);
                 longlist[li] = ((int64_t)t << 40) | p;
@@ -199,7 +203,8 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
                                                   float4* __restrict__ weight, const uint64_t* __restrict__ keys,
                                                   int64_t n, float lr, const float4* __restrict__ partials,
                                                   int64_t pstride, const int64_t* __restrict__ longlist,
-                                                  const int32_t* __restrict__ longcount, uint8_t* __restrict__ touched) {
+                                                  const int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
+                                                  int64_t aux_total) {
     const int c = threadIdx.x % LPR;
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
@@ -224,7 +229,7 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
             w.z = fmaf(-lr, acc.z, w.z); w.w = fmaf(-lr, acc.w, w.w);
             weight[row * D4 + cc] = w;
         }
-        if (c == 0 && touched) touched[row] = 1;
+        if (c == 0 && touched && (int64_t)slot < tab[t].rows - aux_total) touched[row] = 1;
     }
 }
 
@@ -337,20 +342,21 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)T);
     float4* wt = reinterpret_cast<float4*>(ctx->weight);
+    const int64_t aux_total = (int64_t)ctx->aux * ctx->aux_phases;
 #define BWD_CALL(L)                                                                                                \
     if (offsets)                                                                                                   \
         hipLaunchKernelGGL((k_bwd_chunks<L, false>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, w.meta, offsets, n, \
                            n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
-                           touched);                                                                               \
+                           touched, aux_total);                                                                    \
     else                                                                                                           \
         hipLaunchKernelGGL((k_bwd_chunks<L, true>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, w.meta, offsets, n,  \
                            n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
-                           touched)
+                           touched, aux_total)
     DISPATCH_LPR_B(lpr, BWD_CALL)
 #undef BWD_CALL
     int64_t lx = cdiv((int64_t)T * (n / SEG_CH + 1), gpb);
     if (lx > 1024) lx = 1024;
-#define LONG_CALL(L) hipLaunchKernelGGL(k_bwd_long<L>, dim3((unsigned)lx), dim3(256), 0, s, ctx->d_tab, D4, wt, cur, n, lr, w.partials, w.pstride, w.longlist, w.longcount, touched)
+#define LONG_CALL(L) hipLaunchKernelGGL(k_bwd_long<L>, dim3((unsigned)lx), dim3(256), 0, s, ctx->d_tab, D4, wt, cur, n, lr, w.partials, w.pstride, w.longlist, w.longcount, touched, aux_total)
     DISPATCH_LPR_B(lpr, LONG_CALL)
 #undef LONG_CALL
     CDLRM_LAUNCH_CHECK();

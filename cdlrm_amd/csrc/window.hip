@@ -721,9 +721,9 @@ extern "C" int cdlrm_gather_rows(const float* src, const int64_t* index, int64_t
 // K13: table aggregation helpers (broadcast_and_aggregate, main_no_ddp.py:250-292)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_agg_gather(const float4* __restrict__ weight, const int64_t* __restrict__ rows,
-                                                    const int64_t* __restrict__ count, int64_t cap, int D4, float scale,
-                                                    float4* __restrict__ buf) {
-    const int64_t total = min(*count, cap) * D4;
+                                                    const int64_t* __restrict__ count, int64_t first, int64_t cap, int D4,
+                                                    float scale, float4* __restrict__ buf) {
+    const int64_t total = max((int64_t)0, min(*count - first, cap)) * D4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         float4 v = weight[rows[e / D4] * D4 + (e % D4)];
         // reference: weight[unique] / world_size  (:277) -- a true division, not a multiply
@@ -733,9 +733,9 @@ __global__ void __launch_bounds__(256) k_agg_gather(const float4* __restrict__ w
 }
 
 __global__ void __launch_bounds__(256) k_agg_scatter(float4* __restrict__ weight, const int64_t* __restrict__ rows,
-                                                     const int64_t* __restrict__ count, int64_t cap, int D4,
+                                                     const int64_t* __restrict__ count, int64_t first, int64_t cap, int D4,
                                                      const float4* __restrict__ buf) {
-    const int64_t total = min(*count, cap) * D4;
+    const int64_t total = max((int64_t)0, min(*count - first, cap)) * D4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
         weight[rows[e / D4] * D4 + (e % D4)] = buf[e];
 }
@@ -752,26 +752,26 @@ extern "C" int cdlrm_agg_compact(cdlrm_ctx* ctx, uint8_t* touched, int64_t total
 }
 
 extern "C" int cdlrm_agg_gather(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, float scale, float* buf,
-                                int64_t cap, void* stream) {
+                                int64_t cap, int64_t first, void* stream) {
     CDLRM_REQUIRE(ctx && rows && count && buf && ctx->weight, "null argument");
     if (cap == 0) return 0;
     int64_t gx = cdiv(cap * (ctx->D / 4), 256);
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(k_agg_gather, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(ctx->weight), rows, count, cap, ctx->D / 4, scale,
+                       reinterpret_cast<const float4*>(ctx->weight), rows, count, first, cap, ctx->D / 4, scale,
                        reinterpret_cast<float4*>(buf));
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, const float* buf, int64_t cap,
-                                 void* stream) {
+                                 int64_t first, void* stream) {
     CDLRM_REQUIRE(ctx && rows && count && buf && ctx->weight, "null argument");
     if (cap == 0) return 0;
     int64_t gx = cdiv(cap * (ctx->D / 4), 256);
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(k_agg_scatter, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<float4*>(ctx->weight), rows, count, cap, ctx->D / 4,
+                       reinterpret_cast<float4*>(ctx->weight), rows, count, first, cap, ctx->D / 4,
                        reinterpret_cast<const float4*>(buf));
     CDLRM_LAUNCH_CHECK();
     return 0;
@@ -807,6 +807,35 @@ extern "C" int cdlrm_scatter_rows(float* dst, const int64_t* index, const float*
     hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<float4*>(dst), index, reinterpret_cast<const float4*>(rows), count, dim / 4,
                        average);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[i, :] = (dst[index[i], :] + rows[i, :]) / 2: the gather half of the averaging write-back for index lists that
+// may repeat an index (every entry is computed from the OLD destination row, cache_manager.py:62)
+__global__ void __launch_bounds__(256) k_blend_rows(const float4* __restrict__ dst, const int64_t* __restrict__ index,
+                                                    const float4* __restrict__ rows, int64_t count, int D4,
+                                                    float4* __restrict__ out) {
+    const int64_t total = count * D4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / D4;
+        const int c = (int)(e % D4);
+        const float4 v = rows[e];
+        const float4 h = dst[index[r] * D4 + c];
+        out[e] = make_float4((h.x + v.x) / 2, (h.y + v.y) / 2, (h.z + v.z) / 2, (h.w + v.w) / 2);
+    }
+}
+
+extern "C" int cdlrm_blend_rows(const float* dst, const int64_t* index, const float* rows, int64_t count, int32_t dim,
+                                float* out, void* stream) {
+    CDLRM_REQUIRE(dst && index && rows && out && dim % 4 == 0, "bad argument");
+    CDLRM_REQUIRE((((uintptr_t)dst | (uintptr_t)rows | (uintptr_t)out) & 15) == 0, "16-byte aligned rows");
+    if (count == 0) return 0;
+    int64_t gx = cdiv(count * (dim / 4), 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_blend_rows, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(dst), index, reinterpret_cast<const float4*>(rows), count, dim / 4,
+                       reinterpret_cast<float4*>(out));
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

@@ -350,6 +350,9 @@ class TrainEngine:
         self.side = S.new_stream(self.dev)
         self.pref = S.new_stream(self.dev)          # next batch's tag probe + aux-row fill
         self.agg_rows = None
+        # rows per chunk of the touched-row merge (32 MB at D = 128: large enough for xGMI bandwidth, small enough that
+        # the gather of chunk i+1 hides under the reduction of chunk i)
+        self.agg_chunk_rows = int(os.environ.get("CDLRM_AGG_CHUNK_ROWS", str(1 << 16)))
         self._pref = None
         self._phase = 0                             # aux region of the batch being trained
         self._emb_done = None
@@ -373,6 +376,7 @@ class TrainEngine:
         # main stream: at 8192 the overlap buys 2 % (0.783 -> 0.766 ms) and costs the roofline kernel 6 points of its
         # own rate (35.4 -> 38.3 us, 78 % -> 72 % of peak)
         self.gather_alone_min = int(os.environ.get("CDLRM_GATHER_ALONE_MIN", "8192"))
+        self._gslot = None
         self._tapes = {}
         self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
 
@@ -489,6 +493,10 @@ class TrainEngine:
         self._bufs[B] = b
         return b
 
+    def _gather_mark(self, which, stream):
+        """Record the current step's start / stop timing event (a taped call: the event pair changes per step)."""
+        self._gslot[which].record(stream)
+
     def _probe_bufs(self, n, which):
         """(slots, miss_pos, miss_count) of one pipeline stage, allocated once: they are written and read on side
         streams, where the caching allocator's per-stream reuse rules would not protect per-call temporaries."""
@@ -515,25 +523,41 @@ class TrainEngine:
         if self.world == 1:
             return
         ctx = self.ctx
-        flags = self.cg.touched.clone()
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
-        if self.agg_rows is None:
-            self._agg_alloc()
-        ops.agg_compact(ctx, flags, self.agg_rows, self.agg_count)
-        self.agg_count_host.copy_(self.agg_count, non_blocking=True)
-        S.current_stream(self.dev).synchronize()
-        U = int(self.agg_count_host[0])
+        self._agg_alloc()
+        self._agg_flags.copy_(self.cg.touched)
+        dist.all_reduce(self._agg_flags, op=dist.ReduceOp.MAX, group=self.pg)
+        U = self._agg_list(self._agg_flags)
         if U == 0:
             return
-        buf = torch.empty(U, self.D, dtype=torch.float32, device=self.dev)
+        buf = self._agg_buffer(U)
         ops.agg_gather(ctx, self.agg_rows, self.agg_count, 1.0, buf, U)
         dist.broadcast(buf, src=0, group=self.pg)
         ops.agg_scatter(ctx, self.agg_rows, self.agg_count, buf, U)
 
     def _agg_alloc(self):
-        self.agg_rows = torch.empty(self.ctx.total_rows, dtype=torch.int64, device=self.dev)
-        self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.agg_count_host = S.pinned(torch.zeros(1, dtype=torch.int64), self.dev)
+        if self.agg_rows is None:
+            self.agg_rows = torch.empty(self.ctx.total_rows, dtype=torch.int64, device=self.dev)
+            self.agg_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.agg_count_host = S.pinned(torch.zeros(1, dtype=torch.int64), self.dev)
+            self._agg_flags = torch.zeros(self.ctx.total_rows, dtype=torch.uint8, device=self.dev)
+            self._agg_counted = S.new_event(self.dev)
+            self._agg_buf = None
+
+    def _agg_list(self, flags) -> int:
+        """flags -> sorted row list (device) and its length on the host.  The host waits for THIS copy only (an event
+        behind the compaction), not for the stream: kernels queued behind it keep the GPU busy meanwhile."""
+        ops.agg_compact(self.ctx, flags, self.agg_rows, self.agg_count)
+        self.agg_count_host.copy_(self.agg_count, non_blocking=True)
+        self._agg_counted.record(S.current_stream(self.dev))
+        self._agg_counted.synchronize()
+        return int(self.agg_count_host[0])
+
+    def _agg_buffer(self, U: int) -> torch.Tensor:
+        """[>= U, D] exchange buffer, kept between merges (grown by doubling: no allocation in a steady-state merge)."""
+        if self._agg_buf is None or self._agg_buf.shape[0] < U:
+            cap = 1 << max(12, (U - 1).bit_length())
+            self._agg_buf = torch.empty(min(cap, self.ctx.total_rows), self.D, dtype=torch.float32, device=self.dev)
+        return self._agg_buf[:U]
 
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
              j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None):
@@ -547,10 +571,19 @@ class TrainEngine:
             assert lS_o.shape[1] in (B, B + 1) and (self.world == 1 or lS_o.shape[1] == B)
         if j is None:
             j = self.iter
-        if self.world > 1 and j > 0 and j % self.agg_freq == 0:
-            next_idx = None      # the row merge below rewrites touched aux rows: no fill may be in flight
+        # (the row merge at the end of a table-agg step leaves aux rows alone -- the backward never flags them --, so the
+        #  next batch's probe / aux fill may run ahead across it like across any other step)
         sgd_done = False
-        if self.use_tape and gather_events is None and lS_o is None:
+        # bench.py: HIP timing events around the roofline kernel, on ITS stream -- a pre-created (start, stop) pair, or a
+        # list that receives a new pair.  The two records ride on the step's tape through `_gather_mark`.
+        if gather_events is None:
+            self._gslot = None
+        elif isinstance(gather_events, tuple):
+            self._gslot = gather_events
+        else:
+            self._gslot = (S.new_event(self.dev, True), S.new_event(self.dev, True))
+            gather_events.append(self._gslot)
+        if self.use_tape and lS_o is None:
             sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
             sgd_done = self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
@@ -594,10 +627,13 @@ class TrainEngine:
         # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
         if j is None:
             j = self.iter
-        if j > 0 and j % self.agg_freq == 0:
+        if self.world > 1 and j > 0 and j % self.agg_freq == 0:
+            # (one rank averages with itself, W[u] = W[u] / 1: nothing to do, and no flags are kept at world == 1)
             if self._emb_done is not None:      # the merge reads (and the flag reset races with) this step's row updates
                 S.current_stream(self.dev).wait_event(self._emb_done)
             self.table_aggregate()
+            # the next step's gather may run on the side stream: it has to see the merged rows
+            self.side.wait_stream(S.current_stream(self.dev))
         self.iter += 1
         return self._buffers(B)["loss"]
 
@@ -634,12 +670,10 @@ class TrainEngine:
         n_bags = B if lS_o is None else lS_o.shape[1]
 
         def gather(st):
-            if gather_events is not None:       # bench.py: HIP events around the roofline kernel, on ITS stream
-                e0, e1 = S.new_event(self.dev, True), S.new_event(self.dev, True)
-                e0.record(st)
+            if self._gslot is not None:         # bench.py: HIP events around the roofline kernel, on ITS stream
+                rec(self._gather_mark, 0, st)
                 ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
-                e1.record(st)
-                gather_events.append((e0, e1))
+                rec(self._gather_mark, 1, st)
             else:
                 ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
 
@@ -762,8 +796,8 @@ class TrainEngine:
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
         rec(ev["interacted"].record, main)
         rec(side.wait_event, ev["interacted"])
-        ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work, cg.touched,
-                             stream=side)
+        ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
+                             cg.touched if self.world > 1 else None, stream=side)
         emb_done = ev["emb_done"]
         rec(emb_done.record, side)
         self._emb_done = emb_done
@@ -865,7 +899,8 @@ class TrainEngine:
         phase = pref["phase"] if hit else self._phase
         nxt = next_idx is not None
         key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
-               next_idx.stride(0) if nxt else 0, (self.iter & 1) if self.ctx.aux_phases < 2 else 0)
+               next_idx.stride(0) if nxt else 0, (self.iter & 1) if self.ctx.aux_phases < 2 else 0,
+               self._gslot is not None)
         tape = self._tapes.get(key)
         if tape is None:
             calls = []
@@ -916,33 +951,63 @@ class TrainEngine:
 
     def table_aggregate(self):
         """broadcast_and_aggregate (main_no_ddp.py:250-292): average the rows any rank touched since the last
-        merge.  Slot ids are global, so the union of touched rows is an all-reduce(MAX) of the flag bytes; the
-        rows then travel as one compacted [U, D] buffer."""
+        merge.  Slot ids are global, so the union of touched rows is an all-reduce(MAX) of the flag bytes (the reference
+        all-gathers the slot lists and takes torch.unique per table); the rows then travel as ONE compacted [U, D]
+        buffer, in chunks: while chunk i is reduced over xGMI on the exchange stream, chunk i+1 is gathered and chunk
+        i-1 scattered back on the main stream.  No allocation in steady state; the host waits only for the row count."""
         cg, ctx = self.cg, self.ctx
         touched = cg.touched
         if self.world == 1:
-            # a single rank averages with itself: W[u] = W[u] / 1; only the bookkeeping is reset
             touched.zero_()
             return
+        main = S.current_stream(self.dev)
         dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=self.pg)
-        if self.agg_rows is None:
-            self._agg_alloc()
-        ops.agg_compact(ctx, touched, self.agg_rows, self.agg_count)
-        self.agg_count_host.copy_(self.agg_count, non_blocking=True)
-        S.current_stream(self.dev).synchronize()
-        U = int(self.agg_count_host[0])
+        self._agg_alloc()
+        U = self._agg_list(touched)                   # consumes (clears) the flags
         if U == 0:
             return
-        buf = torch.empty(U, self.D, dtype=torch.float32, device=self.dev)
+        buf = self._agg_buffer(U)
         if self.agg_op == "mean":
-            ops.agg_gather(ctx, self.agg_rows, self.agg_count, float(self.world), buf, U)
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            scale, rop = float(self.world), dist.ReduceOp.SUM
         elif self.agg_op == "sum":
-            ops.agg_gather(ctx, self.agg_rows, self.agg_count, 1.0, buf, U)
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            scale, rop = 1.0, dist.ReduceOp.SUM
         elif self.agg_op == "max":
-            ops.agg_gather(ctx, self.agg_rows, self.agg_count, 1.0, buf, U)
-            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.pg)
+            scale, rop = 1.0, dist.ReduceOp.MAX
         else:
             raise ValueError(self.agg_op)
-        ops.agg_scatter(ctx, self.agg_rows, self.agg_count, buf, U)
+        ch = self.agg_chunk_rows
+        nch = (U + ch - 1) // ch
+        if nch == 1 or self.comm is None or not S.is_hip(self.dev):
+            ops.agg_gather(ctx, self.agg_rows, self.agg_count, scale, buf, U)
+            dist.all_reduce(buf, op=rop, group=self.pg)
+            ops.agg_scatter(ctx, self.agg_rows, self.agg_count, buf, U)
+            return
+        comm = self.comm
+        gathered = [S.new_event(self.dev) for _ in range(nch)]
+        reduced = [S.new_event(self.dev) for _ in range(nch)]
+
+        def gather(i):
+            lo, hi = i * ch, min(U, (i + 1) * ch)
+            ops.agg_gather(ctx, self.agg_rows[lo:], self.agg_count, scale, buf[lo:hi], hi - lo, first=lo)
+            gathered[i].record(main)
+
+        def reduce(i):
+            lo, hi = i * ch, min(U, (i + 1) * ch)
+            with S.on_stream(comm):
+                comm.wait_event(gathered[i])
+                dist.all_reduce(buf[lo:hi], op=rop, group=self.pg)
+                reduced[i].record(comm)
+
+        def scatter(i):
+            lo, hi = i * ch, min(U, (i + 1) * ch)
+            main.wait_event(reduced[i])
+            ops.agg_scatter(ctx, self.agg_rows[lo:], self.agg_count, buf[lo:hi], hi - lo, first=lo)
+
+        gather(0)
+        for i in range(nch):
+            reduce(i)
+            if i + 1 < nch:
+                gather(i + 1)
+            if i >= 1:
+                scatter(i - 1)
+        scatter(nch - 1)

@@ -38,12 +38,25 @@ def make_host_tables(ln_emb: Sequence[int], m_spa: int, *, device, seed: int = 1
         eg._pinned = True
         return eg
     total = sum(ln) * m_spa
-    path = os.path.join("/dev/shm", shm_name)
+    # The backing file: created by rank 0 under a name nobody can predict, exclusively (O_EXCL: never an existing file),
+    # without following a symlink, readable by the owner only; the other ranks learn the name from rank 0.  (A fixed
+    # world-writable path could be pre-created or symlinked by another local user.)
+    import secrets
+    import torch.distributed as dist
+    name = [None]
     if rank == 0:
-        if os.path.exists(path):
-            os.unlink(path)
-        with open(path, "wb") as f:
-            f.truncate(total * 4)
+        name[0] = "%s_%s" % (shm_name, secrets.token_hex(8))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast_object_list(name, src=0)
+    elif world > 1:
+        raise RuntimeError("make_host_tables(world > 1) needs an initialised process group to share the table file's name")
+    path = os.path.join("/dev/shm", name[0])
+    if rank == 0:
+        fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        try:
+            os.ftruncate(fd, total * 4)
+        finally:
+            os.close(fd)
     barrier()
     flat = torch.from_file(path, shared=True, size=total, dtype=torch.float32)
     off = 0

@@ -251,18 +251,71 @@ def share_occupancy_tables(cache_group, occupancy_tables_fifos, rank):
         assert float(lo) == float(hi), "cache tag replicas differ between ranks"
 
 
+def _multi_rank() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+@torch.no_grad()
+def _take_rank0_rows(cache_group):
+    """Every cache row some rank updated since the last refill becomes rank 0's copy on every rank -- what the
+    reference's whole-cache broadcast from rank 0 (main_no_ddp.py:318-319) does to the rows that CAN differ between the
+    replicas.  The union of the ranks' touched-row flags (set by the fused backward) is compacted into one row list;
+    only those rows travel.  The flags are consumed."""
+    ctx, dev = cache_group.ctx, cache_group.weight.device
+    flags = cache_group.touched
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    rows = torch.empty(ctx.total_rows, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.agg_compact(ctx, flags, rows, count)           # clears the flags it lists
+    U = int(count.item())
+    if U == 0:
+        return
+    buf = torch.empty(U, ctx.D, dtype=torch.float32, device=dev)
+    ops.agg_gather(ctx, rows, count, 1.0, buf, U)
+    dist.broadcast(buf, src=0)
+    ops.agg_scatter(ctx, rows, count, buf, U)
+
+
 @torch.no_grad()
 def load_caches_and_broadcast(cache_group, batch_fifo, eviction_fifo, rank):
-    """main_no_ddp.py:309-321.  Reference: rank 0 inserts, then EVERY cache table is broadcast from rank 0
-    (10.9 GB at the README config).  Here every rank performs the same deterministic insert from the same window
-    payload (each rank's Prefetcher produces it), after first taking rank 0's copy of the rows that can differ
-    between ranks (those touched since the last merge) -- the same end state without the whole-cache broadcast.
-    Rank 0's draw of the way choice is shared so the replicas stay identical."""
-    cached_entries_per_table, lists_of_unique_idxs, unique_indices_maps = batch_fifo.get()
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if multi:
+    """main_no_ddp.py:309-321.  Reference: rank 0 takes the window from batch_fifo and inserts it, then EVERY cache
+    table is broadcast from rank 0 (10.9 GB at the README config).  Here: rank 0 alone takes the window from the FIFO
+    (as in the reference: the FIFO is one shared queue) and broadcasts the window's payload -- the unique lists and
+    their host rows, [U, D] instead of whole cache tables --, every rank first takes rank 0's copy of the rows that can
+    differ between the replicas, then performs the same deterministic insert (rank 0's Exp(1) generator state is shared
+    so the way choices agree).  Same end state on every rank as after the reference's broadcast."""
+    multi = _multi_rank()
+    dev = cache_group.weight.device
+    T = len(cache_group.cache_sizes)
+    if not multi:
+        cached_entries_per_table, lists_of_unique_idxs, unique_indices_maps = batch_fifo.get()
+    else:
+        payload = None
+        if rank == 0:
+            payload = batch_fifo.get()
+            sizes = [int(u.numel()) for u in payload[1]]
+        else:
+            sizes = None
+        box = [sizes]
+        dist.broadcast_object_list(box, src=0)
+        sizes = box[0]
+        n = sum(sizes)
+        D = cache_group.m_spa
+        uniq_flat = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        rows_flat = torch.empty(max(n, 1), D, dtype=torch.float32, device=dev)
+        if rank == 0 and n:
+            uniq_flat[:n] = torch.cat([u.reshape(-1).to(dev, torch.int64) for u in payload[1]])
+            rows_flat[:n] = torch.cat([r.to(dev, torch.float32).reshape(-1, D) for r in payload[0]])
+        dist.broadcast(uniq_flat, src=0)
+        dist.broadcast(rows_flat, src=0)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        lists_of_unique_idxs = [uniq_flat[offs[k]:offs[k + 1]] for k in range(T)]
+        cached_entries_per_table = [rows_flat[offs[k]:offs[k + 1]] for k in range(T)]
+        from .cache_manager import UniqueIndexMap
+        unique_indices_maps = [UniqueIndexMap(u) for u in lists_of_unique_idxs]
+        _take_rank0_rows(cache_group)
         # ranks other than 0 must consume the same Exp(1) stream as rank 0: share its generator state
-        state = torch.get_rng_state().to(cache_group.weight.device)
+        state = torch.get_rng_state().to(dev)
         dist.broadcast(state, src=0)
         torch.set_rng_state(state.cpu())
     CacheEmbeddings(cached_entries_per_table, lists_of_unique_idxs, unique_indices_maps, cache_group, eviction_fifo, rank)
@@ -342,15 +395,25 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
                           world_size=world, host_gather=lookahead_plan)
 
-    total_time = total_iter = total_samp = 0
-    total_loss = total_accu = 0.0
+    # Print statistics (main_no_ddp.py:427-476) stay on the device between print boundaries: the loss / head kernel leaves
+    # [loss, #correct, loss * mbs] per step, ONE small add per step folds them into a float64 accumulator, and the host
+    # reads (and, at world > 1, all-reduces) it every print_freq iterations only.  The reference synchronises the device
+    # twice per step for its timer (time_wrap, :401, 425) and moves Z and T to the host every step (:428-431); here the
+    # wall time between two print boundaries, minus the refills and the test loop inside it, is the ms/it it prints --
+    # the same quantity (iteration time without caching overhead) without stopping the pipeline every step.
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)        # [sum of correct, sum of loss * mbs]
+    total_iter = total_samp = 0
     caching_overhead = []
+    print_interval_stats = args.print_freq > 0
     for epoch in range(args.nepochs):
         it = iter(train_ld)
         window = []
         next_window = None          # look-ahead plan: the window whose plan is already in flight
         carried_idx = None          # device indices of the batch whose probe the previous step already issued
         j = 0
+        torch.cuda.synchronize(dev)
+        t_mark = time.time()        # start of the current print interval
+        t_excluded = 0.0            # refill + test time inside it
 
         def read_window():
             win = []
@@ -383,6 +446,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 pipe.commit()
                 pipe.wait_writeback()
                 caching_overhead.append(timer() - start)
+                t_excluded += caching_overhead[-1]
                 if lookahead_plan:
                     next_window = read_window() or None
                     if next_window is not None:     # evictions are in the host tables: the next plan may read them
@@ -407,52 +471,52 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 # during this step instead of at the head of the next one
                 nxt = rank_indices(window[0][2]) if window else None
                 carried_idx = nxt
-            t1 = time_wrap(rank)
             lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j, next_idx=nxt)
-            t2 = time_wrap(rank)
             mbs = Tr.shape[0]
-            Z = eng.prediction(Xr.shape[0])
-            stats = torch.stack([lossbuf[0] * mbs, (torch.round(Z) == Tr).sum().to(torch.float32),
-                                 torch.tensor(float(mbs), device=dev)])
-            if world > 1:
-                dist.all_reduce(stats)
-            total_time += t2 - t1
+            acc.add_(lossbuf[1:3])              # [#correct, loss * mbs] of this step, left there by the loss kernel
             total_iter += 1
-            if rank == 0:
-                s = stats.tolist()
-                total_loss += s[0] / world
-                total_accu += s[1] / world
-                total_samp += mbs
-                if j > 0 and j % args.print_freq == 0:
+            total_samp += mbs
+            last = (j == len(train_ld) - 1)
+            should_print = print_interval_stats and j > 0 and j % args.print_freq == 0
+            should_test = test_ld is not None and ((j > 0 and args.test_freq > 0 and j % args.test_freq == 0) or last)
+            if should_print:
+                if world > 1:
+                    dist.all_reduce(acc)
+                torch.cuda.synchronize(dev)
+                total_time = time.time() - t_mark - t_excluded
+                if rank == 0:
+                    s = acc.tolist()
                     gT = 1000.0 * total_time / total_iter
-                    gA = total_accu / total_samp
-                    gL = total_loss / total_samp
+                    gA = (s[0] / world) / total_samp
+                    gL = (s[1] / world) / total_samp
                     avg_caching_overhead = np.mean(caching_overhead) / args.lookahead if caching_overhead else 0.0
                     print('Epoch {}: Finished {}/{} in {} ms/it. Caching overhead = {}. Loss = {}, Train Acc = {}'.format(
                         epoch, j, len(train_ld), gT, 1000 * avg_caching_overhead, gL, gA), flush=True)
-                    total_time = total_iter = total_samp = 0
-                    total_loss = total_accu = 0.0
-                    caching_overhead = []
+                acc.zero_()
+                total_iter = total_samp = 0
+                caching_overhead = []
+                t_mark, t_excluded = time.time(), 0.0
+            if rank == 0 and should_test:
                 # Testing -- only rank 0 tests (main_no_ddp.py:478-494).  The reference's `j % args.test_freq == 0`
                 # with its default test_freq = -1 is true for every j; here test_freq <= 0 means "at the end only".
-                last = (j == len(train_ld) - 1)
-                if test_ld is not None and ((j > 0 and args.test_freq > 0 and j % args.test_freq == 0) or last):
-                    print('Testing at {}/{}....'.format(j, len(train_ld)), flush=True)
-                    test_samp = 0
-                    total_test_acc = 0
-                    for Xt, lS_ot, lS_it, Tt in test_ld:
-                        if getattr(test_ld, "multi_hot", False):        # ragged multi-hot test batches
-                            Ot, It = square_bags([lS_ot[k] for k in range(len(ln_emb))], lS_it, dev)
-                            Zt = eng.evaluate(Xt.to(dev), It, Ot)
-                        else:
-                            lS_it = torch.as_tensor(lS_it) if not isinstance(lS_it, (list, tuple)) else torch.stack(
-                                [torch.as_tensor(s).reshape(-1) for s in lS_it])
-                            Zt = eng.evaluate(Xt.to(dev), lS_it.contiguous().to(dev))
-                        S_ = Zt.cpu().numpy()
-                        Tn = Tt.cpu().numpy()
-                        total_test_acc += np.sum((np.round(S_, 0) == Tn).astype(np.uint32))
-                        test_samp += Tn.shape[0]
-                    print('Test accuracy = {}%'.format(100 * (total_test_acc / test_samp)), flush=True)
+                t_test = time.time()
+                print('Testing at {}/{}....'.format(j, len(train_ld)), flush=True)
+                test_samp = 0
+                total_test_acc = 0
+                for Xt, lS_ot, lS_it, Tt in test_ld:
+                    if getattr(test_ld, "multi_hot", False):        # ragged multi-hot test batches
+                        Ot, It = square_bags([lS_ot[k] for k in range(len(ln_emb))], lS_it, dev)
+                        Zt = eng.evaluate(Xt.to(dev), It, Ot)
+                    else:
+                        lS_it = torch.as_tensor(lS_it) if not isinstance(lS_it, (list, tuple)) else torch.stack(
+                            [torch.as_tensor(s).reshape(-1) for s in lS_it])
+                        Zt = eng.evaluate(Xt.to(dev), lS_it.contiguous().to(dev))
+                    S_ = Zt.cpu().numpy()
+                    Tn = Tt.cpu().numpy()
+                    total_test_acc += np.sum((np.round(S_, 0) == Tn).astype(np.uint32))
+                    test_samp += Tn.shape[0]
+                print('Test accuracy = {}%'.format(100 * (total_test_acc / test_samp)), flush=True)
+                t_excluded += time.time() - t_test
             j += 1
     eng.finish()
     torch.cuda.synchronize()
@@ -488,6 +552,9 @@ class _SyntheticLoader:
 
 
 def main(argv=None):
+    # The step's streams are tuned for the HIP runtime's default of 4 hardware queues per process (with 6 or 8 the c3
+    # step measured 1.39-1.42 ms instead of 0.79): pin the default before the first HIP call, as bench.py does.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     args = ProcessArgs(argv)
     np.random.seed(args.numpy_rand_seed)
     torch.manual_seed(args.numpy_rand_seed)
@@ -495,6 +562,12 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if "WORLD_SIZE" in os.environ:
         args.world_size = int(os.environ["WORLD_SIZE"])
+    if rank != local_rank:
+        # `Run(rank, ...)` keeps the reference's contract -- ONE integer that is both the device index and the
+        # distributed rank (main_no_ddp.py:324-344, single node, MASTER_ADDR=localhost) -- and the host tables are one
+        # /dev/shm mapping shared by the ranks of a node
+        sys.exit("ERROR: cdlrm_amd.main_no_ddp runs on one node (RANK %d != LOCAL_RANK %d), like the reference"
+                 % (rank, local_rank))
     ln_bot = np.fromstring(args.arch_mlp_bot, dtype=int, sep="-")
     if args.data_generation not in ("random", "criteo-synthetic", "dataset"):
         sys.exit("ERROR: --data-generation=%s is not supported (dataset | criteo-synthetic | random)" % args.data_generation)

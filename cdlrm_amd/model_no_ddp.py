@@ -71,10 +71,11 @@ class Embedding_Table_Group(nn.Module):
             self.md_flag = md_flag
             if self.md_flag:
                 self.md_threshold = md_threshold
-            if qr_flag or md_flag:
-                raise NotImplementedError(
-                    "the reference never wires QR/MD tables into the cached path (SURVEY.md 2.4); "
-                    "use cdlrm_amd.tricks for the stand-alone operators")
+            if md_flag:
+                # dead at the reference's CLI as well: md_solver turns m_spa into a per-table list
+                # (main_no_ddp.py:612-618) and the group is then built WITHOUT md_flag (:621), so nn.EmbeddingBag(n, <list>)
+                # raises there; cache rows have one width, so mixed widths have no cached semantics to match
+                raise NotImplementedError("mixed-dimension tables (--md-flag) are not part of the cached path")
             self.m_spa = m_spa
             self.emb_l = self.create_emb(m_spa, np.asarray(ln_emb), init)
 
@@ -82,6 +83,13 @@ class Embedding_Table_Group(nn.Module):
         emb_l = nn.ModuleList()
         for i in range(0, ln.size):
             n = int(ln[i])
+            if self.qr_flag and n > self.qr_threshold:
+                # model_no_ddp.py:52-56: tables above the threshold become quotient-remainder pairs (HIP operator,
+                # cdlrm_amd/tricks/qr_embedding_bag.py); no numpy draw is consumed for them, as in the reference
+                from .tricks.qr_embedding_bag import QREmbeddingBag
+                emb_l.append(QREmbeddingBag(n, m, self.qr_collisions, operation=self.qr_operation, mode="sum",
+                                            sparse=True))
+                continue
             if init == "numpy":
                 W = np.random.uniform(low=-np.sqrt(1 / n), high=np.sqrt(1 / n), size=(n, m)).astype(np.float32)
                 Wt = torch.from_numpy(W)
@@ -99,6 +107,8 @@ class Embedding_Table_Group(nn.Module):
         """Pinned (page-locked, GPU-mapped) copies of the tables; idempotent."""
         if not self._pinned:
             for E in self.emb_l:
+                if not hasattr(E, "weight"):
+                    continue
                 w = E.weight.data
                 if not w.is_pinned():
                     p = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
@@ -124,10 +134,18 @@ class Embedding_Table_Group(nn.Module):
         self._pinned = True
         return self
 
+    def _plain(self, E, k):
+        if not hasattr(E, "weight"):
+            # the reference fails the same way: fetch_unique_idx_slices reads E.weight (model_no_ddp.py:84), which a
+            # QREmbeddingBag (weight_q / weight_r) does not have -- QR tables cannot feed the cache
+            raise AttributeError("'%s' object has no attribute 'weight' (table %d is a quotient-remainder table; the "
+                                 "cached path needs plain host tables)" % (type(E).__name__, k))
+        return E
+
     def device_pointers(self) -> List[int]:
         if not self._pinned:
             self.pin()
-        return [int(E.weight.data.data_ptr()) for E in self.emb_l]
+        return [int(self._plain(E, k).weight.data.data_ptr()) for k, E in enumerate(self.emb_l)]
 
     def fetch_unique_idx_slices(self, lists_of_unique_indices):
         """rows[k] = W_host[k][uniq_k] (model_no_ddp.py:80-87), gathered by the GPU straight from the

@@ -301,14 +301,17 @@ def agg_compact(ctx: CacheCtx, touched: torch.Tensor, rows_out: torch.Tensor, co
 
 
 def agg_gather(ctx: CacheCtx, rows: torch.Tensor, count: torch.Tensor, scale: float, buf: torch.Tensor, cap: int,
-               stream=None):
+               stream=None, first: int = 0):
+    """buf[i] = weight[rows[i]] / scale for i < min(count - first, cap): `rows` points at entry `first` of the list
+    whose length is the device word `count` (chunked merges pass slices)."""
     check(_lib.lib().cdlrm_agg_gather(ctx.handle, rows.data_ptr(), count.data_ptr(), float(scale), buf.data_ptr(),
-                                      int(cap), stream_ptr(stream)))
+                                      int(cap), int(first), stream_ptr(stream)))
 
 
-def agg_scatter(ctx: CacheCtx, rows: torch.Tensor, count: torch.Tensor, buf: torch.Tensor, cap: int, stream=None):
+def agg_scatter(ctx: CacheCtx, rows: torch.Tensor, count: torch.Tensor, buf: torch.Tensor, cap: int, stream=None,
+                first: int = 0):
     check(_lib.lib().cdlrm_agg_scatter(ctx.handle, rows.data_ptr(), count.data_ptr(), buf.data_ptr(), int(cap),
-                                       stream_ptr(stream)))
+                                       int(first), stream_ptr(stream)))
 
 
 # ---- dense model -------------------------------------------------------------------------------------
@@ -458,9 +461,18 @@ def scale_div(x: torch.Tensor, divisor: float, stream=None):
     check(_lib.lib().cdlrm_scale_div(x.data_ptr(), x.numel(), float(divisor), stream_ptr(stream)))
 
 
-def scatter_rows(dst_ptr: int, index: torch.Tensor, rows: torch.Tensor, average: bool, stream=None):
+def scatter_rows(dst_ptr: int, index: torch.Tensor, rows: torch.Tensor, average: bool, stream=None,
+                 distinct: bool = True):
+    """dst[index[i]] = rows[i] (or the average with the old row).  distinct=False: the list may repeat an index (the
+    reference's eviction lists do): the averaging arm then blends every entry against the OLD destination row first
+    (cdlrm_blend_rows) and scatters the blended rows -- repeats carry identical rows, so the result is defined."""
     _require_cuda(index, "index"); _require_cuda(rows, "rows")
     assert rows.is_contiguous() and index.is_contiguous() and index.dtype == torch.int64
+    if average and not distinct:
+        out = torch.empty_like(rows)
+        check(_lib.lib().cdlrm_blend_rows(int(dst_ptr), index.data_ptr(), rows.data_ptr(), index.numel(), rows.shape[1],
+                                          out.data_ptr(), stream_ptr(stream)))
+        rows, average = out, False
     check(_lib.lib().cdlrm_scatter_rows(int(dst_ptr), index.data_ptr(), rows.data_ptr(), index.numel(), rows.shape[1],
                                         1 if average else 0, stream_ptr(stream)))
 

@@ -108,7 +108,8 @@ int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offset
  * slots summed in position order.  Also marks the touched rows for the table-agg merge.
  *   grad     device fp32, same addressing as `out` above (ld_bag / ld_table)
  *   work     device scratch, cdlrm_embbag_bwd_work_bytes(T, n) bytes
- *   touched  device uint8 [total cache rows] or NULL: set to 1 for every updated row
+ *   touched  device uint8 [total cache rows] or NULL: set to 1 for every updated row of the cache proper (aux rows --
+ *            transient copies of host rows, rewritten by every forward -- are never flagged)
  *            (replaces cache_group_idxs_window, main_no_ddp.py:417-423)                          */
 uint64_t cdlrm_embbag_bwd_work_bytes(int32_t num_tables, int64_t n, int32_t dim);
 /* The same in two halves: `prepare` (sort of the slot ids + run metadata into `work`) depends only on
@@ -231,9 +232,16 @@ int cdlrm_gather_rows(const float* src, const int64_t* index, int64_t count, int
                       float* out, void* stream);
 
 /* Generic row scatter used by the drop-in Prefetcher.eviction_manager (cache_manager.py:57-62):
- * dst[index[i], :] = rows[i, :], or (dst + rows) / 2 with average != 0.  dst is device-visible. */
+ * dst[index[i], :] = rows[i, :], or (dst + rows) / 2 with average != 0.  dst is device-visible.
+ * average != 0 reads and writes dst in one pass and therefore needs DISTINCT indices; an eviction list in the
+ * reference's format may repeat an index (one entry per claimant of an occupied slot, all carrying the same row,
+ * SURVEY App. A): blend it first with cdlrm_blend_rows -- every entry computed from the OLD destination row, as
+ * `W[idx] = (W[idx] + emb) / 2` (cache_manager.py:62) does -- then scatter the blended rows with average = 0. */
 int cdlrm_scatter_rows(float* dst, const int64_t* index, const float* rows, int64_t count,
                        int32_t dim, int average, void* stream);
+/* out[i, :] = (dst[index[i], :] + rows[i, :]) / 2   (the gather half of the averaging write-back) */
+int cdlrm_blend_rows(const float* dst, const int64_t* index, const float* rows, int64_t count,
+                     int32_t dim, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Quotient-remainder embedding bag, stand-alone operator (QREmbeddingBag.forward,
@@ -263,11 +271,14 @@ int cdlrm_mark_rows(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, uint8_t* to
  * cache_group_idxs, :270) and clear them.  rows_out device int64 [cap]; count_out device int64 [1]. */
 int cdlrm_agg_compact(cdlrm_ctx* ctx, uint8_t* touched, int64_t total_rows, int64_t* rows_out,
                       int64_t cap, int64_t* count_out, void* stream);
-/* buf[i,:] = weight[rows[i],:] * scale   (:273-281)   /   weight[rows[i],:] = buf[i,:]   (:288-292) */
+/* buf[i,:] = weight[rows[i],:] / scale   (:273-281)   /   weight[rows[i],:] = buf[i,:]   (:288-292)
+ * for i < min(*count - first, cap): `rows` / `buf` point at entry `first` of a list whose total length is the device
+ * word *count, so a merge can be cut into chunks (gather chunk i+1 while chunk i is reduced over xGMI) without the
+ * host knowing more than an upper bound. */
 int cdlrm_agg_gather(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, float scale,
-                     float* buf, int64_t cap, void* stream);
+                     float* buf, int64_t cap, int64_t first, void* stream);
 int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, const float* buf,
-                      int64_t cap, void* stream);
+                      int64_t cap, int64_t first, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense model: DLRM_Net (model_no_ddp.py:215-316), loss (main_no_ddp.py:212-221), SGD (:375, 415)
@@ -325,7 +336,10 @@ int cdlrm_bce_fwd_bwd(const float* Z, const float* target, int64_t n, float* los
 /* The loss with all its arms (main_no_ddp.py:212-221, 364-372) and the --loss-threshold clamp of the prediction
  * (model_no_ddp.py:311-314): kind 0 BCELoss(mean), 1 MSELoss(mean), 2 weighted BCE (w0 / w1 = --loss-weights for
  * target 0 / 1, mean of w[t] * BCE(none)); 0 < threshold < 1: z = clamp(Z, threshold, 1 - threshold), gradient only
- * where Z lies inside.  loss_out[0] = loss; dZ (may be NULL) = dL/dZ, times (1 - Z) Z when sigmoid_bwd != 0;
+ * where Z lies inside.  loss_out (>= 3 floats): [0] = loss, [1] = number of samples with round(prediction) == target
+ * (the train-accuracy count of main_no_ddp.py:431, round half to even as np.round), [2] = loss * n in fp32 (the term
+ * the reference adds to its running loss, :433) -- so a trainer keeps its print statistics on the device and reads them
+ * at print boundaries.  dZ (may be NULL) = dL/dZ, times (1 - Z) Z when sigmoid_bwd != 0;
  * Zc (may be NULL) = the clamped prediction the reference's DLRM_Net.forward returns. */
 int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t kind, float w0, float w1,
                        float threshold, float* loss_out, float* dZ, float* Zc, int32_t sigmoid_bwd, void* stream);
@@ -334,7 +348,8 @@ int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t k
  * NULL), the loss above, and the layer's input gradient.  Y [B, K] (row pitch ldy) is the layer's input, produced
  * by activation x_act (0 none, 1 ReLU, 2 sigmoid).  Outputs: Z [B] = sigmoid(Y w + b), Zc [B] (may be NULL) clamped
  * prediction, dZ [B] = dL/d(pre-activation of the last layer), dY [B, K] (pitch lddy; may be NULL) = dZ w^T times
- * the derivative of x_act, loss_out[0].  scratch: cdlrm_head_scratch_floats() floats, zeroed once by the caller. */
+ * the derivative of x_act, loss_out[0..2] as for cdlrm_loss_fwd_bwd.  scratch: cdlrm_head_scratch_floats() floats,
+ * zeroed once by the caller. */
 int64_t cdlrm_head_scratch_floats(void);
 int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
                        int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold, int32_t x_act,

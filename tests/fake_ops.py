@@ -107,8 +107,9 @@ def embbag_bwd_apply(ctx, n, offsets, grad, ld_bag, ld_table, lr, work, touched=
     for k in range(ctx.T):
         off = torch.arange(n) if offsets is None else offsets[k]
         O.embbag_bwd_sgd(ctx.w(k), slots[k].long(), off, grad[:, k, :], lr)
-        if touched is not None:
-            touched[ctx.row_base[k] + slots[k].long()] = 1
+        if touched is not None:     # like the kernel: aux rows are never flagged
+            sl = slots[k].long()
+            touched[ctx.row_base[k] + sl[sl < ctx.ways * ctx.cache_sets[k]]] = 1
 
 
 class WindowPlan:
@@ -179,13 +180,13 @@ def agg_compact(ctx, touched, rows_out, count_out, stream=None):
     touched.zero_()
 
 
-def agg_gather(ctx, rows, count, scale, buf, cap, stream=None):
-    U = int(count[0])
+def agg_gather(ctx, rows, count, scale, buf, cap, stream=None, first=0):
+    U = max(0, min(int(count[0]) - first, cap))
     buf[:U] = ctx.weight[rows[:U]] / scale if scale != 1.0 else ctx.weight[rows[:U]]
 
 
-def agg_scatter(ctx, rows, count, buf, cap, stream=None):
-    U = int(count[0])
+def agg_scatter(ctx, rows, count, buf, cap, stream=None, first=0):
+    U = max(0, min(int(count[0]) - first, cap))
     ctx.weight[rows[:U]] = buf[:U]
 
 

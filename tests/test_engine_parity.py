@@ -250,7 +250,12 @@ def test_engine_loss_and_interaction_arms_vs_oracle(op, loss, ws, thr, defer):
             pipe.plan_window(torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV))
             pipe.commit()
             pipe.wait_writeback()
-        losses.append(float(eng.step(X.to(DEV), idx.to(DEV), Tt.to(DEV), j=j)[0]))
+        lossbuf = eng.step(X.to(DEV), idx.to(DEV), Tt.to(DEV), j=j)
+        losses.append(float(lossbuf[0]))
+        # the print statistics the loss kernel leaves for Run (main_no_ddp.py:431-433): #correct and loss * mbs
+        Zp = eng.prediction(B)
+        assert float(lossbuf[1]) == float((torch.round(Zp) == Tt.to(DEV)).sum())
+        assert float(lossbuf[2]) == float(lossbuf[0] * B)
     Zg = eng.evaluate(batches[-1][0].to(DEV), batches[-1][1].to(DEV))
     cg.ctx.check()
     np.testing.assert_allclose(np.array(losses), np.array([l[0] for l in otr.losses]), rtol=1e-5)

@@ -14,18 +14,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, host_shared, ret, defer=False):
+def _worker(rank, world, port, name, host_shared, ret, defer=False, chunk=0):
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)        # a stuck worker says where, instead of a silent time-out
     try:
-        _worker_body(rank, world, port, name, host_shared, ret, defer)
+        _worker_body(rank, world, port, name, host_shared, ret, defer, chunk)
     except BaseException as e:      # a dead worker must fail the test, not hang it
         import traceback
         ret.put((rank, {"error": traceback.format_exc()}))
         raise
 
 
-def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
+def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -53,6 +53,8 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
     eng = engine.TrainEngine(cg, dl, eg, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), world_size=world, rank=rank,
                              table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]), defer_top_update=defer)
     pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
+    if chunk:       # the touched-row merge in chunks of `chunk` rows: gather i+1 / reduce i / scatter i-1 pipelined
+        eng.agg_chunk_rows = chunk
     lbs = B // world
     losses = []
     dev_idx = {}
@@ -82,16 +84,17 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,port,defer", [("train_w2_mean", 29821, False), ("train_w2_max", 29822, False),
-                                             ("train_w2_mean", 29823, True)])
-def test_two_ranks_one_gpu_match_reference(golden, name, port, defer):
+@pytest.mark.parametrize("name,port,defer,chunk", [("train_w2_mean", 29821, False, 0), ("train_w2_max", 29822, False, 0),
+                                                   ("train_w2_mean", 29823, True, 0), ("train_w2_freq1", 29824, True, 16),
+                                                   ("train_w2_max", 29825, False, 8)])
+def test_two_ranks_one_gpu_match_reference(golden, name, port, defer, chunk):
     from oracle import cdlrm_oracle as O
     g = golden(name)
     np.random.seed(int(g["seed"]))
     host = [h.share_memory_() for h in O.init_host_tables([int(x) for x in g["ln_emb"]], int(g["m_spa"]))]
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret, defer)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret, defer, chunk)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -184,6 +187,108 @@ def test_sharded_window_fetch_two_ranks():
         p.start()
     for _ in range(2):
         r, payload = ret.get(timeout=300)
+        assert "error" not in payload, payload["error"]
+    for p in procs:
+        p.join(timeout=60)
+
+
+def _overlap_worker(rank, world, port, host_shared, ret):
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        import cdlrm_amd.engine as engine
+        import cdlrm_amd.model_no_ddp as M
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = "cuda:0"
+        torch.cuda.set_device(0)
+        ln_emb, m_spa, B, L, ways, cache, nwin = np.array([6000, 90, 11, 2500, 30000]), 16, 128, 6, 4, 60, 4
+        lbs = B // world
+        nf = len(ln_emb) + 1
+        ln_bot, ln_top = np.array([13, 32, m_spa]), np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+        eg = M.Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+        for k in range(len(ln_emb)):
+            eg.emb_l[k].weight.data = host_shared[k]
+        eg.register_shared()
+        rng = np.random.RandomState(9)
+        wins = [torch.stack([torch.from_numpy((rng.zipf(1.15, size=L * B).astype(np.int64) * 2654435761 % n)) for n in ln_emb])
+                .to(dev) for _ in range(nwin)]
+        Xs = [torch.from_numpy(rng.rand(B, 13).astype(np.float32)).to(dev) for _ in range(L)]
+        Ts = [torch.from_numpy(np.round(rng.rand(B, 1)).astype(np.float32)).to(dev) for _ in range(L)]
+        host0 = [h.clone() for h in host_shared] if rank == 0 else None
+        out = {}
+        for lookahead in (True, False):
+            dist.barrier()
+            if rank == 0:
+                for h, h0 in zip(host_shared, host0):
+                    h.copy_(h0)
+            dist.barrier()
+            np.random.seed(3)
+            torch.manual_seed(3)
+            cg = M.Embedding_Table_Cache_Group(m_spa, ln_emb, cache, B, ways).to(dev)
+            dl = M.DLRM_Net(ln_bot, ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
+            eng = engine.TrainEngine(cg, dl, eg, lr=0.1, lr_embeds=0.3, world_size=world, rank=rank, table_agg_freq=1,
+                                     table_agg_op="mean", defer_top_update=True)
+            eng.agg_chunk_rows = 32
+            pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=False, seed=77, rank=rank, world_size=world,
+                                         host_gather=True, gather_threads=2)
+            losses, in_flight = [], 0
+            planned = False
+            for w in range(nwin):
+                if not planned:
+                    pipe.plan_window(wins[w])
+                eng.sync_touched_to_rank0()
+                pipe.commit()
+                pipe.wait_writeback()
+                planned = False
+                if lookahead and w + 1 < nwin:
+                    # the plan of window w+1 (scans + compactions on the plan stream, CPU row gather in a thread) runs
+                    # WHILE the steps below merge touched rows every iteration (compactions on the main stream)
+                    pipe.plan_window(wins[w + 1])
+                    planned = True
+                for jj in range(L):
+                    sl = slice(jj * B + rank * lbs, jj * B + (rank + 1) * lbs)
+                    nxt = wins[w][:, (jj + 1) * B + rank * lbs:(jj + 1) * B + (rank + 1) * lbs] if jj + 1 < L else None
+                    in_flight += int(pipe.plan_in_flight())
+                    lo = eng.step(Xs[jj][rank * lbs:(rank + 1) * lbs], wins[w][:, sl], Ts[jj][rank * lbs:(rank + 1) * lbs],
+                                  j=jj, next_idx=nxt)
+                    losses.append(lo[0:1].clone())
+            eng.finish()
+            cg.ctx.check()
+            torch.cuda.synchronize()
+            out[lookahead] = (torch.cat(losses).cpu(), cg.tags.cpu().clone(), cg.weight.data.cpu().clone(), in_flight)
+            dist.barrier()
+        a, b = out[True], out[False]
+        assert torch.equal(a[0], b[0]), "losses differ between the in-flight and the boundary plan"
+        assert torch.equal(a[1], b[1]), "tags"
+        assert torch.equal(a[2], b[2]), "cache rows"
+        ret.put((rank, {"ok": True, "in_flight": a[3]}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        ret.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+def test_plan_in_flight_while_rows_merge_every_step():
+    """Two ranks, --table-agg-freq=1 (a touched-row merge, i.e. a stream compaction on the MAIN stream, every step) while
+    the NEXT window's plan (its own compactions, on the plan stream) is in flight: the two compactions use separate
+    scratch, so the run equals -- bit for bit: losses, tags, every cache row -- the run that plans at the boundary with
+    nothing else in flight.  (With one shared block-sum scratch the scans overwrite each other: wrong winner lists.)"""
+    from oracle import cdlrm_oracle as O
+    np.random.seed(4)
+    host = [h.share_memory_() for h in O.init_host_tables([6000, 90, 11, 2500, 30000], 16)]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, 29851, host, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for _ in range(2):
+        r, payload = ret.get(timeout=400)
         assert "error" not in payload, payload["error"]
     for p in procs:
         p.join(timeout=60)
