@@ -44,9 +44,10 @@ class GatedLoader:
         self.n_groups = (n + L - 1) // L
         self.gates = [threading.Event() for _ in range(self.n_groups)]
         self.gates[0].set()
-        # batch index whose arrival flushes group g (cache_manager.py:91-93, 106-107): the first batch of group g+1, or
-        # the epoch's last batch
-        self.trigger = {min((g + 1) * L, n - 1): g for g in range(self.n_groups)}
+        # The reference flushes group g when the first batch of group g+1 arrives (or the epoch's last batch,
+        # cache_manager.py:91-93, 106-107); this package's Prefetcher emits it as soon as the group's own last batch has
+        # arrived.  Holding back the group's LAST batch is early enough for both.
+        self.trigger = {min(g * L + L - 1, n - 1): g for g in range(self.n_groups)}
 
     def __len__(self):
         return len(self.batches)
@@ -117,7 +118,7 @@ def test_reference_loop_prefetcher_fifo_refill_train(golden):
         E.backward()
         optimizer_embeds.step()
         optimizer_mlps.step()
-        losses.append(float(E))
+        losses.append(float(E.detach()))
         assert len(cache_group_idxs) == len(ln_emb) and cache_group_idxs[0].dtype == torch.int32
     finish_event.set()
     cm.join(timeout=15)
@@ -372,7 +373,7 @@ def _w2_worker(rid, port, name, host_shared, ret):
                 window = []
             else:
                 window.append(torch.stack(cgi))
-            losses.append(float(E))
+            losses.append(float(E.detach()))
         cache_group.ctx.check()
         lin = M._linears(dlrm.top_l)
         ret.put((rid, dict(losses=np.array(losses), occ=[o.cpu().numpy() for o in cache_group.occupancy_tables],
