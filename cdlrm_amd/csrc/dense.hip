@@ -4,7 +4,7 @@
 //
 // fp32 everywhere (1e-5 loss-trajectory parity): v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32
 // fma chain at the fp32 vector peak (MI355X_MICROARCH.md "Matrix cores").
-#include "gemm.h"
+#include "gemm_glds.h"
 
 
 // Linear forward with a short contraction (K <= 32: the first bottom layer reads the 13 dense features).  An MFMA

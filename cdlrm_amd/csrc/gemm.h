@@ -877,27 +877,3 @@ static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s
     return 0;
 }
 
-template <bool A_KC, bool B_KC>
-static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
-    if (g.K < 4) g.vecA = g.vecB = 0;
-    if (gemm_use_direct(g.M, g.N, splits)) {
-        launch_gemm_direct<A_KC, B_KC>(g, splits, s);
-        CDLRM_LAUNCH_CHECK();
-        return 0;
-    }
-    int tm, tn;
-    gemm_pick_tile(g.M, g.N, splits, &tm, &tn);
-    if (g.N <= 32) tn = 1;
-    if (g.M <= 32) tm = 1;
-    if (tm == 2 && tn == 1) { tm = 1; tn = g.N <= 64 ? 1 : 2; }     // 128x64 is never the best shape here
-    // vector loads also need extents >= 4 in the vectorised direction (clamped addresses must stay inside)
-    if (g.K < 4) g.vecA = g.vecB = 0;
-    if (!A_KC && g.M < 4) g.vecA = 0;
-    if (!B_KC && g.N < 4) g.vecB = 0;
-    dim3 grid((unsigned)cdiv(g.N, 64 * tn), (unsigned)cdiv(g.M, 64 * tm), (unsigned)splits);
-    if (tm == 2 && tn == 2) launch_gemm_v<A_KC, B_KC, 2, 2>(g, grid, s);
-    else if (tm == 1 && tn == 2) launch_gemm_v<A_KC, B_KC, 1, 2>(g, grid, s);
-    else launch_gemm_v<A_KC, B_KC, 1, 1>(g, grid, s);
-    CDLRM_LAUNCH_CHECK();
-    return 0;
-}

@@ -23,6 +23,9 @@
 #include "gemm.h"
 
 #define G2_BK 32
+#ifndef G2_ABL
+#define G2_ABL 0        // diagnostic builds: 1 no DMA in the loop, 2 no barrier in the loop, 4 pieces behind every 2nd MFMA
+#endif
 
 typedef __attribute__((address_space(3))) void* g2_lds_ptr;
 
@@ -44,15 +47,16 @@ __device__ __forceinline__ unsigned g2_lds_addr(const float* p) {
     return (unsigned)(uintptr_t)(g2_lds_ptr)(p);
 }
 
-// per-thread source pointers of one operand's tile (ROWS/32 DMA rounds), advanced by one K tile per iteration
+// per-thread source pointers of one operand's tile (ROWS/32 DMA pieces per thread), advanced by one K tile per issue
 template <bool KC, int ROWS>
 struct G2Stage {
-    const float* src[ROWS / 32];
+    static constexpr int NP = ROWS / 32;
+    const float* src[NP];
     int64_t step;
     __device__ __forceinline__ void init(const float* P, int64_t ld, int64_t r0, int64_t rmax, int64_t kbeg) {
         const int tid = threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i) {
+        for (int i = 0; i < NP; ++i) {
             if (KC) {
                 const int row = i * 32 + (tid >> 3);
                 const int c = (tid & 7) ^ ((row >> 1) & 7);
@@ -66,19 +70,57 @@ struct G2Stage {
         }
         step = KC ? G2_BK : G2_BK * ld;
     }
-    // issue the DMA of the current tile into `stage` (the operand's [ROWS * 32] float image) and move on one tile
-    __device__ __forceinline__ void issue(const float* stage) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(g2_lds_addr(stage) + (threadIdx.x >> 6) * 1024u);
-#pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i) {
-            g2_dma16(src[i], base + i * 4096u);
-            src[i] += step;
-        }
+    // piece i of the current tile -> stage image at LDS byte address `base` (this wave's first piece); moves on one tile
+    __device__ __forceinline__ void piece(int i, unsigned base) {
+        g2_dma16(src[i], base + i * 4096u);
+        src[i] += step;
     }
 };
 
+// the MFMA fragments of one 8-deep contraction group: lane half lk holds indices 4*lk .. 4*lk+3 of the group
+template <bool A_KC, bool B_KC, int TM, int TN>
+__device__ __forceinline__ void g2_frags(const float* Ab, const float* Bb, int kg, int ra, int rb, int lk, int sw,
+                                         float4 (&a)[TM], float4 (&b)[TN]) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = ra + i * 32;
+        if (A_KC) {
+            a[i] = *reinterpret_cast<const float4*>(Ab + r * G2_BK + 4 * ((kg * 2 + lk) ^ sw));
+        } else {
+            const float* q = Ab + (kg * 8 + 4 * lk) * BM + r;
+            a[i] = make_float4(q[0], q[BM], q[2 * BM], q[3 * BM]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = rb + j * 32;
+        if (B_KC) {
+            b[j] = *reinterpret_cast<const float4*>(Bb + c * G2_BK + 4 * ((kg * 2 + lk) ^ sw));
+        } else {
+            const float* q = Bb + (kg * 8 + 4 * lk) * BN + c;
+            b[j] = make_float4(q[0], q[BN], q[2 * BN], q[3 * BN]);
+        }
+    }
+}
+
+#ifdef GEMM2_STAMP      // diagnostic builds only (tools/gemm2_bench.hip): where a workgroup's time goes, and at what clock
+__device__ unsigned long long g2_stamps[8 * 4096];
+#define G2_STAMP(slot)                                                                            \
+    if (threadIdx.x == 0 && g2_wg < 4096) {                                                         \
+        g2_stamps[g2_wg * 8 + (slot)] = __builtin_amdgcn_s_memtime();                                \
+        if ((slot) == 0 || (slot) == 3) g2_stamps[g2_wg * 8 + 4 + ((slot) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define G2_STAMP(slot)
+#endif
+
 template <bool A_KC, bool B_KC, int TM, int TN>
 __device__ __forceinline__ void gemm2_tile_body(const GemmArgs& g, unsigned bx, unsigned by, unsigned bz, float* lds) {
+#ifdef GEMM2_STAMP
+    const unsigned g2_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#endif
+    G2_STAMP(0)
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_ST = BM * G2_BK, B_ST = BN * G2_BK;        // floats per stage
     float* As = lds;                                            // [2][A_ST]
@@ -108,59 +150,97 @@ __device__ __forceinline__ void gemm2_tile_body(const GemmArgs& g, unsigned bx, 
 
     G2Stage<A_KC, BM> sa;
     G2Stage<B_KC, BN> sb;
+    constexpr int NPA = G2Stage<A_KC, BM>::NP, NPB = G2Stage<B_KC, BN>::NP, NPIECE = NPA + NPB;
     sa.init(g.A, g.lda, m0, g.M, kbeg);
     sb.init(g.B, g.ldb, n0, g.N, kbeg);
-    sa.issue(As);
-    sb.issue(Bs);
+    // LDS byte address of this wave's first DMA piece in stage 0 of each operand (wave-uniform: scalar registers)
+    const unsigned a_dst = __builtin_amdgcn_readfirstlane(g2_lds_addr(As) + wave * 1024u);
+    const unsigned b_dst = __builtin_amdgcn_readfirstlane(g2_lds_addr(Bs) + wave * 1024u);
+    const int ra = wm * (32 * TM) + lr, rb = wn * (32 * TN) + lr;
     const int sw = (lr >> 1) & 7;                               // read-side chunk permutation of contraction-contiguous images
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        g2_dma_wait();              // this wave's share of tile t has landed ...
-        __syncthreads();            // ... and everybody's; every wave is done reading stage cur^1 (tile t-1)
-        if (t + 1 < nt) {           // wave-uniform; never a DMA in flight when the workgroup ends (its LDS is re-assigned)
-            sa.issue(As + (cur ^ 1) * A_ST);
-            sb.issue(Bs + (cur ^ 1) * B_ST);
+
+    // One wave's instruction stream is in-order: whatever sits between two MFMAs of a wave delays the second one unless
+    // it fits into the 64 cycles the first one executes.  So the loop is software-pipelined by hand:
+    //   * fragments are double-buffered in registers: the reads of group kg+1 are issued in front of the MFMAs of group kg;
+    //   * the barrier that publishes tile t+1 sits in front of the LAST group of tile t, with that group's MFMAs (fragments
+    //     already in registers) queued behind it: they cover the DMA issue of tile t+2 -- one piece after each MFMA --
+    //     and the LDS latency of tile t+1's first fragments.
+    // (The un-pipelined form of this loop -- barrier, all DMA pieces, fragment reads, MFMAs -- measured 89-96 TF/s at
+    //  8192 x 512 x 512: two workgroups per CU run in lockstep, their stalls coincide instead of covering each other.)
+    float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) sa.piece(i, a_dst);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) sb.piece(i, b_dst);
+    g2_dma_wait();
+    __syncthreads();
+    if (nt > 1) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) sa.piece(i, a_dst + A_ST * 4u);
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) sb.piece(i, b_dst + B_ST * 4u);
+    }
+    g2_frags<A_KC, B_KC, TM, TN>(As, Bs, 0, ra, rb, lk, sw, fa[0], fb[0]);
+    G2_STAMP(1)
+
+    auto mfma_group = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
+        if (!A_KC && do_colsum) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) csum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
         }
-        const float* Ab = As + cur * A_ST;
-        const float* Bb = Bs + cur * B_ST;
 #pragma unroll
-        for (int kg = 0; kg < G2_BK / 8; ++kg) {
-            float4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = wm * (32 * TM) + i * 32 + lr;
-                if (A_KC) {
-                    a[i] = *reinterpret_cast<const float4*>(Ab + r * G2_BK + 4 * ((kg * 2 + lk) ^ sw));
-                } else {
-                    const float* q = Ab + (kg * 8 + 4 * lk) * BM + r;
-                    a[i] = make_float4(q[0], q[BM], q[2 * BM], q[3 * BM]);
-                }
-            }
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int c = wn * (32 * TN) + j * 32 + lr;
-                if (B_KC) {
-                    b[j] = *reinterpret_cast<const float4*>(Bb + c * G2_BK + 4 * ((kg * 2 + lk) ^ sw));
-                } else {
-                    const float* q = Bb + (kg * 8 + 4 * lk) * BN + c;
-                    b[j] = make_float4(q[0], q[BN], q[2 * BN], q[3 * BN]);
-                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
             }
-            if (!A_KC && do_colsum) {
+    };
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const float* Ab = As + cur * A_ST;
+        const float* Bb = Bs + cur * B_ST;
+        g2_frags<A_KC, B_KC, TM, TN>(Ab, Bb, 1, ra, rb, lk, sw, fa[1], fb[1]);
+        mfma_group(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        g2_frags<A_KC, B_KC, TM, TN>(Ab, Bb, 2, ra, rb, lk, sw, fa[0], fb[0]);
+        mfma_group(fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        g2_frags<A_KC, B_KC, TM, TN>(Ab, Bb, 3, ra, rb, lk, sw, fa[1], fb[1]);
+        mfma_group(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = t + 1 < nt, more2 = t + 2 < nt;       // wave-uniform
+        if (more) {
+            g2_dma_wait();          // this wave's pieces of tile t+1 have landed (issued a whole tile ago) ...
+            if (!(G2_ABL & 2))
+            __syncthreads();        // ... and everybody's; every wave has read its last fragments of tile t (stage cur)
+            g2_frags<A_KC, B_KC, TM, TN>(As + (cur ^ 1) * A_ST, Bs + (cur ^ 1) * B_ST, 0, ra, rb, lk, sw, fa[0], fb[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // last group of tile t: its MFMAs interleaved with the DMA pieces of tile t+2 (into stage cur, free since the barrier)
+        if (!A_KC && do_colsum) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) csum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+            for (int i = 0; i < TM; ++i) csum[i] += (fa[1][i].x + fa[1][i].y) + (fa[1][i].z + fa[1][i].w);
+        }
+        const unsigned a_st = a_dst + cur * (A_ST * 4u), b_st = b_dst + cur * (B_ST * 4u);
+#pragma unroll
+        for (int m = 0; m < 4 * TM * TN; ++m) {                 // one DMA piece behind each of the first MFMAs
+            const int i = (m >> 2) / TN, j = (m >> 2) % TN, comp = m & 3;
+            const float av = comp == 0 ? fa[1][i].x : comp == 1 ? fa[1][i].y : comp == 2 ? fa[1][i].z : fa[1][i].w;
+            const float bv = comp == 0 ? fb[1][j].x : comp == 1 ? fb[1][j].y : comp == 2 ? fb[1][j].z : fb[1][j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);
+            constexpr int PSTEP = (G2_ABL & 4) ? 2 : 1;
+            if (!(G2_ABL & 1) && (m % PSTEP) == 0 && m / PSTEP < NPIECE && more2) {
+                if (m / PSTEP < NPA) sa.piece(m / PSTEP, a_st);
+                else sb.piece(m / PSTEP - NPA, b_st);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    G2_STAMP(2)
     if (!A_KC && g.colsum != nullptr && bx == 0) {
         // the two lane halves of a wave hold the two halves of the contraction range: add them in a fixed order
         if (wn == 0) {
@@ -173,28 +253,55 @@ __device__ __forceinline__ void gemm2_tile_body(const GemmArgs& g, unsigned bx, 
             }
         }
     }
+    // Epilogue.  The MFMAs were issued with the operand roles swapped (first operand = the B fragment), so an accumulator
+    // tile is C^T: lane l holds output ROW (l & 31) and, per group of four registers, four CONSECUTIVE columns
+    // 8*(r>>2) + 4*(l>>5) + (0..3) -- one 16-byte store per lane and register group (4 per 32x32 tile instead of the 16
+    // scalar stores of the row-per-register layout: the store tail of the first version took 20 k cycles per workgroup,
+    // a fifth of the kernel).  Same products in the same k order: bit-identical results.
     float* C = g.C + (int64_t)bz * g.slab;
+    const bool vbias = g.bias != nullptr && (((uintptr_t)g.bias) & 15) == 0;
+    const bool vmask = g.mask_act != 0 && (((uintptr_t)g.mask) & 15) == 0 && (g.ldmask & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int64_t row = m0 + wm * (32 * TM) + i * 32 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int64_t col = n0 + wn * (32 * TN) + j * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (g.act == 1) v = v > 0.f ? v : 0.f;
-                else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-                if (g.mask_act) {               // activation backward of the layer below, fused into the dgrad
-                    const float x = g.mask[row * g.ldmask + col];
-                    v = g.mask_act == 1 ? (x > 0.f ? v : 0.f) : v * ((1.0f - x) * x);
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = n0 + wn * (32 * TN) + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (row >= g.M || col >= g.N) continue;          // N % 4 == 0: a group of four columns is in or out
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (g.bias) {
+                    float4 bv;
+                    if (vbias) bv = *reinterpret_cast<const float4*>(g.bias + col);
+                    else bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
-                C[row * g.ldc + col] = v;
+                if (g.act == 1) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                } else if (g.act == 2) {
+                    v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+                    v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+                }
+                if (g.mask_act) {               // activation backward of the layer below, fused into the dgrad
+                    float4 x;
+                    const float* mp = g.mask + row * g.ldmask + col;
+                    if (vmask) x = *reinterpret_cast<const float4*>(mp);
+                    else x = make_float4(mp[0], mp[1], mp[2], mp[3]);
+                    if (g.mask_act == 1) {
+                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
+                        v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x *= (1.0f - x.x) * x.x; v.y *= (1.0f - x.y) * x.y;
+                        v.z *= (1.0f - x.z) * x.z; v.w *= (1.0f - x.w) * x.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(C + row * g.ldc + col) = v;
             }
         }
+    }
+    G2_STAMP(3)
 }
 
 template <bool A_KC, bool B_KC, int TM, int TN>
@@ -221,6 +328,8 @@ static inline bool gemm2_applies(const GemmArgs& g) {
     if (g.K < G2_BK || g.K % G2_BK != 0 || kc % G2_BK != 0) return false;
     if (!A_KC && g.M < 4) return false;
     if (!B_KC && g.N < 4) return false;
+    // the epilogue stores four consecutive columns per lane
+    if (g.N % 4 != 0 || g.ldc % 4 != 0 || g.slab % 4 != 0 || (((uintptr_t)g.C) & 15) != 0) return false;
     return true;
 }
 
@@ -231,4 +340,39 @@ static void launch_gemm2(const GemmArgs& g, int tm, int tn, int splits, hipStrea
     else if (tm == 2 && tn == 1) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 1>), grid, dim3(256), 0, s, g);
     else if (tm == 1 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 2>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 1>), grid, dim3(256), 0, s, g);
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
+    if (g.K < 4) g.vecA = g.vecB = 0;
+    if (gemm_use_direct(g.M, g.N, splits)) {
+        launch_gemm_direct<A_KC, B_KC>(g, splits, s);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
+    if (gemm2_applies<A_KC, B_KC>(g)) {
+        // LDS-DMA kernel.  Measured on the c3 layer shapes (tools/gemm2_bench.hip, M = 8192, all three layouts): 128x64
+        // tiles win wherever they leave >= 1 workgroup per CU (512-wide layers 40-42 us against 43-47 for 64x64), the
+        // 64x64 tile below that (128-wide output: 9.9 against 14.3 us)
+        int tm2 = 2, tn2 = 1;
+        if (g.M <= 64 || cdiv(g.M, 128) * cdiv(g.N, 64) * splits < 256) tm2 = 1;
+        launch_gemm2<A_KC, B_KC>(g, tm2, tn2, splits, s);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
+    int tm, tn;
+    gemm_pick_tile(g.M, g.N, splits, &tm, &tn);
+    if (g.N <= 32) tn = 1;
+    if (g.M <= 32) tm = 1;
+    if (tm == 2 && tn == 1) { tm = 1; tn = g.N <= 64 ? 1 : 2; }     // 128x64 is never the best shape here
+    // vector loads also need extents >= 4 in the vectorised direction (clamped addresses must stay inside)
+    if (g.K < 4) g.vecA = g.vecB = 0;
+    if (!A_KC && g.M < 4) g.vecA = 0;
+    if (!B_KC && g.N < 4) g.vecB = 0;
+    dim3 grid((unsigned)cdiv(g.N, 64 * tn), (unsigned)cdiv(g.M, 64 * tm), (unsigned)splits);
+    if (tm == 2 && tn == 2) launch_gemm_v<A_KC, B_KC, 2, 2>(g, grid, s);
+    else if (tm == 1 && tn == 2) launch_gemm_v<A_KC, B_KC, 1, 2>(g, grid, s);
+    else launch_gemm_v<A_KC, B_KC, 1, 1>(g, grid, s);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
 }

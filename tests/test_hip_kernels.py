@@ -373,7 +373,11 @@ def test_dense_golden(ops, golden, itself):
 
 @pytest.mark.parametrize("M,N,K,act", [(8192, 512, 13, 1), (1030, 200, 5, 2), (33, 132, 32, 0), (1000, 256, 512, 1), (777, 1, 256, 2), (4096, 512, 479, 1),
                                        (130, 70, 33, 0), (1024, 512, 480, 1), (2048, 128, 256, 1), (8192, 1, 256, 2),
-                                       (5000, 512, 512, 1), (3, 5, 2, 0), (1024, 512, 13, 1)])
+                                       (5000, 512, 512, 1), (3, 5, 2, 0), (1024, 512, 13, 1),
+                                       # long batches on 16-byte-loadable layers: the LDS-DMA kernel (gemm_glds.h), 128x64 and
+                                       # 64x64 tiles, partial tiles in both directions, K = 96 (3 K tiles), sigmoid epilogue
+                                       (8192, 512, 512, 1), (8192, 256, 512, 1), (8192, 128, 256, 1), (6400, 512, 480, 2),
+                                       (8256, 264, 96, 0), (8200, 264, 64, 1)])
 def test_linear_vs_torch_fp32(ops, M, N, K, act):
     """FP32-MFMA Linear fwd/bwd against a plain torch fp32 reference (CPU, float64 accumulate for the bound)."""
     rng = np.random.RandomState(M + N + K)
@@ -483,7 +487,7 @@ def test_interaction_kernels_vs_torch(ops, B, F, D, itself, pad):
     np.testing.assert_allclose(dfeat.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
 
 
-@pytest.mark.parametrize("M", [64, 1000, 2048, 4100])
+@pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 4096, 8192])
 def test_mlp_wgrad_group(ops, M):
     """All layers' weight + bias gradients in one call (grouped LDS-free launch up to M = 2048, tiled split-M path
     above) against fp64 torch."""

@@ -8,18 +8,23 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "gemm_glds.h"
 
 void cdlrm_set_error(const char* fmt, ...) {}
 
+static int g_data_mode = 1;      // 0 zeros, 1 uniform [-1, 1), 2 ReLU-like (half of the values zero)
 static float* dev_rand(size_t n, unsigned seed) {
     std::vector<float> h(n);
     unsigned s = seed * 2654435761u + 12345u;
     for (size_t i = 0; i < n; ++i) {
         s = s * 1664525u + 1013904223u;
-        h[i] = (float)((s >> 8) & 0xffff) / 32768.f - 1.f;
+        float v = (float)((s >> 8) & 0xffff) / 32768.f - 1.f;
+        if (g_data_mode == 0) v = 0.f;
+        if (g_data_mode == 2 && v < 0.f) v = 0.f;
+        h[i] = v;
     }
     float* d;
     hipMalloc(&d, n * 4);
@@ -111,6 +116,30 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
             std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
             t0 = a[2]; t1 = b[2];
         }
+#ifdef GEMM2_STAMP
+        {
+            hipMemset(C1, 0, 16);
+            launch_gemm2<A_KC, B_KC>(g1, tm, tn, zs, 0);
+            hipDeviceSynchronize();
+            static unsigned long long hs[8 * 4096];
+            hipMemcpyFromSymbol(hs, HIP_SYMBOL(g2_stamps), sizeof(hs));
+            const unsigned nwg = (unsigned)(cdiv(g.N, 64 * tn) * cdiv(g.M, 64 * tm) * zs);
+            std::vector<double> pro, loop, epi, clk, tot;
+            unsigned long long first = ~0ull, last = 0;
+            for (unsigned w = 0; w < nwg && w < 4096; ++w) {
+                const unsigned long long* q = hs + w * 8;
+                pro.push_back((double)(q[1] - q[0])); loop.push_back((double)(q[2] - q[1])); epi.push_back((double)(q[3] - q[2]));
+                tot.push_back((double)(q[3] - q[0]));
+                clk.push_back((double)(q[3] - q[0]) / (double)(q[5] - q[4]) * 100.0);       // MHz: realtime ticks at 100 MHz
+                first = std::min(first, q[4]); last = std::max(last, q[5]);
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            const int nt = (int)(g.kchunk / 32);
+            printf("    stamps: prologue %.0f  loop %.0f (= %.1f per MFMA of %d)  epilogue %.0f  total %.0f cycles; clock %.0f MHz; "
+                   "first start -> last end %.1f us\n", med(pro), med(loop), med(loop) / (nt * 16.0 * tm * tn), nt * 16 * tm * tn,
+                   med(epi), med(tot), med(clk), (double)(last - first) / 100.0);
+        }
+#endif
         const double fl = 2.0 * M * N * K;
         printf("%-28s %6ld x %4d x %5ld z%-2d tile %3dx%-3d  max|d| %.2e (|C| %.1f) colsum d %.1e %s", name, (long)M, N, (long)K,
                zs, 64 * tm, 64 * tn, maxd, maxv, csd, ok ? "ok  " : "BAD ");
@@ -124,7 +153,16 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
 int main(int argc, char** argv) {
     const bool timing = argc < 2 || atoi(argv[1]) != 0;
     const int64_t M = argc > 2 ? atol(argv[2]) : 8192;
+    g_data_mode = argc > 3 ? atoi(argv[3]) : 1;
+    const bool quick = argc > 4 && atoi(argv[4]) != 0;
     int bad = 0;
+    if (quick) {
+        bad += run_case<true, true>("fwd 512<-512", M, 512, 512, 1, timing);
+        bad += run_case<true, false>("dgrad 512<-512", M, 512, 512, 1, timing);
+        bad += run_case<false, false>("wgrad 512x512", 512, 512, M, 16, timing);
+        printf(bad ? "FAILED: %d cases\n" : "all cases agree\n", bad);
+        return bad != 0;
+    }
     // edge shapes: partial tiles in both directions
     bad += run_case<true, true>("fwd edge", 1000, 200, 96, 1, false);
     bad += run_case<true, false>("dgrad edge", 1000, 200, 96, 1, false);
