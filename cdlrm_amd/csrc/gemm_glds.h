@@ -104,12 +104,67 @@ __device__ __forceinline__ void g2_frags(const float* Ab, const float* Bb, int k
     }
 }
 
+template <int TM, int TN>
+__device__ __forceinline__ void g2_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int64_t m0, int64_t n0, unsigned bz,
+                                            int wm, int wn, int lane) {
+    // Epilogue.  The MFMAs were issued with the operand roles swapped (first operand = the B fragment), so an accumulator
+    // tile is C^T: lane l holds output ROW (l & 31) and, per group of four registers, four CONSECUTIVE columns
+    // 8*(r>>2) + 4*(l>>5) + (0..3) -- one 16-byte store per lane and register group (4 per 32x32 tile instead of the 16
+    // scalar stores of the row-per-register layout: the store tail of the first version took 20 k cycles per workgroup,
+    // a fifth of the kernel).  Same products in the same k order: bit-identical results.
+    float* C = g.C + (int64_t)bz * g.slab;
+    const bool vbias = g.bias != nullptr && (((uintptr_t)g.bias) & 15) == 0;
+    const bool vmask = g.mask_act != 0 && (((uintptr_t)g.mask) & 15) == 0 && (g.ldmask & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int64_t row = m0 + wm * (32 * TM) + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = n0 + wn * (32 * TN) + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (row >= g.M || col >= g.N) continue;          // N % 4 == 0: a group of four columns is in or out
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (g.bias) {
+                    float4 bv;
+                    if (vbias) bv = *reinterpret_cast<const float4*>(g.bias + col);
+                    else bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (g.act == 1) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                } else if (g.act == 2) {
+                    v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+                    v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+                }
+                if (g.mask_act) {               // activation backward of the layer below, fused into the dgrad
+                    float4 x;
+                    const float* mp = g.mask + row * g.ldmask + col;
+                    if (vmask) x = *reinterpret_cast<const float4*>(mp);
+                    else x = make_float4(mp[0], mp[1], mp[2], mp[3]);
+                    if (g.mask_act == 1) {
+                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
+                        v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x *= (1.0f - x.x) * x.x; v.y *= (1.0f - x.y) * x.y;
+                        v.z *= (1.0f - x.z) * x.z; v.w *= (1.0f - x.w) * x.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(C + row * g.ldc + col) = v;
+            }
+        }
+    }
+}
+
 #ifdef GEMM2_STAMP      // diagnostic builds only (tools/gemm2_bench.hip): where a workgroup's time goes, and at what clock
 __device__ unsigned long long g2_stamps[8 * 4096];
 #define G2_STAMP(slot)                                                                            \
     if (threadIdx.x == 0 && g2_wg < 4096) {                                                         \
         g2_stamps[g2_wg * 8 + (slot)] = __builtin_amdgcn_s_memtime();                                \
         if ((slot) == 0 || (slot) == 3) g2_stamps[g2_wg * 8 + 4 + ((slot) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+        if ((slot) == 0) g2_stamps[g2_wg * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | \
+                                                    (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);               \
     }
 #else
 #define G2_STAMP(slot)
@@ -253,54 +308,7 @@ __device__ __forceinline__ void gemm2_tile_body(const GemmArgs& g, unsigned bx, 
             }
         }
     }
-    // Epilogue.  The MFMAs were issued with the operand roles swapped (first operand = the B fragment), so an accumulator
-    // tile is C^T: lane l holds output ROW (l & 31) and, per group of four registers, four CONSECUTIVE columns
-    // 8*(r>>2) + 4*(l>>5) + (0..3) -- one 16-byte store per lane and register group (4 per 32x32 tile instead of the 16
-    // scalar stores of the row-per-register layout: the store tail of the first version took 20 k cycles per workgroup,
-    // a fifth of the kernel).  Same products in the same k order: bit-identical results.
-    float* C = g.C + (int64_t)bz * g.slab;
-    const bool vbias = g.bias != nullptr && (((uintptr_t)g.bias) & 15) == 0;
-    const bool vmask = g.mask_act != 0 && (((uintptr_t)g.mask) & 15) == 0 && (g.ldmask & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int64_t row = m0 + wm * (32 * TM) + i * 32 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t col = n0 + wn * (32 * TN) + j * 32 + 8 * q + 4 * (lane >> 5);
-                if (row >= g.M || col >= g.N) continue;          // N % 4 == 0: a group of four columns is in or out
-                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                if (g.bias) {
-                    float4 bv;
-                    if (vbias) bv = *reinterpret_cast<const float4*>(g.bias + col);
-                    else bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                }
-                if (g.act == 1) {
-                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                } else if (g.act == 2) {
-                    v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
-                    v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
-                }
-                if (g.mask_act) {               // activation backward of the layer below, fused into the dgrad
-                    float4 x;
-                    const float* mp = g.mask + row * g.ldmask + col;
-                    if (vmask) x = *reinterpret_cast<const float4*>(mp);
-                    else x = make_float4(mp[0], mp[1], mp[2], mp[3]);
-                    if (g.mask_act == 1) {
-                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
-                        v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
-                    } else {
-                        v.x *= (1.0f - x.x) * x.x; v.y *= (1.0f - x.y) * x.y;
-                        v.z *= (1.0f - x.z) * x.z; v.w *= (1.0f - x.w) * x.w;
-                    }
-                }
-                *reinterpret_cast<float4*>(C + row * g.ldc + col) = v;
-            }
-        }
-    }
+    g2_epilogue<TM, TN>(g, acc, m0, n0, bz, wm, wn, lane);
     G2_STAMP(3)
 }
 
@@ -309,10 +317,22 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
     // ONE LDS object (a second one beside an LDS-DMA staging array makes hipcc wait vmcnt(0) before every fragment read)
     __shared__ __attribute__((aligned(1024))) float lds[2 * 64 * (TM + TN) * G2_BK];
     const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nwg);
+    const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned wgid = xcd_remap(orig, nwg);
     gemm2_tile_body<A_KC, B_KC, TM, TN>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y,
                                         wgid / (gridDim.x * gridDim.y), lds);
 }
+
+// Tried on top of this kernel and dropped (tools/gemm2_bench.hip, M = 8192, 512-wide layers, in-kernel stamps):
+//   * a fifth, DMA-only wave per workgroup (three LDS stages, two tiles in flight, counted vmcnt): 42.7-43.9 us against
+//     42.0-42.3 -- the compute waves do not get faster when they issue no DMA (149 cycles per MFMA and wave against 144;
+//     132 with the DMA ablated altogether, 129 with the barrier ablated too, ideal 128): what costs them ~8 % is the
+//     tile traffic into the CU's LDS itself, not the issue slots;
+//   * starting half of the workgroups 2.5-8 k cycles late so that the store tails of the co-resident pairs do not
+//     coincide: 40.6 against 42.0 us on the forward layout, nothing on the weight-gradient layout;
+//   * 128x128 tiles (one workgroup per CU): 42.3-43.4 us, no better than 128x64 with two.
+// Where a workgroup's 83 k cycles go at 8192 x 512 x 512 (128x64 tile, two workgroups per CU, 2.3-2.4 GHz): prologue 2.5 k,
+// loop 73.7 k (ideal 65.5 k), epilogue 10.5 k -- the 16 MB of output leave all 512 workgroups at the same moment.
 
 // the DMA kernel applies: every split's contraction range a multiple of 32, 16-byte loadable rows, >= 4 elements along
 // the vectorised non-contraction directions
@@ -333,13 +353,17 @@ static inline bool gemm2_applies(const GemmArgs& g) {
     return true;
 }
 
+#ifndef G2_EXTRA_LDS
+#define G2_EXTRA_LDS(tm, tn) 0
+#endif
 template <bool A_KC, bool B_KC>
 static void launch_gemm2(const GemmArgs& g, int tm, int tn, int splits, hipStream_t s) {
     dim3 grid((unsigned)cdiv(g.N, 64 * tn), (unsigned)cdiv(g.M, 64 * tm), (unsigned)splits);
-    if (tm == 2 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 2>), grid, dim3(256), 0, s, g);
-    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 1>), grid, dim3(256), 0, s, g);
-    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 2>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 1>), grid, dim3(256), 0, s, g);
+    const size_t dyn = (size_t)G2_EXTRA_LDS(tm, tn);
+    if (tm == 2 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 2>), grid, dim3(256), dyn, s, g);
+    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 1>), grid, dim3(256), dyn, s, g);
+    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 2>), grid, dim3(256), dyn, s, g);
+    else hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 1>), grid, dim3(256), dyn, s, g);
 }
 
 template <bool A_KC, bool B_KC>

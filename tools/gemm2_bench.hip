@@ -11,6 +11,8 @@
 #include <functional>
 #include <vector>
 
+static int g_extra_lds = 0;      // development: extra dynamic LDS per workgroup (caps the workgroups a CU admits)
+#define G2_EXTRA_LDS(tm, tn) g_extra_lds
 #include "gemm_glds.h"
 
 void cdlrm_set_error(const char* fmt, ...) {}
@@ -64,10 +66,10 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
     float* B = dev_rand((size_t)(B_KC ? (int64_t)N * K : K * N), 2);
     float* bias = dev_rand(N, 3);
     float* mask = dev_rand((size_t)M * N, 4);
-    float *C0, *C1, *cs0, *cs1;
+    float *C0, *C1, *C2, *cs0, *cs1, *cs2;
     const size_t cn = (size_t)M * N * splits;
-    hipMalloc(&C0, cn * 4); hipMalloc(&C1, cn * 4);
-    hipMalloc(&cs0, (size_t)M * splits * 4); hipMalloc(&cs1, (size_t)M * splits * 4);
+    hipMalloc(&C0, cn * 4); hipMalloc(&C1, cn * 4); hipMalloc(&C2, cn * 4);
+    hipMalloc(&cs0, (size_t)M * splits * 4); hipMalloc(&cs1, (size_t)M * splits * 4); hipMalloc(&cs2, (size_t)M * splits * 4);
     GemmArgs g = gemm_args();
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.ldc = N; g.slab = (int64_t)M * N;
     g.M = M; g.N = N; g.K = K; g.kchunk = cdiv(cdiv(K, splits), 32) * 32;
@@ -80,10 +82,10 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
     std::vector<float> h0(cn), h1(cn), hc0((size_t)M * zs), hc1((size_t)M * zs);
     for (int ti = 0; ti < 4; ++ti) {
         const int tm = tiles[ti][0], tn = tiles[ti][1];
-        GemmArgs g0 = g, g1 = g;
-        g0.C = C0; g1.C = C1;
-        if (!A_KC) { g0.colsum = cs0; g1.colsum = cs1; }
-        hipMemset(C0, 0, cn * 4); hipMemset(C1, 0xff, cn * 4);
+        GemmArgs g0 = g, g1 = g, g2 = g;
+        g0.C = C0; g1.C = C1; g2.C = C2;
+        if (!A_KC) { g0.colsum = cs0; g1.colsum = cs1; g2.colsum = cs2; }
+        hipMemset(C0, 0, cn * 4); hipMemset(C1, 0xff, cn * 4); hipMemset(C2, 0xee, cn * 4);
         old_launch<A_KC, B_KC>(g0, tm, tn, zs);
         if (!gemm2_applies<A_KC, B_KC>(g1)) { printf("%s: DMA kernel does not apply\n", name); return 1; }
         launch_gemm2<A_KC, B_KC>(g1, tm, tn, zs, 0);
@@ -102,19 +104,21 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
             hipMemcpy(hc0.data(), cs0, (size_t)M * zs * 4, hipMemcpyDeviceToHost);
             hipMemcpy(hc1.data(), cs1, (size_t)M * zs * 4, hipMemcpyDeviceToHost);
             for (size_t i = 0; i < (size_t)M * zs; ++i) csd = std::max(csd, (double)fabsf(hc0[i] - hc1[i]));
+
         }
         // same products, same k order inside a tile: the two kernels agree exactly (colsum: another summation order)
         const bool ok = maxd == 0.0 && csd <= 1e-3;
         if (!ok) ++bad;
-        double t0 = 0, t1 = 0;
+        double t0 = 0, t1 = 0, t2 = 0;
         if (timing) {
-            std::vector<double> a, b;
+            std::vector<double> a, b, c;
             for (int round = 0; round < 5; ++round) {
                 a.push_back(time_us([&]() { old_launch<A_KC, B_KC>(g0, tm, tn, zs); }, 20));
                 b.push_back(time_us([&]() { launch_gemm2<A_KC, B_KC>(g1, tm, tn, zs, 0); }, 20));
+                c.push_back(0.0);
             }
-            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
-            t0 = a[2]; t1 = b[2];
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); std::sort(c.begin(), c.end());
+            t0 = a[2]; t1 = b[2]; t2 = c[2];
         }
 #ifdef GEMM2_STAMP
         {
@@ -133,6 +137,22 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
                 clk.push_back((double)(q[3] - q[0]) / (double)(q[5] - q[4]) * 100.0);       // MHz: realtime ticks at 100 MHz
                 first = std::min(first, q[4]); last = std::max(last, q[5]);
             }
+            {   // workgroups per CU (XCC id, SE, SH, CU from the hardware id registers)
+                std::vector<unsigned> cu;
+                for (unsigned w = 0; w < nwg && w < 4096; ++w) {
+                    const unsigned long long h = hs[w * 8 + 6];
+                    const unsigned hw = (unsigned)h, xcc = (unsigned)(h >> 32) & 15;
+                    cu.push_back((xcc << 12) | (hw & 0xff00));          // cu_id[11:8] sh_id[12] se_id[15:13]
+                }
+                std::sort(cu.begin(), cu.end());
+                int hist[16] = {0};
+                size_t i0 = 0;
+                int ncu = 0;
+                while (i0 < cu.size()) { size_t j0 = i0; while (j0 < cu.size() && cu[j0] == cu[i0]) ++j0; hist[std::min<size_t>(15, j0 - i0)]++; ++ncu; i0 = j0; }
+                printf("    placement: %d CUs used;", ncu);
+                for (int k = 1; k < 16; ++k) if (hist[k]) printf(" %d CUs x %d WGs;", hist[k], k);
+                printf("\n");
+            }
             auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             const int nt = (int)(g.kchunk / 32);
             printf("    stamps: prologue %.0f  loop %.0f (= %.1f per MFMA of %d)  epilogue %.0f  total %.0f cycles; clock %.0f MHz; "
@@ -143,10 +163,11 @@ static int run_case(const char* name, int64_t M, int N, int64_t K, int splits, b
         const double fl = 2.0 * M * N * K;
         printf("%-28s %6ld x %4d x %5ld z%-2d tile %3dx%-3d  max|d| %.2e (|C| %.1f) colsum d %.1e %s", name, (long)M, N, (long)K,
                zs, 64 * tm, 64 * tn, maxd, maxv, csd, ok ? "ok  " : "BAD ");
-        if (timing) printf("  old %7.1f us %6.1f TF | dma %7.1f us %6.1f TF", t0, fl / t0 / 1e6, t1, fl / t1 / 1e6);
+        (void)t2;
+        if (timing) printf("  old %6.1f us %5.1f TF | dma %6.1f us %5.1f TF", t0, fl / t0 / 1e6, t1, fl / t1 / 1e6);
         printf("\n");
     }
-    hipFree(A); hipFree(B); hipFree(bias); hipFree(mask); hipFree(C0); hipFree(C1); hipFree(cs0); hipFree(cs1);
+    hipFree(A); hipFree(B); hipFree(bias); hipFree(mask); hipFree(C0); hipFree(C1); hipFree(C2); hipFree(cs0); hipFree(cs1); hipFree(cs2);
     return bad;
 }
 
@@ -154,6 +175,7 @@ int main(int argc, char** argv) {
     const bool timing = argc < 2 || atoi(argv[1]) != 0;
     const int64_t M = argc > 2 ? atol(argv[2]) : 8192;
     g_data_mode = argc > 3 ? atoi(argv[3]) : 1;
+    g_extra_lds = argc > 5 ? atoi(argv[5]) : 0;
     const bool quick = argc > 4 && atoi(argv[4]) != 0;
     int bad = 0;
     if (quick) {
