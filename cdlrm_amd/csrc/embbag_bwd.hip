@@ -15,43 +15,127 @@
 // HBM-bound: algorithmic bytes per lookup 4D (grad) + 2*4D (row read-modify-write) + 8.
 #include "common.h"
 
-#define SORT_CHUNK 8192          // keys per LDS bitonic sort (64 KiB of LDS)
+#define SORT_CHUNK 8192          // most keys one workgroup sorts (64 KiB of LDS)
 #define SORT_THREADS 1024
 #define SEG_CH 32
 
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, lane_mask, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lane_mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Sort of one chunk of (slot, position) keys by ONE workgroup of 1024 threads, E keys per thread (chunk padded to
+// 1024 * E with ~0 keys):
+//   1. every wave sorts its 64 * E keys in REGISTERS -- a bitonic network whose exchanges at distance < E stay inside a
+//      thread and at distance >= E are lane shuffles: no LDS, no barrier;
+//   2. the 16 sorted runs meet in LDS and are merged pairwise by RANK: a key's place in the merged run is its place in
+//      its own run plus the number of smaller keys in the sibling run (a binary search in LDS): log2(16) = 4 passes with
+//      two barriers each.
+// The all-LDS bitonic network this replaces took 91 compare-exchange stages with a 1024-thread barrier after each
+// (91-113 us for 26 tables x 8192 lookups, profiles/r01_v7_c3_n1_kernel_stats.csv).
+template <int E>
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __restrict__ slots, int64_t n,
                                                               uint64_t* __restrict__ keys, int32_t* __restrict__ meta,
                                                               int npow2, int write_meta) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
     __shared__ int wmax[16];
     const int t = blockIdx.y;
-    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
-    const int cnt = (int)min((int64_t)SORT_CHUNK, n - base);
-    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-        uint64_t k = ~0ull;
+    const int chunk = SORT_THREADS * E;       // == sort_chunk(n): whole chunks, a shorter last one
+    const int64_t base = (int64_t)blockIdx.x * chunk;
+    const int cnt = (int)min((int64_t)chunk, n - base);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WK = 64 * E;              // keys per wave
+    constexpr int NT = SORT_THREADS * E;    // keys per workgroup (>= npow2)
+    uint64_t k[E];
+    int pos[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        // coalesced load: element e of lane l is chunk index wave*WK + e*64 + l (which key a thread starts with is irrelevant)
+        const int i = wave * WK + e * 64 + lane;
+        k[e] = ~0ull;
         if (i < cnt) {
             const int64_t p = base + i;
-            k = ((uint64_t)(uint32_t)slots[(int64_t)t * n + p] << 32) | (uint64_t)p;
+            k[e] = ((uint64_t)(uint32_t)slots[(int64_t)t * n + p] << 32) | (uint64_t)p;
         }
-        sk[i] = k;
+    }
+    // 1. wave-local bitonic sort; the key with wave-local index g = lane * E + e lives in register e of lane `lane`
+#pragma unroll
+    for (int size = 2; size <= WK; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j >= 1; j >>= 1) {
+            if (j >= E) {
+                const int lm = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint64_t o = shfl_xor_u64(k[e], lm);
+                    const int g = lane * E + e;
+                    const bool up = (g & size) == 0, lower = (g & j) == 0;
+                    const uint64_t mn = k[e] < o ? k[e] : o, mx = k[e] < o ? o : k[e];
+                    k[e] = (lower == up) ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int p = e ^ j;
+                    if (p > e) {
+                        const int g = lane * E + e;
+                        const bool up = (g & size) == 0;
+                        const uint64_t a = k[e], b = k[p];
+                        const bool sw = (a > b) == up;
+                        k[e] = sw ? b : a;
+                        k[p] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        pos[e] = wave * WK + lane * E + e;
+        sk[pos[e]] = k[e];
     }
     __syncthreads();
-    for (int k = 2; k <= npow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const int hi = lo | j;
-                const bool up = (lo & k) == 0;
-                const uint64_t a = sk[lo], b = sk[hi];
-                if ((a > b) == up) { sk[lo] = b; sk[hi] = a; }
-            }
-            __syncthreads();
+    // 2. rank-merge the 16 runs pairwise; ties (only the ~0 pad keys repeat) go left run first.  Branch-free binary
+    //    searches with a fixed step count, the E searches of a thread interleaved (E independent LDS reads in flight per
+    //    step instead of one dependent read at a time)
+    for (int run = WK; run < NT; run <<= 1) {
+        int sib[E], cntl[E];
+        bool left[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int s0 = pos[e] & ~(2 * run - 1);
+            left[e] = (pos[e] & run) == 0;
+            sib[e] = left[e] ? s0 + run : s0;       // first key of the sibling run
+            cntl[e] = 0;                            // sibling keys that sort in front of k[e], so far
         }
+        for (int st = run >> 1; st > 0; st >>= 1) {
+            uint64_t v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = sk[sib[e] + cntl[e] + st - 1];
+#pragma unroll
+            for (int e = 0; e < E; ++e) cntl[e] += (left[e] ? (v[e] < k[e]) : (v[e] <= k[e])) ? st : 0;
+        }
+        {
+            uint64_t v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = sk[sib[e] + cntl[e]];        // cntl <= run - 1 here: in range
+#pragma unroll
+            for (int e = 0; e < E; ++e) cntl[e] += (left[e] ? (v[e] < k[e]) : (v[e] <= k[e])) ? 1 : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int s0 = pos[e] & ~(2 * run - 1);
+            pos[e] = s0 + (pos[e] - (left[e] ? s0 : s0 + run)) + cntl[e];
+        }
+        __syncthreads();                    // every search of this pass has read the old layout
+#pragma unroll
+        for (int e = 0; e < E; ++e) sk[pos[e]] = k[e];
+        __syncthreads();
     }
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[(int64_t)t * n + base + i] = sk[i];
     if (!write_meta) return;
     // run starts by an inclusive max-scan of head positions: thread owns E consecutive sorted keys
-    const int E = (npow2 + SORT_THREADS - 1) / SORT_THREADS;
     const int i0 = threadIdx.x * E;
     int local = -1;     // last head position inside my range
     for (int e = 0; e < E; ++e) {
@@ -59,7 +143,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __r
         if (i < cnt && (i == 0 || (uint32_t)(sk[i] >> 32) != (uint32_t)(sk[i - 1] >> 32))) local = i;
     }
     int inc = local;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wid = wave;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl_up(inc, d, 64);
@@ -119,7 +203,7 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
                                                     int64_t ld_table, float lr, float4* __restrict__ partials,
                                                     int64_t pstride, int64_t* __restrict__ longlist,
                                                     int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
-                                                    int64_t aux_total) {
+                                                    int64_t aux_total, int32_t* __restrict__ runend) {
     constexpr int KM = (SEG_CH + LPR - 1) / LPR;
     const int t = blockIdx.y;
     const int64_t row_base = tab[t].row_base;
@@ -194,6 +278,9 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
                 const int li = atomicAdd(longcount, 1);
                 longlist[li] = ((int64_t)t << 40) | p;
             }
+            // the LAST chunk of a long run knows where the run ends: leave it at the run's head for k_bwd_long (which
+            // would otherwise find it by a 13-step binary search over the keys, one dependent global read per step)
+            if (!single && !more) runend[(int64_t)t * n + (p - r0)] = (int32_t)(p + len);
         }
     }
 }
@@ -204,7 +291,7 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
                                                   int64_t n, float lr, const float4* __restrict__ partials,
                                                   int64_t pstride, const int64_t* __restrict__ longlist,
                                                   const int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
-                                                  int64_t aux_total) {
+                                                  int64_t aux_total, const int32_t* __restrict__ runend) {
     const int c = threadIdx.x % LPR;
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
@@ -215,12 +302,25 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
         const int64_t p0 = e & (((int64_t)1 << 40) - 1);
         const uint64_t* kt = keys + (int64_t)t * n;
         const uint32_t slot = (uint32_t)(kt[p0] >> 32);
-        const int64_t end = lower_bound_u64(kt, p0, n, ((uint64_t)slot + 1) << 32);
+        const int64_t end = runend[(int64_t)t * n + p0];
         const int64_t row = tab[t].row_base + slot;
         for (int cc = c; cc < D4; cc += LPR) {
             float4 w = weight[row * D4 + cc];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int64_t p = p0; p < end; p += SEG_CH) {
+            // chunk partials in chunk order (a fixed order: reproducible), four loads in flight
+            int64_t p = p0;
+            for (; p + 3 * SEG_CH < end; p += 4 * SEG_CH) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t q = p + u * SEG_CH;
+                    const int64_t pi = 2 * (q / SEG_CH) + (q == p0 ? 1 : 0);
+                    v[u] = partials[((int64_t)t * pstride + pi) * D4 + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; p < end; p += SEG_CH) {
                 const int64_t pi = 2 * (p / SEG_CH) + (p == p0 ? 1 : 0);
                 const float4 v = partials[((int64_t)t * pstride + pi) * D4 + cc];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -248,7 +348,7 @@ static int lanes_per_row_b(int D4) { int l = pow2ceil(D4); return l > 64 ? 64 : 
     }
 
 // work layout: keys A [T*n] u64 | keys B [T*n] u64 | meta [T*n] i32 | partials [T*pstride*D] f32 |
-//              longlist [T*(n/SEG_CH+2)] i64 | sorted-buffer selector + long-run counter
+//              longlist [T*(n/SEG_CH+2)] i64 | long-run counter | runend [T*n] i32 (end of a long run, at its head)
 static int64_t bwd_pstride(int64_t n) { return 2 * (cdiv(n, SEG_CH) + 1); }
 static uint64_t align256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
 
@@ -258,6 +358,7 @@ struct BwdWork {
     float4* partials;
     int64_t* longlist;
     int32_t* longcount;
+    int32_t* runend;
     int64_t pstride;
 };
 
@@ -270,19 +371,30 @@ static BwdWork carve(void* work, int T, int64_t n, int D) {
     w.pstride = bwd_pstride(n);
     w.partials = (float4*)wp; wp += align256((uint64_t)T * w.pstride * D * 4);
     w.longlist = (int64_t*)wp; wp += align256((uint64_t)T * (n / SEG_CH + 2) * 8);
-    w.longcount = (int32_t*)wp;
+    w.longcount = (int32_t*)wp; wp += 256;
+    w.runend = (int32_t*)wp;
     return w;
 }
 
 extern "C" uint64_t cdlrm_embbag_bwd_work_bytes(int32_t T, int64_t n, int32_t dim) {
     return 2 * align256((uint64_t)T * n * 8) + align256((uint64_t)T * n * 4) +
-           align256((uint64_t)T * bwd_pstride(n) * dim * 4) + align256((uint64_t)T * (n / SEG_CH + 2) * 8) + 256;
+           align256((uint64_t)T * bwd_pstride(n) * dim * 4) + align256((uint64_t)T * (n / SEG_CH + 2) * 8) + 256 +
+           align256((uint64_t)T * n * 4);
+}
+
+// Keys per sorting workgroup.  The in-LDS sort is bound by vector-instruction issue on ONE CU (measured: 9 / 16 / 33 / 83 us
+// for 1024 / 2048 / 4096 / 8192 keys per workgroup, tools/sort_scale.py), so mid-sized inputs are cut into 2048-key
+// chunks that sort on different CUs and meet in global rank-merge passes (k_merge_pass, ~8 us each at 26 x 8192 keys);
+// very long inputs (config c5: 65536 lookups per table) keep 8192-key chunks: there the merge passes dominate.
+static int64_t sort_chunk(int64_t n) {
+    if (n <= 2048) return n <= 1024 ? 1024 : 2048;
+    return n <= 16384 ? 2048 : SORT_CHUNK;
 }
 
 // number of rank-merge passes decides which key buffer ends up sorted
 static bool sorted_in_B(int64_t n) {
     int passes = 0;
-    for (int64_t run = SORT_CHUNK; run < n; run *= 2) ++passes;
+    for (int64_t run = sort_chunk(n); run < n; run *= 2) ++passes;
     return passes & 1;
 }
 
@@ -294,20 +406,27 @@ extern "C" int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, in
     if (n == 0) return 0;
     const int T = ctx->T;
     BwdWork w = carve(work, T, n, ctx->D);
-    const int64_t nchunks = cdiv(n, SORT_CHUNK);
-    int npow2 = pow2ceil((int)(n < SORT_CHUNK ? n : SORT_CHUNK));
-    if (npow2 < 2) npow2 = 2;
+    const int64_t chunk = sort_chunk(n);
+    const int64_t nchunks = cdiv(n, chunk);
+    const int npow2 = (int)chunk;
     static bool attr_set = false;
     if (!attr_set) {
-        CDLRM_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_chunks, hipFuncAttributeMaxDynamicSharedMemorySize,
+        CDLRM_HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_chunks<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             SORT_CHUNK * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_sort_chunks, dim3((unsigned)nchunks, (unsigned)T), dim3(SORT_THREADS), (size_t)npow2 * 8, s,
-                       slots, n, w.keysA, w.meta, npow2, nchunks == 1 ? 1 : 0);
+    // keys per thread: the chunk spread over the 1024 threads
+    const int E = (int)(chunk / SORT_THREADS);
+    const dim3 sgrid((unsigned)nchunks, (unsigned)T);
+    const size_t slds = (size_t)SORT_THREADS * E * 8;
+    const int wm = nchunks == 1 ? 1 : 0;
+    if (E == 1) hipLaunchKernelGGL(k_sort_chunks<1>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
+    else if (E == 2) hipLaunchKernelGGL(k_sort_chunks<2>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
+    else if (E == 4) hipLaunchKernelGGL(k_sort_chunks<4>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
+    else hipLaunchKernelGGL(k_sort_chunks<8>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
     uint64_t* cur = w.keysA;
     uint64_t* alt = w.keysB;
-    for (int64_t run = SORT_CHUNK; run < n; run *= 2) {
+    for (int64_t run = chunk; run < n; run *= 2) {
         int64_t gx = cdiv(n, 256);
         if (gx > 4096) gx = 4096;
         hipLaunchKernelGGL(k_merge_pass, dim3((unsigned)gx, (unsigned)T), dim3(256), 0, s, cur, alt, n, run);
@@ -347,16 +466,16 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     if (offsets)                                                                                                   \
         hipLaunchKernelGGL((k_bwd_chunks<L, false>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, w.meta, offsets, n, \
                            n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
-                           touched, aux_total);                                                                    \
+                           touched, aux_total, w.runend);                                                          \
     else                                                                                                           \
         hipLaunchKernelGGL((k_bwd_chunks<L, true>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, w.meta, offsets, n,  \
                            n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
-                           touched, aux_total)
+                           touched, aux_total, w.runend)
     DISPATCH_LPR_B(lpr, BWD_CALL)
 #undef BWD_CALL
     int64_t lx = cdiv((int64_t)T * (n / SEG_CH + 1), gpb);
     if (lx > 1024) lx = 1024;
-#define LONG_CALL(L) hipLaunchKernelGGL(k_bwd_long<L>, dim3((unsigned)lx), dim3(256), 0, s, ctx->d_tab, D4, wt, cur, n, lr, w.partials, w.pstride, w.longlist, w.longcount, touched, aux_total)
+#define LONG_CALL(L) hipLaunchKernelGGL(k_bwd_long<L>, dim3((unsigned)lx), dim3(256), 0, s, ctx->d_tab, D4, wt, cur, n, lr, w.partials, w.pstride, w.longlist, w.longcount, touched, aux_total, w.runend)
     DISPATCH_LPR_B(lpr, LONG_CALL)
 #undef LONG_CALL
     CDLRM_LAUNCH_CHECK();

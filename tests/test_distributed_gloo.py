@@ -94,7 +94,8 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
 
 
 @pytest.mark.parametrize("name,port,defer", [("train_w2_mean", 29811, False), ("train_w2_freq1", 29812, False),
-                                             ("train_w2_max", 29813, False), ("train_w2_mean", 29814, True)])
+                                             ("train_w2_max", 29813, False), ("train_w2_mean", 29814, True),
+                                             ("train_w2_sum", 29815, True)])
 def test_two_rank_training_matches_reference(golden, name, port, defer):
     """defer: the top / bottom MLP gradients travel as two exchanges (TrainEngine(defer_top_update=True))."""
     from oracle import cdlrm_oracle as O

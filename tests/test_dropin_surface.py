@@ -389,7 +389,8 @@ def _w2_worker(rid, port, name, host_shared, ret):
         raise
 
 
-@pytest.mark.parametrize("name,port", [("train_w2_mean", 29841), ("train_w2_max", 29842), ("train_w2_freq1", 29843)])
+@pytest.mark.parametrize("name,port", [("train_w2_mean", 29841), ("train_w2_max", 29842), ("train_w2_freq1", 29843),
+                                       ("train_w2_sum", 29844)])
 def test_reference_named_collectives_two_ranks(golden, name, port):
     """aggregate_gradients + wait_wrap, broadcast_and_aggregate (mean / max, merge every 3 / 2 / 1 iterations) and
     load_caches_and_broadcast in the reference's own loop shape, two processes on one GPU over gloo, against the

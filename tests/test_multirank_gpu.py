@@ -86,7 +86,7 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0
 
 @pytest.mark.parametrize("name,port,defer,chunk", [("train_w2_mean", 29821, False, 0), ("train_w2_max", 29822, False, 0),
                                                    ("train_w2_mean", 29823, True, 0), ("train_w2_freq1", 29824, True, 16),
-                                                   ("train_w2_max", 29825, False, 8)])
+                                                   ("train_w2_max", 29825, False, 8), ("train_w2_sum", 29826, True, 0)])
 def test_two_ranks_one_gpu_match_reference(golden, name, port, defer, chunk):
     from oracle import cdlrm_oracle as O
     g = golden(name)

@@ -268,7 +268,7 @@ def test_loss_trajectory_config_shapes(golden, name):
                                    rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("name", ["train_w2_mean", "train_w2_freq1", "train_w2_max"])
+@pytest.mark.parametrize("name", ["train_w2_mean", "train_w2_freq1", "train_w2_max", "train_w2_sum"])
 def test_loss_trajectory_w2(golden, name):
     g = golden(name)
     tr = run_oracle_training(g, 2)

@@ -80,6 +80,10 @@ def main():
             us, look * (8 * D + 16) / us / 1e3, look * (8 * D + 16) / us / 1e3 / 80))
         us = timeit(lambda: ops.embbag_bwd_sgd(ctx, slots, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched))
         print("embbag_bwd_sgd       %8.1f us   %7.1f GB/s algorithmic (12D+8 B/lookup)" % (us, look * (12 * D + 8) / us / 1e3))
+        us_p = timeit(lambda: ops.embbag_bwd_prepare(ctx, slots, work))
+        us_a = timeit(lambda: ops.embbag_bwd_apply(ctx, B, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched))
+        print("  prepare (slot sort) %7.1f us | apply (sums + row update) %7.1f us = %.1f GB/s = %.1f%% of 8 TB/s" % (
+            us_p, us_a, look * (12 * D + 8) / us_a / 1e3, look * (12 * D + 8) / us_a / 1e3 / 80))
 
     if want("interact"):
         F = 27

@@ -625,7 +625,11 @@ def _w2_worker(rid, cfg, occ_shared, host_shared, ret_q):
 
 def g_train_w2(M, MD, CM, QR):
     import torch.multiprocessing as mp
-    for name, agg_op, agg_freq in (("train_w2_mean", "mean", 3), ("train_w2_freq1", "mean", 1), ("train_w2_max", "max", 2)):
+    only = os.environ.get("GOLDEN_W2_ONLY", "")
+    for name, agg_op, agg_freq in (("train_w2_mean", "mean", 3), ("train_w2_freq1", "mean", 1), ("train_w2_max", "max", 2),
+                                   ("train_w2_sum", "sum", 4)):
+        if only and name != only:
+            continue
         cfg = dict(ln_emb=[3000, 50, 7, 1200], m_spa=8, ln_bot=[4, 16, 8], top=[16, 1], cache_size=40, ways=4,
                    B=32, L=4, nbatch=24, seed=9, lr=0.1, lr_emb=0.3, alpha=1.3, agg_op=agg_op, agg_freq=agg_freq,
                    port=29731)

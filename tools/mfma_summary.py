@@ -12,6 +12,7 @@ serialise the dispatches, so these are per-kernel figures without the step's cro
 import csv
 import glob
 import json
+import os
 import statistics
 import sys
 
@@ -25,7 +26,7 @@ def short(n):
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = sorted(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
     per = {}
     for r in csv.DictReader(open(f)):
         k = (short(r["Kernel_Name"]), r["Dispatch_Id"])
@@ -54,7 +55,7 @@ def main():
                       "mfma_util_vs_gui_active": util,
                       "gui_active_per_second_ghz": gui / 8.0 / secs / 1e9}
     res = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 "
-                      "bench.py --no-cpu-baseline --steps 300 --warmup 50 (MI355X, 1 GPU, config c3)",
+                      "bench.py --no-cpu-baseline --steps 50 --warmup 10 (tools/profile_round.sh; MI355X, 1 GPU, config c3)",
            "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time * 2.4 GHz * 1024 SIMDs); tflops = busy / 64 * 4096 / time; "
                       "mfma_util_vs_gui_active = busy / (GRBM_GUI_ACTIVE / 8 * 1024)",
            "kernels": dict(sorted(rows.items(), key=lambda kv: -kv[1]["mfma_util"]))}

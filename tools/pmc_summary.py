@@ -11,6 +11,7 @@ Corrections as MI355X_MICROARCH.md prescribes: counters are KB; on gfx950 FETCH_
 import csv
 import glob
 import json
+import os
 import statistics
 import sys
 
@@ -18,13 +19,13 @@ GATHER = "k_embbag_fwd_arange"
 
 
 def load(d, ctr, skip):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = sorted(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
     per = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != ctr:
             continue
         per.setdefault(r["Kernel_Name"].replace("void ", "").split("(")[0], []).append(float(r["Counter_Value"]))
-    kt = glob.glob(d + "/*/*kernel_trace.csv")[0]
+    kt = sorted(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)[-1]
     dur = {}
     for r in csv.DictReader(open(kt)):
         dur.setdefault(r["Kernel_Name"].replace("void ", "").split("(")[0], []).append(
@@ -40,14 +41,17 @@ def load(d, ctr, skip):
 
 def main():
     fetch_dir, write_dir, dst = sys.argv[1:4]
-    fe, wr = load(fetch_dir, "FETCH_SIZE", 20), load(write_dir, "WRITE_SIZE", 20)
+    workload = sys.argv[4] if len(sys.argv) > 4 else "c3"
+    alpha = float(sys.argv[5]) if len(sys.argv) > 5 else 1.05
+    fe, wr = load(fetch_dir, "FETCH_SIZE", 10), load(write_dir, "WRITE_SIZE", 10)
     gk = [k for k in fe if GATHER in k][0]
     rd = fe[gk]["median_counter_KB"] * 1024 * 2
     wb = wr[gk]["median_counter_KB"] * 1024
     doc = {
-        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py "
-                   "--no-cpu-baseline --steps 300 --warmup 50 (two separate passes, MI355X, 1 GPU, config c3)",
-        "workload": "c3",
+        "command": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 "
+                   "bench.py --no-cpu-baseline --steps 50 --warmup 10 [--alpha A] (two separate passes, MI355X, 1 GPU)",
+        "workload": workload,
+        "alpha": alpha,
         "n_gpus": 1,
         "kernel": gk,
         "FETCH_SIZE_KB_median": fe[gk]["median_counter_KB"],
