@@ -226,6 +226,8 @@ def main():
             return lambda: (syn.window(c, C) for c in range(w * (L // C), (w + 1) * (L // C)))
         return pregen[w] if w in pregen else syn.window(w, L)
 
+    from cdlrm_amd.engine import WindowResolver
+    use_resolver = os.environ.get("CDLRM_WINDOW_RESOLVE", "1") != "0"
     state = {"win": None, "next": None, "w": -1}
     plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
     ev_pairs = []
@@ -257,6 +259,10 @@ def main():
         if timed:
             refills["commits"] += 1
         state["win"], state["next"], state["w"] = state["next"], None, w
+        # window-resident probe: the window's lookups are resolved against the new tags once, in chunks ahead of the
+        # training position (streamed windows: per chunk, when the chunk is loaded)
+        state["res"] = WindowResolver(eng, state["win"], B) if (use_resolver and not C) else None
+        state["cid"] = None
 
     def run_step(j, timed):
         w, jj = divmod(j, L)
@@ -272,6 +278,7 @@ def main():
             cid, jc = divmod(j, C)
             if state.get("cid") != cid:
                 state["chunk"], state["cid"] = syn.window(cid, C), cid
+                state["res"] = WindowResolver(eng, state["chunk"], B) if use_resolver else None
             win_t, jloc, nloc = state["chunk"], jc, C
         else:
             win_t, jloc, nloc = state["win"], jj, L
@@ -289,7 +296,12 @@ def main():
             ev_pairs.append(ev_pool[j])
         if timed and world > 1 and jj > 0 and jj % cfg["agg"] == 0:
             refills["merges"] += 1
-        eng.step(X, idx, T, j=jj, gather_events=ev_pool[j] if sample else None, next_idx=nxt)
+        rs = state.get("res")
+        eng.step(X, idx, T, j=jj, gather_events=ev_pool[j] if sample else None, next_idx=nxt,
+                 res=rs.batch(jloc) if rs is not None else None,
+                 next_res=rs.batch(jloc + 1) if (rs is not None and nxt is not None) else None)
+        if rs is not None:
+            rs.ensure(jloc + rs.CH + 2)
 
     for j in range(a.warmup):
         run_step(j, False)

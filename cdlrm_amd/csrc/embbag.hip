@@ -406,6 +406,150 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window-resident probe.  Tags only change at a refill (main_no_ddp.py:393-399), so every lookup of a look-ahead window
+// resolves to the same slot whenever it is probed while that window trains: the tag match, the ordered miss numbering
+// and the search of a miss in the window's victim list are done ONCE per window (in chunks of batches, ahead of the
+// training position) instead of once per iteration; the per-iteration work that remains is k_take below -- copy the
+// batch's slot ids and the rows of its misses.  Results are identical to cdlrm_embbag_probe on each batch (same slot
+// ids, same aux rows): tests/test_hip_kernels.py::test_window_resolve_take_equals_probe.
+// ---------------------------------------------------------------------------------------------
+// ordered miss numbering per SEGMENT (= one batch of one rank: seg_len lookups): the i-th miss of a segment, in
+// position order, gets aux slot P*ways + i (phase 0; k_take adds the aux phase)
+__global__ void __launch_bounds__(1024) k_resolve_seg(const TableDesc* __restrict__ tab, int ways, int aux,
+                                                      int32_t* __restrict__ wslots, int64_t n, int64_t seg_len, int* err) {
+    __shared__ int smem[32];
+    const int t = blockIdx.y;
+    const TableDesc d = tab[t];
+    const int64_t s0 = (int64_t)blockIdx.x * seg_len;
+    const int64_t cnt = min(seg_len, n - s0);
+    int32_t* row = wslots + (int64_t)t * n + s0;
+    int running = 0;
+    for (int64_t base = 0; base < cnt; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const int miss = (i < cnt && row[i] < 0) ? 1 : 0;
+        int total;
+        const int ex = block_excl_scan(miss, smem, &total);
+        if (miss) {
+            const int r = running + ex;
+            if (r < aux) {
+                row[i] = (int32_t)(d.P * ways + r);
+            } else {
+                row[i] = (int32_t)(d.P * ways);     // keep addresses legal; the call reports the error
+                atomicOr(err, 2);
+            }
+        }
+        running += total;
+    }
+}
+
+// where a miss's row comes from: its position in the window's victim rows (sorted list per table: binary search), or
+// -1 = not listed (the host table)
+__global__ void __launch_bounds__(256) k_victim_pos(const TableDesc* __restrict__ tab, int T, int ways,
+                                                    const int64_t* __restrict__ idx, int64_t n, int64_t ld_idx,
+                                                    const int32_t* __restrict__ wslots, int32_t* __restrict__ wsrc,
+                                                    const int64_t* __restrict__ v_idx, const int64_t* __restrict__ v_off) {
+    const int t = blockIdx.y;
+    const int64_t first_aux = tab[t].P * ways;
+    const int64_t lo0 = v_idx ? v_off[t] : 0, hi0 = v_idx ? v_off[t + 1] : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (wslots[(int64_t)t * n + i] < first_aux) continue;
+        const int64_t id = idx[(int64_t)t * ld_idx + i];
+        int64_t lo = lo0, hi = hi0;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (v_idx[mid] < id) lo = mid + 1; else hi = mid;
+        }
+        wsrc[(int64_t)t * n + i] = (lo < hi0 && v_idx[lo] == id) ? (int32_t)lo : -1;
+    }
+}
+
+extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, int64_t seg_len,
+                                    int32_t* wslots, int32_t* wsrc, void* stream) {
+    CDLRM_CLEAR_STALE();
+    CDLRM_REQUIRE(ctx && idx && wslots && wsrc, "null argument");
+    CDLRM_REQUIRE(ctx->tags && ctx->weight, "cdlrm_ctx_bind_cache first");
+    CDLRM_REQUIRE(n >= 1 && ld_idx >= n && n < ((int64_t)1 << 31) && seg_len >= 1, "bad n / ld_idx / seg_len");
+    CDLRM_REQUIRE(ctx->vict_idx == nullptr || ctx->total_rows < ((int64_t)1 << 31), "victim positions must fit 31 bits");
+    hipStream_t s = (hipStream_t)stream;
+    int lpl = pow2ceil(ctx->ways);
+    if (lpl > 16) lpl = 16;
+    int64_t gx = cdiv(n, 256 / lpl);
+    if (gx > 8192) gx = 8192;
+    dim3 grid((unsigned)gx, (unsigned)ctx->T);
+#define PROBE_CALL(L) hipLaunchKernelGGL(k_probe<L>, grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, wslots, ctx->d_err)
+    switch (lpl) {
+        case 1: PROBE_CALL(1); break;
+        case 2: PROBE_CALL(2); break;
+        case 4: PROBE_CALL(4); break;
+        case 8: PROBE_CALL(8); break;
+        default: PROBE_CALL(16); break;
+    }
+#undef PROBE_CALL
+    const int64_t nseg = cdiv(n, seg_len);
+    CDLRM_REQUIRE(nseg <= 65535 * 16, "too many segments");
+    // grid.x is the segment index (up to 2^31 - 1 on HIP)
+    hipLaunchKernelGGL(k_resolve_seg, dim3((unsigned)nseg, (unsigned)ctx->T), dim3(1024), 0, s, ctx->d_tab, ctx->ways, ctx->aux,
+                       wslots, n, seg_len, ctx->d_err);
+    int64_t gv = cdiv(n, 256);
+    if (gv > 4096) gv = 4096;
+    hipLaunchKernelGGL(k_victim_pos, dim3((unsigned)gv, (unsigned)ctx->T), dim3(256), 0, s, ctx->d_tab, ctx->T, ctx->ways, idx, n,
+                       ld_idx, wslots, wsrc, ctx->vict_idx, ctx->vict_off);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// the per-iteration remainder: slot ids of one batch out of the window's resolved ids (misses move to the aux region of
+// `aux_phase`), rows of its misses from the victim rows (or the host table) into their aux rows
+template <int LPR>
+__global__ void __launch_bounds__(256) k_take(const TableDesc* __restrict__ tab, int ways, int aux_first, int D4,
+                                              float4* __restrict__ weight, float* const* __restrict__ host_rows,
+                                              const int64_t* __restrict__ idx, int64_t ld_idx,
+                                              const int32_t* __restrict__ wslots, const int32_t* __restrict__ wsrc,
+                                              int64_t ld_w, int64_t n, const float* __restrict__ v_rows,
+                                              int32_t* __restrict__ slots_out) {
+    const int t = blockIdx.y;
+    const TableDesc d = tab[t];
+    const int32_t first_aux = (int32_t)(d.P * ways);
+    const int c = threadIdx.x % LPR;
+    const int gpb = blockDim.x / LPR;
+    const int gid = threadIdx.x / LPR;
+    const float4* vr = reinterpret_cast<const float4*>(v_rows);
+    const float4* hr = reinterpret_cast<const float4*>(host_rows[t]);
+    for (int64_t i = (int64_t)blockIdx.x * gpb + gid; i < n; i += (int64_t)gridDim.x * gpb) {
+        int32_t sl = wslots[(int64_t)t * ld_w + i];
+        if (sl >= first_aux) {
+            sl += aux_first;
+            const int32_t src = wsrc[(int64_t)t * ld_w + i];
+            const float4* from = src >= 0 ? vr + (int64_t)src * D4 : hr + idx[(int64_t)t * ld_idx + i] * D4;
+            float4* to = weight + (d.row_base + sl) * D4;
+            for (int cc = c; cc < D4; cc += LPR) to[cc] = from[cc];
+        }
+        if (c == 0) slots_out[(int64_t)t * n + i] = sl;
+    }
+}
+
+extern "C" int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, const int32_t* wslots,
+                                 const int32_t* wsrc, int64_t ld_w, int32_t* slots_out, int32_t aux_phase, void* stream) {
+    CDLRM_CLEAR_STALE();
+    CDLRM_REQUIRE(ctx && idx && wslots && wsrc && slots_out, "null argument");
+    CDLRM_REQUIRE(aux_phase >= 0 && aux_phase < ctx->aux_phases, "aux_phase outside the geometry's aux_phases");
+    CDLRM_REQUIRE(ctx->tags && ctx->weight, "cdlrm_ctx_bind_cache first");
+    CDLRM_REQUIRE(n >= 1 && ld_idx >= n && ld_w >= n, "bad n / ld");
+    CDLRM_REQUIRE(ctx->h_host_rows[0] != nullptr, "cdlrm_ctx_bind_host_tables first");
+    hipStream_t s = (hipStream_t)stream;
+    const int D4 = ctx->D / 4;
+    const int lpr = lanes_per_row(D4);
+    int64_t gx = cdiv(n, 256 / lpr);
+    if (gx > 1024) gx = 1024;
+    dim3 grid((unsigned)gx, (unsigned)ctx->T);
+#define TAKE_CALL(L) hipLaunchKernelGGL(k_take<L>, grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, aux_phase * ctx->aux, D4, reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, ld_idx, wslots, wsrc, ld_w, n, ctx->vict_rows, slots_out)
+    DISPATCH_LPR(lpr, TAKE_CALL)
+#undef TAKE_CALL
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,
                                 int64_t n_bags, int64_t ld_off, float* out, int64_t ld_bag, int64_t ld_table,
                                 void* stream) {

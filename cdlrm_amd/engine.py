@@ -312,6 +312,59 @@ class WindowPipeline:
         return out
 
 
+class WindowResolver:
+    """The look-ahead window's lookups resolved ONCE (tags only change at a refill, main_no_ddp.py:393-399): tag match,
+    ordered miss numbering per batch and the place of every miss in the window's victim rows (cdlrm_window_resolve), in
+    chunks of `chunk` batches issued on the engine's prefetch stream ahead of the training position.  `batch(j)` hands the
+    engine the views of batch j; what is left per iteration is cdlrm_embbag_take (copy the slot ids, copy the miss rows).
+    Create it right after the window's commit(); call ensure() after every step."""
+
+    def __init__(self, engine: "TrainEngine", window_idx: torch.Tensor, global_batch: int, *, chunk: int = 16):
+        self.eng, self.ctx = engine, engine.ctx
+        self.idx = window_idx
+        self.B = int(global_batch)
+        self.lbs = -(-self.B // engine.world)
+        self.rank = engine.rank
+        n = int(window_idx.shape[1])
+        assert n % self.B == 0, "a window is a whole number of batches"
+        self.nb = n // self.B
+        self.CH = max(1, int(chunk))
+        self.chunks = {}            # chunk number -> (wslots, wsrc, ready event)
+        self.done = 0               # chunks issued
+        self.ensure(self.CH + 2)
+
+    def ensure(self, upto_batch: int):
+        """Issue the resolve of every chunk that holds a batch < upto_batch (prefetch stream; no host wait)."""
+        eng, ctx = self.eng, self.ctx
+        nchunks = -(-self.nb // self.CH)
+        want = min(nchunks, -(-min(int(upto_batch), self.nb) // self.CH))
+        while self.done < want:
+            c = self.done
+            b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
+            cols = self.idx[:, b0 * self.B:b1 * self.B]
+            ws = torch.empty(ctx.T, cols.shape[1], dtype=torch.int32, device=self.idx.device)
+            wsrc = torch.empty_like(ws)
+            pst = eng.pref
+            if self.done == 0:
+                pst.wait_stream(S.current_stream(eng.dev))      # the commit (tags, victims) is on the main stream
+            with S.on_stream(pst):
+                ops.window_resolve(ctx, cols, self.lbs, ws, wsrc, stream=pst)
+                ev = S.new_event(eng.dev)
+                ev.record(pst)
+            self.chunks[c] = (ws, wsrc, ev)
+            self.done += 1
+
+    def batch(self, j: int):
+        """(wslots view, wsrc view, ready event) of this rank's lookups of batch j of the window."""
+        c = j // self.CH
+        self.ensure(j + 1)
+        ws, wsrc, ev = self.chunks[c]
+        col = (j - c * self.CH) * self.B + self.rank * self.lbs
+        if c >= 2 and (c - 2) in self.chunks:       # chunks far behind the training position are not needed any more
+            del self.chunks[c - 2]
+        return ws[:, col:col + self.lbs], wsrc[:, col:col + self.lbs], ev
+
+
 class TrainEngine:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, dlrm: DLRM_Net, host_tables: Embedding_Table_Group,
                  *, lr: float, lr_embeds: float, world_size: int = 1, rank: int = 0, table_agg_freq: int = 1,
@@ -377,6 +430,7 @@ class TrainEngine:
         # own rate (35.4 -> 38.3 us, 78 % -> 72 % of peak)
         self.gather_alone_min = int(os.environ.get("CDLRM_GATHER_ALONE_MIN", "8192"))
         self._gslot = None
+        self._res = self._next_res = None
         self._tapes = {}
         self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
 
@@ -560,13 +614,18 @@ class TrainEngine:
         return self._agg_buf[:U]
 
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
-             j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None):
+             j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None,
+             res=None, next_res=None):
         """One training iteration on this rank's slice (next_idx: the NEXT batch's indices, if it belongs to the same
         window: its tag probe and aux fill are then issued behind this step's embedding backward).  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
         on the device; lS_o None = Criteo layout (one lookup per bag), else int64 [T, B] offsets -- or [T, B + 1] from
         square_bags() for ragged multi-hot tables; j = batch number inside the epoch (table-agg schedule).
+        res / next_res: WindowResolver.batch(j) / .batch(j + 1) -- the window-resident probe: this batch's (the next
+        batch's) slot ids and miss sources were resolved once for the whole window, the per-step tag probe shrinks to
+        cdlrm_embbag_take.
         Returns the device loss buffer (element 0 = BCE loss)."""
         B, n = X.shape[0], lS_i.shape[1]
+        self._res, self._next_res = res, (next_res if next_idx is not None else None)
         if lS_o is not None:
             assert lS_o.shape[1] in (B, B + 1) and (self.world == 1 or lS_o.shape[1] == B)
         if j is None:
@@ -583,6 +642,9 @@ class TrainEngine:
         else:
             self._gslot = (S.new_event(self.dev, True), S.new_event(self.dev, True))
             gather_events.append(self._gslot)
+        if res is not None:
+            # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
+            self.side.wait_event(res[2])
         if self.use_tape and lS_o is None:
             sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
@@ -663,8 +725,12 @@ class TrainEngine:
             self._phase = pref["phase"]
         else:
             rec(side.wait_stream, main)
-            slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side, aux_phase=self._phase,
-                                                           out=self._probe_bufs(n, self._phase))
+            if self._res is not None and lS_o is None:
+                slots, miss_pos, miss_count = self._probe_bufs(n, self._phase)
+                ops.embbag_take(ctx, lS_i, self._res[0], self._res[1], slots, aux_phase=self._phase, stream=side)
+            else:
+                slots, miss_pos, miss_count = ops.embbag_probe(ctx, lS_i, stream=side, aux_phase=self._phase,
+                                                               out=self._probe_bufs(n, self._phase))
             probed = ev["probed_inline"]
             rec(probed.record, side)
         n_bags = B if lS_o is None else lS_o.shape[1]
@@ -714,7 +780,11 @@ class TrainEngine:
             if self._emb_done is not None:
                 rec(pst.wait_event, self._emb_done)
             ph = 1 - self._phase
-            res = ops.embbag_probe(ctx, next_idx, stream=pst, aux_phase=ph, out=self._probe_bufs(n, ph))
+            if self._next_res is not None:
+                res = self._probe_bufs(n, ph)
+                ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=ph, stream=pst)
+            else:
+                res = ops.embbag_probe(ctx, next_idx, stream=pst, aux_phase=ph, out=self._probe_bufs(n, ph))
             evp = ev["probed"][ph]
             rec(evp.record, pst)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=ph,
@@ -804,7 +874,11 @@ class TrainEngine:
         if next_idx is not None and not two_phase:
             # single aux region: the next batch's fill can only follow this batch's embedding update
             which = 2 + (self.iter & 1)
-            res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
+            if self._next_res is not None:
+                res = self._probe_bufs(n, which)
+                ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=0, stream=side)
+            else:
+                res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
             evp = ev["probed"][which]
             rec(evp.record, side)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
@@ -900,7 +974,9 @@ class TrainEngine:
         nxt = next_idx is not None
         key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
                next_idx.stride(0) if nxt else 0, (self.iter & 1) if self.ctx.aux_phases < 2 else 0,
-               self._gslot is not None)
+               self._gslot is not None,
+               self._res[0].stride(0) if (self._res is not None and not hit) else 0,
+               self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
         if tape is None:
             calls = []
@@ -915,6 +991,12 @@ class TrainEngine:
             cells = {"X": C.c_void_p(X.data_ptr()), "T": C.c_void_p(T.data_ptr()), "idx": C.c_void_p(lS_i.data_ptr())}
             if nxt:
                 cells["next"] = C.c_void_p(next_idx.data_ptr())
+            if self._res is not None and not hit:
+                cells["ws"] = C.c_void_p(self._res[0].data_ptr())
+                cells["wsrc"] = C.c_void_p(self._res[1].data_ptr())
+            if self._next_res is not None:
+                cells["nws"] = C.c_void_p(self._next_res[0].data_ptr())
+                cells["nwsrc"] = C.c_void_p(self._next_res[1].data_ptr())
             by_value = {c.value: c for c in cells.values()}
             if len(by_value) != len(cells):
                 return self.world == 1      # aliased inputs: stay on the untaped path
@@ -935,6 +1017,12 @@ class TrainEngine:
         cells["idx"].value = lS_i.data_ptr()
         if nxt:
             cells["next"].value = next_idx.data_ptr()
+        if "ws" in cells:
+            cells["ws"].value = self._res[0].data_ptr()
+            cells["wsrc"].value = self._res[1].data_ptr()
+        if "nws" in cells:
+            cells["nws"].value = self._next_res[0].data_ptr()
+            cells["nwsrc"].value = self._next_res[1].data_ptr()
         bufs = self._buffers(B)
         (bufs["wgrad_split"][0] if bufs["wgrad_split"] is not None else bufs["wgrad"]).set_x(0, X)
         for fn, args, is_lib in tape["prog"]:

@@ -331,7 +331,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         emb_tables, args):
     """main_no_ddp.py:324-502 on the fused engine.  One process per GPU; `rank` is the device index and the
     distributed rank.  train_ld yields (X, lS_o, lS_i, T) global batches; every rank takes its slice."""
-    from .engine import TrainEngine, WindowPipeline, pad_window, square_bags
+    from .engine import TrainEngine, WindowPipeline, WindowResolver, pad_window, square_bags
     try:
         from setproctitle import setproctitle
         setproctitle("DlrmTrainer:" + str(rank))
@@ -409,6 +409,8 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         it = iter(train_ld)
         window = []
         next_window = None          # look-ahead plan: the window whose plan is already in flight
+        next_win_idx = cur_win_idx = None
+        resolver, wj = None, 0
         carried_idx = None          # device indices of the batch whose probe the previous step already issued
         j = 0
         torch.cuda.synchronize(dev)
@@ -440,18 +442,28 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     break
                 torch.cuda.synchronize(dev)     # the steps issued so far belong to the iteration time, not to the refill
                 start = timer()
+                cur_win_idx = next_win_idx if planned else None
                 if not planned:
-                    pipe.plan_window(window_indices(window))
+                    cur_win_idx = window_indices(window)
+                    pipe.plan_window(cur_win_idx)
                 if world > 1:
                     eng.sync_touched_to_rank0()
                 pipe.commit()
                 pipe.wait_writeback()
+                # window-resident probe (one lookup per bag): the window's lookups are resolved against the new tags once
+                resolver, wj = None, 0
+                if not multi_hot and os.environ.get("CDLRM_WINDOW_RESOLVE", "1") != "0":
+                    if cur_win_idx is None:
+                        cur_win_idx = window_indices(window)
+                    if cur_win_idx.shape[1] == len(window) * args.mini_batch_size:      # whole batches only
+                        resolver = WindowResolver(eng, cur_win_idx, args.mini_batch_size)
                 caching_overhead.append(timer() - start)
                 t_excluded += caching_overhead[-1]
                 if lookahead_plan:
                     next_window = read_window() or None
                     if next_window is not None:     # evictions are in the host tables: the next plan may read them
-                        pipe.plan_window(window_indices(next_window))
+                        next_win_idx = window_indices(next_window)
+                        pipe.plan_window(next_win_idx)
             X, lS_o, lS_i, T = window.pop(0)
             Or = nxt = None
             sl = slice(rank * local_batch_size, (rank + 1) * local_batch_size)
@@ -472,7 +484,13 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 # during this step instead of at the head of the next one
                 nxt = rank_indices(window[0][2]) if window else None
                 carried_idx = nxt
-            lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j, next_idx=nxt)
+            rs = resolver if (resolver is not None and Xr.shape[0] == local_batch_size) else None
+            lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j, next_idx=nxt,
+                               res=rs.batch(wj) if rs is not None else None,
+                               next_res=rs.batch(wj + 1) if (rs is not None and nxt is not None) else None)
+            if rs is not None:
+                rs.ensure(wj + rs.CH + 2)
+            wj += 1
             mbs = Tr.shape[0]
             acc.add_(lossbuf[1:3])              # [#correct, loss * mbs] of this step, left there by the loss kernel
             total_iter += 1

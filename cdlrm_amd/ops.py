@@ -109,6 +109,29 @@ def embbag_probe(ctx: CacheCtx, idx: torch.Tensor, stream=None, aux_phase: int =
     return slots, miss_pos, miss_count
 
 
+def window_resolve(ctx: CacheCtx, idx: torch.Tensor, seg_len: int, wslots: torch.Tensor, wsrc: torch.Tensor, stream=None):
+    """Resolve every lookup of idx [T, n] (n / seg_len consecutive batches) against the CURRENT tags and the bound victim
+    list, once: wslots / wsrc int32 [T, n] contiguous (see include/cdlrm_hip.h)."""
+    _require_cuda(idx, "idx")
+    assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.shape[0] == ctx.T and idx.stride(1) == 1
+    n = idx.shape[1]
+    for w in (wslots, wsrc):
+        assert w.dtype == torch.int32 and tuple(w.shape) == (ctx.T, n) and w.is_contiguous()
+    check(_lib.lib().cdlrm_window_resolve(ctx.handle, idx.data_ptr(), n, idx.stride(0), int(seg_len), wslots.data_ptr(),
+                                          wsrc.data_ptr(), stream_ptr(stream)))
+
+
+def embbag_take(ctx: CacheCtx, idx: torch.Tensor, wslots: torch.Tensor, wsrc: torch.Tensor, slots_out: torch.Tensor,
+                aux_phase: int = 0, stream=None):
+    """One batch out of a resolved window: idx / wslots / wsrc are [T, n] column VIEWS of the window's tensors."""
+    n = idx.shape[1]
+    assert idx.dtype == torch.int64 and idx.stride(1) == 1 and wslots.stride(1) == 1 and wsrc.stride(1) == 1
+    assert wslots.shape == (ctx.T, n) and wsrc.shape == (ctx.T, n) and wslots.stride(0) == wsrc.stride(0)
+    assert slots_out.dtype == torch.int32 and slots_out.shape == (ctx.T, n) and slots_out.is_contiguous()
+    check(_lib.lib().cdlrm_embbag_take(ctx.handle, idx.data_ptr(), n, idx.stride(0), wslots.data_ptr(), wsrc.data_ptr(),
+                                       wslots.stride(0), slots_out.data_ptr(), int(aux_phase), stream_ptr(stream)))
+
+
 def embbag_fwd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.Tensor], out: torch.Tensor,
                ld_bag: int, ld_table: int, n_bags: Optional[int] = None, stream=None):
     n = slots.shape[1]

@@ -91,6 +91,23 @@ int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld
                        int32_t* slots_out, int32_t* miss_pos, int32_t* miss_count, int32_t aux_phase,
                        void* stream);
 
+/* Window-resident form of the same (round 2).  Tags only change at a refill (main_no_ddp.py:393-399), so the tag match
+ * of model_no_ddp.py:163-174, the ordered miss numbering (:176-177) and the lookup of a miss in the window's victim list
+ * need to run ONCE per look-ahead window, not once per iteration:
+ *   cdlrm_window_resolve   idx [T, n] = the lookups of n/seg_len consecutive batches (seg_len = lookups of one batch of one
+ *                          rank).  wslots int32 [T, n]: the slot of every lookup, misses numbered per segment in position
+ *                          order as P_k*ways + i (aux phase 0); wsrc int32 [T, n]: for a miss, the position of its row in
+ *                          the bound victim rows (cdlrm_ctx_bind_victims), -1 = read the host table; undefined for hits.
+ *                          Call after the window's cdlrm_plan_commit + cdlrm_ctx_bind_victims.
+ *   cdlrm_embbag_take      per iteration: slots_out int32 [T, n] = the batch's columns of wslots (misses moved to aux
+ *                          region aux_phase) and the misses' rows copied into their aux rows -- exactly what
+ *                          cdlrm_embbag_probe leaves behind for that batch.  wslots / wsrc / idx point at the batch's
+ *                          first column; ld_w / ld_idx are the row strides. */
+int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, int64_t seg_len,
+                         int32_t* wslots, int32_t* wsrc, void* stream);
+int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, const int32_t* wslots,
+                      const int32_t* wsrc, int64_t ld_w, int32_t* slots_out, int32_t aux_phase, void* stream);
+
 /* Fused multi-table sum-pool gather: nn.EmbeddingBag(mode="sum") forward on the cache rows for all
  * T tables in one launch (model_no_ddp.py:200-203).
  *   slots    device int32 [T, n]

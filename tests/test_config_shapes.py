@@ -31,9 +31,10 @@ def t(a):
     return torch.from_numpy(np.asarray(a))
 
 
-@pytest.mark.parametrize("name,chunks,pipelined", [("train_c3shape", 0, True), ("train_c2shape", 0, True),
-                                                   ("train_c5shape", 3, True), ("train_c3shape", 2, False)])
-def test_config_shaped_training_vs_reference(golden, name, chunks, pipelined):
+@pytest.mark.parametrize("name,chunks,pipelined,resolved", [("train_c3shape", 0, True, False), ("train_c2shape", 0, True, True),
+                                                            ("train_c5shape", 3, True, False), ("train_c3shape", 2, False, False),
+                                                            ("train_c3shape", 0, True, True), ("train_c5shape", 0, True, True)])
+def test_config_shaped_training_vs_reference(golden, name, chunks, pipelined, resolved):
     from test_engine_parity import build, make_batches
     g = golden(name)
     host, cg, dl, eng, pipe = build(g)
@@ -54,8 +55,16 @@ def test_config_shaped_training_vs_reference(golden, name, chunks, pipelined):
                 pipe.plan_window(win)
             pipe.commit()
             pipe.wait_writeback()
+            rs = None
+            if resolved:        # window-resident probe: tag match once per window, cdlrm_embbag_take per step
+                from cdlrm_amd.engine import WindowResolver
+                rs = WindowResolver(eng, win, int(g["B"]), chunk=2)
         nxt = dev_idx[j + 1] if pipelined and j + 1 < len(batches) and (j + 1) % L != 0 else None
-        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt)
+        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt,
+                        res=rs.batch(j % L) if rs is not None else None,
+                        next_res=rs.batch(j % L + 1) if (rs is not None and nxt is not None) else None)
+        if rs is not None:
+            rs.ensure(j % L + rs.CH + 2)
         losses.append(loss[0:1].clone())
     losses = np.array([float(x) for x in losses])
     cg.ctx.check()
@@ -115,6 +124,8 @@ def _run_full_size(config, host, L, n_windows, steps_per_window):
         pipe.plan_window(win)
         pipe.commit()
         _check_cache_invariants(cg)
+        from cdlrm_amd.engine import WindowResolver
+        rs = WindowResolver(eng, win, B)              # as bench.py: the window's lookups resolved once
         for jj in range(steps_per_window):
             idx = win[:, jj * B:(jj + 1) * B]
             X, Tt = syn.dense(wi * L + jj)
@@ -131,7 +142,9 @@ def _run_full_size(config, host, L, n_windows, steps_per_window):
                 rows_before = slots.to(torch.int64) + rb
                 snapshot = cg.weight.data[rows_before[:, :4096].reshape(-1)].view(T, -1, cg.m_spa).clone()
                 eng._pref = None                     # the in-line probe above replaced any prefetched one
-            lossbuf = eng.step(X, idx, Tt, j=jj, next_idx=nxt)
+            lossbuf = eng.step(X, idx, Tt, j=jj, next_idx=nxt, res=rs.batch(jj),
+                               next_res=rs.batch(jj + 1) if nxt is not None else None)
+            rs.ensure(jj + rs.CH + 2)
             losses.append(lossbuf[0:1].clone())
             if check_rows:
                 # gather == row copy: feat[:, k+1] is bit-exactly the cache row the probe resolved (one lookup per bag)

@@ -50,11 +50,14 @@ def build(g, world=1, rank=0, host=None, aux_phases=2):
     return host, cg, dl, eng, pipe
 
 
-@pytest.mark.parametrize("name,pipelined,aux_phases", [("train_small", False, 2), ("train_c1", False, 2),
-                                                        ("train_small", True, 2), ("train_c1", True, 2),
-                                                        ("train_small", True, 1), ("train_stream", False, 2),
-                                                        ("train_stream", True, 2)])
-def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases):
+@pytest.mark.parametrize("name,pipelined,aux_phases,resolved", [
+    ("train_small", False, 2, False), ("train_c1", False, 2, False), ("train_small", True, 2, False),
+    ("train_c1", True, 2, False), ("train_small", True, 1, False), ("train_stream", False, 2, False),
+    ("train_stream", True, 2, False),
+    # window-resident probe (engine.WindowResolver): the window's lookups resolved once per window, cdlrm_embbag_take per step
+    ("train_small", True, 2, True), ("train_c1", True, 2, True), ("train_small", False, 2, True),
+    ("train_small", True, 1, True), ("train_stream", True, 2, True)])
+def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, resolved):
     """pipelined: the next batch's indices are handed to step() (as bench.py does inside a window), so its tag probe
     and aux-row fill run during the current step, into the other aux region (aux_phases = 2) or behind the current
     embedding update (aux_phases = 1).  Same trajectory either way."""
@@ -73,8 +76,16 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases):
             pipe.plan_window(win)
             pipe.commit()
             pipe.wait_writeback()
+            rs = None
+            if resolved:
+                from cdlrm_amd.engine import WindowResolver
+                rs = WindowResolver(eng, win, int(g["B"]), chunk=3)
         nxt = dev_idx[j + 1] if pipelined and j + 1 < len(batches) and (j + 1) % L != 0 else None
-        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt)
+        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt,
+                        res=rs.batch(j % L) if rs is not None else None,
+                        next_res=rs.batch(j % L + 1) if (rs is not None and nxt is not None) else None)
+        if rs is not None:
+            rs.ensure(j % L + rs.CH + 2)
         losses.append(loss[0:1].clone())
     losses = [float(x) for x in losses]
     cg.ctx.check()

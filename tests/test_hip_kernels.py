@@ -76,6 +76,64 @@ def test_probe_and_gather_forward(ops, golden, name):
         assert torch.all(feat[:, 0, :] == 0)
 
 
+@pytest.mark.parametrize("with_victims", [False, True])
+def test_window_resolve_take_equals_probe(ops, with_victims):
+    """The window-resident probe (cdlrm_window_resolve once per window + cdlrm_embbag_take per batch) leaves exactly what
+    cdlrm_embbag_probe leaves for every batch: the same slot ids (misses numbered per batch in position order, in the
+    requested aux region) and the same aux rows -- with the misses' rows coming from the host tables or, when a window's
+    victim rows are bound, from there (and from the host for misses the list does not hold)."""
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Cache_Group, Embedding_Table_Group
+    from cdlrm_amd.engine import WindowPipeline
+    rng = np.random.RandomState(12)
+    ln_emb, D, ways, B, nb, cache = np.array([5000, 64, 9, 1300, 20000]), 16, 4, 96, 7, 50
+    T = len(ln_emb)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    host = Embedding_Table_Group(D, ln_emb).pin()
+    cg = Embedding_Table_Cache_Group(D, ln_emb, cache, B, ways).to(DEV)
+    ctx = cg.ctx
+    ctx.bind_host_tables(host.device_pointers())
+    win = torch.stack([torch.from_numpy((rng.zipf(1.15, size=nb * B).astype(np.int64) * 2654435761 % n)) for n in ln_emb]).to(DEV)
+    pipe = WindowPipeline(cg, host, nb * B, parity_rng=False, seed=5, victim_rows=(400 if with_victims else 0))
+    prev = torch.stack([torch.from_numpy(rng.randint(0, n, size=nb * B).astype(np.int64)) for n in ln_emb]).to(DEV)
+    for w in (prev, win):           # two windows: the second insert meets full sets -> victims
+        pipe.plan_window(w)
+        pipe.commit()
+        pipe.wait_writeback()
+    torch.cuda.synchronize()
+    if with_victims:
+        nv = int(pipe.victims[pipe._vnext ^ 1].off.cpu()[-1])
+        assert 0 < nv, "the fixture must produce victims"
+    # lookups: the window's own batches plus ids the window never saw (host fallback)
+    look = win.clone()
+    for k, n in enumerate(ln_emb):
+        look[k, ::7] = torch.from_numpy(rng.randint(0, n, size=look[k, ::7].numel())).to(DEV)
+    ws = torch.empty(T, nb * B, dtype=torch.int32, device=DEV)
+    wsrc = torch.empty_like(ws)
+    ops.window_resolve(ctx, look, B, ws, wsrc)
+    for phase in (0, 1):
+        for j in range(nb):
+            idx = look[:, j * B:(j + 1) * B]
+            cg.weight.data[:] = cg.weight.data         # no-op; keeps the buffer identity
+            slots_p, _, mc = ops.embbag_probe(ctx, idx.contiguous(), aux_phase=phase)
+            torch.cuda.synchronize()
+            rows_p = cg.weight.data.clone()
+            # wipe the aux rows, then take
+            for k in range(T):
+                a0 = cg.row_base[k] + ways * cg.cache_sizes[k]
+                cg.weight.data[a0:a0 + 2 * B] = -7.0
+            slots_t = torch.empty(T, B, dtype=torch.int32, device=DEV)
+            ops.embbag_take(ctx, idx, ws[:, j * B:(j + 1) * B], wsrc[:, j * B:(j + 1) * B], slots_t, aux_phase=phase)
+            torch.cuda.synchronize()
+            assert torch.equal(slots_t, slots_p), (phase, j)
+            assert int(mc.sum()) > 0
+            for k in range(T):
+                a0 = cg.row_base[k] + ways * cg.cache_sizes[k] + phase * B
+                m = int(mc[k])
+                assert torch.equal(cg.weight.data[a0:a0 + m], rows_p[a0:a0 + m]), (phase, j, k)
+    ctx.check()
+
+
 def test_appendix_a(ops, golden):
     g = golden("appendix_a")
     P = int(g["P"][0])
