@@ -16,27 +16,59 @@ __global__ void __launch_bounds__(256) k_probe(const TableDesc* __restrict__ tab
                                                const int64_t* __restrict__ tags,
                                                const int64_t* __restrict__ idx, int64_t n, int64_t ld_idx,
                                                int32_t* __restrict__ slots, int* err) {
+    // PU lookups per lane group and pass, phased (all ids, then all tag words, then the reductions): a group's set is one
+    // random 128-B line, so what bounds the probe is the number of lines in flight, not the arithmetic
+    constexpr int PU = 4;
     const int t = blockIdx.y;
     const TableDesc d = tab[t];
     const int g = threadIdx.x % LPL;
     const int64_t grp0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPL;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / LPL;
-    const int64_t n_round = cdiv_dev(n, ngrp) * ngrp;
-    for (int64_t i = grp0; i < n_round; i += ngrp) {
-        const bool valid = i < n;
-        int64_t v = valid ? idx[(int64_t)t * ld_idx + i] : 0;
-        bool bad = valid && (v < 0 || v >= d.n_rows);
-        if (bad) v = 0;
-        const int64_t set = mod_sets(v, d.P);
-        const int64_t* tg = tags + d.tag_base + set * ways;
-        int found = 0x7fffffff;
-        for (int w = g; w < ways; w += LPL)
-            if (tg[w] == v) found = w;
+    const int64_t n_round = cdiv_dev(n, ngrp * PU) * ngrp * PU;
+    for (int64_t i0 = grp0; i0 < n_round; i0 += ngrp * PU) {
+        int64_t v[PU], set[PU];
+        bool valid[PU], bad[PU];
 #pragma unroll
-        for (int m = LPL >> 1; m >= 1; m >>= 1) found = min(found, __shfl_xor(found, m, LPL));
-        if (valid && g == 0) {
-            slots[(int64_t)t * n + i] = (found == 0x7fffffff) ? -1 : (int32_t)(d.P * found + set);
-            if (bad) atomicOr(err, 1);
+        for (int u = 0; u < PU; ++u) {
+            const int64_t i = i0 + u * ngrp;
+            valid[u] = i < n;
+            v[u] = idx[(int64_t)t * ld_idx + min(i, n - 1)];
+        }
+        int found[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            bad[u] = valid[u] && (v[u] < 0 || v[u] >= d.n_rows);
+            if (bad[u] || !valid[u]) v[u] = 0;
+            set[u] = mod_sets(v[u], d.P);
+            found[u] = 0x7fffffff;
+        }
+        if (LPL >= 16 || ways <= LPL) {         // one tag word per lane (the common geometry): loads of the PU sets back to back
+            int64_t tw[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) tw[u] = g < ways ? tags[d.tag_base + set[u] * ways + g] : -2;
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+                if (g < ways && tw[u] == v[u]) found[u] = g;
+            if (ways > LPL) {                   // more ways than lanes (ways > 16): the remaining words
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                    for (int w = g + LPL; w < ways; w += LPL)
+                        if (tags[d.tag_base + set[u] * ways + w] == v[u]) found[u] = min(found[u], w);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+                for (int w = g; w < ways; w += LPL)
+                    if (tags[d.tag_base + set[u] * ways + w] == v[u]) found[u] = min(found[u], w);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+#pragma unroll
+            for (int m = LPL >> 1; m >= 1; m >>= 1) found[u] = min(found[u], __shfl_xor(found[u], m, LPL));
+            if (valid[u] && g == 0) {
+                slots[(int64_t)t * n + i0 + u * ngrp] = (found[u] == 0x7fffffff) ? -1 : (int32_t)(d.P * found[u] + set[u]);
+                if (bad[u]) atomicOr(err, 1);
+            }
         }
     }
 }
