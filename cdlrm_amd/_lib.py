@@ -65,6 +65,8 @@ PROTOTYPES = {
     "cdlrm_embbag_bwd_apply": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),
     "cdlrm_qr_embbag_fwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "cdlrm_qr_embbag_bwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp]),
+    "cdlrm_bag_fwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, c_i64, c_i32, vp, vp, vp]),
+    "cdlrm_bag_bwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_window_unique": (C.c_int, [vp, C.POINTER(Plan), vp, c_i64, c_i64, vp]),
     "cdlrm_window_unique_add": (C.c_int, [vp, C.POINTER(Plan), vp, c_i64, c_i64, vp]),
     "cdlrm_window_unique_finish": (C.c_int, [vp, C.POINTER(Plan), vp]),

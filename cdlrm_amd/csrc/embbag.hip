@@ -11,14 +11,14 @@
 // consecutive lanes -> consecutive tags -> one coalesced segment per set).
 // model_no_ddp.py:166-174
 // ---------------------------------------------------------------------------------------------
-template <int LPL>
+template <int LPL, int PU>
 __global__ void __launch_bounds__(256) k_probe(const TableDesc* __restrict__ tab, int ways,
                                                const int64_t* __restrict__ tags,
                                                const int64_t* __restrict__ idx, int64_t n, int64_t ld_idx,
                                                int32_t* __restrict__ slots, int* err) {
     // PU lookups per lane group and pass, phased (all ids, then all tag words, then the reductions): a group's set is one
-    // random 128-B line, so what bounds the probe is the number of lines in flight, not the arithmetic
-    constexpr int PU = 4;
+    // random 128-B line, so what bounds a LONG probe (a window chunk: millions of lookups) is the number of lines in flight
+    // per wave; a single batch has fewer lookups than the grid has lane groups and uses PU = 1
     const int t = blockIdx.y;
     const TableDesc d = tab[t];
     const int g = threadIdx.x % LPL;
@@ -393,7 +393,7 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
     int64_t gx = cdiv(n, groups_per_block);
     if (gx > 4096) gx = 4096;
     dim3 grid((unsigned)gx, (unsigned)ctx->T);
-#define PROBE_CALL(L) hipLaunchKernelGGL(k_probe<L>, grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, slots_out, ctx->d_err)
+#define PROBE_CALL(L) hipLaunchKernelGGL((k_probe<L, 1>), grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, slots_out, ctx->d_err)
     switch (lpl) {
         case 1: PROBE_CALL(1); break;
         case 2: PROBE_CALL(2); break;
@@ -509,7 +509,7 @@ extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t 
     int64_t gx = cdiv(n, 256 / lpl);
     if (gx > 8192) gx = 8192;
     dim3 grid((unsigned)gx, (unsigned)ctx->T);
-#define PROBE_CALL(L) hipLaunchKernelGGL(k_probe<L>, grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, wslots, ctx->d_err)
+#define PROBE_CALL(L) hipLaunchKernelGGL((k_probe<L, 4>), grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, wslots, ctx->d_err)
     switch (lpl) {
         case 1: PROBE_CALL(1); break;
         case 2: PROBE_CALL(2); break;

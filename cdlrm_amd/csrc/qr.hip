@@ -136,3 +136,67 @@ extern "C" int cdlrm_qr_embbag_bwd(const int64_t* idx, const int64_t* offsets, i
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Plain stand-alone EmbeddingBag(mode="sum") over ONE table of any width (the mixed-dimension trick's
+// PrEmbeddingBag.embs, tricks/md_embedding_bag.py:60-78: widths are powers of two down to 1, so no 16-byte rows
+// can be assumed).  One thread per output element; backward = dense gradient by float atomics (stand-alone operator,
+// not on the cached training step).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bag_fwd(const int64_t* __restrict__ idx, const int64_t* __restrict__ offsets,
+                                                 int64_t n, int64_t n_bags, const float* __restrict__ W, int64_t rows, int D,
+                                                 float* __restrict__ out, int* err) {
+    const int64_t total = n_bags * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = e / D;
+        const int c = (int)(e % D);
+        const int64_t lo = offsets[b], hi = (b + 1 < n_bags) ? offsets[b + 1] : n;
+        float acc = 0.f;
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t v = idx[i];
+            if (v < 0 || v >= rows) { atomicOr(err, 1); v = 0; }
+            acc += W[v * D + c];
+        }
+        out[e] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bag_bwd(const int64_t* __restrict__ idx, const int64_t* __restrict__ offsets,
+                                                 int64_t n, int64_t n_bags, const float* __restrict__ gout, int64_t rows,
+                                                 int D, float* __restrict__ gW) {
+    const int64_t total = n_bags * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = e / D;
+        const int c = (int)(e % D);
+        const int64_t lo = offsets[b], hi = (b + 1 < n_bags) ? offsets[b + 1] : n;
+        const float g = gout[e];
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t v = idx[i];
+            if (v >= 0 && v < rows) atomicAdd(gW + v * D + c, g);
+        }
+    }
+}
+
+extern "C" int cdlrm_bag_fwd(const int64_t* idx, const int64_t* offsets, int64_t n, int64_t n_bags, const float* W,
+                             int64_t rows, int32_t dim, float* out, int32_t* err_word, void* stream) {
+    CDLRM_REQUIRE(idx && offsets && W && out && err_word && dim >= 1 && rows >= 1, "bad argument");
+    if (n_bags == 0) return 0;
+    int64_t gx = cdiv(n_bags * dim, 256);
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(k_bag_fwd, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, idx, offsets, n, n_bags, W, rows,
+                       (int)dim, out, err_word);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdlrm_bag_bwd(const int64_t* idx, const int64_t* offsets, int64_t n, int64_t n_bags, const float* grad_out,
+                             int64_t rows, int32_t dim, float* gW, void* stream) {
+    CDLRM_REQUIRE(idx && offsets && grad_out && gW && dim >= 1 && rows >= 1, "bad argument");
+    if (n_bags == 0) return 0;
+    int64_t gx = cdiv(n_bags * dim, 256);
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(k_bag_bwd, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, idx, offsets, n, n_bags, grad_out, rows,
+                       (int)dim, gW);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}

@@ -632,6 +632,12 @@ def main(argv=None):
     ln_top = np.fromstring(str(num_int) + "-" + args.arch_mlp_top, dtype=int, sep="-")
     if m_spa != m_den_out:
         sys.exit("ERROR: arch-sparse-feature-size " + str(m_spa) + " does not match last dim of bottom mlp " + str(m_den_out))
+    if args.md_flag or args.qr_flag:
+        # the reference computes md_solver's width list here and then builds plain tables from it (main_no_ddp.py:612-621),
+        # which raises in nn.EmbeddingBag; --qr-flag only changes a width check (:579-596), the tables stay plain.  A cache row has one width and one source
+        # row, so neither trick has cached semantics: the operators are available stand-alone
+        # (cdlrm_amd.tricks, Embedding_Table_Group(qr_flag= / md_flag=)).
+        sys.exit("ERROR: --md-flag / --qr-flag tables cannot feed the embedding cache (stand-alone operators only)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.world_size > 1:

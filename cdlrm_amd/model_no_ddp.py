@@ -71,11 +71,6 @@ class Embedding_Table_Group(nn.Module):
             self.md_flag = md_flag
             if self.md_flag:
                 self.md_threshold = md_threshold
-            if md_flag:
-                # dead at the reference's CLI as well: md_solver turns m_spa into a per-table list
-                # (main_no_ddp.py:612-618) and the group is then built WITHOUT md_flag (:621), so nn.EmbeddingBag(n, <list>)
-                # raises there; cache rows have one width, so mixed widths have no cached semantics to match
-                raise NotImplementedError("mixed-dimension tables (--md-flag) are not part of the cached path")
             self.m_spa = m_spa
             self.emb_l = self.create_emb(m_spa, np.asarray(ln_emb), init)
 
@@ -90,6 +85,23 @@ class Embedding_Table_Group(nn.Module):
                 emb_l.append(QREmbeddingBag(n, m, self.qr_collisions, operation=self.qr_operation, mode="sum",
                                             sparse=True))
                 continue
+            if self.md_flag and n > self.md_threshold:
+                # model_no_ddp.py:57-66: m is the per-table width list (md_solver); PrEmbeddingBag of width m[i] projected
+                # to max(m), its table drawn from the numpy generator like the plain ones.  Stand-alone HIP operator
+                # (cdlrm_amd/tricks/md_embedding_bag.py): a cache row has ONE width, so such a table cannot feed the
+                # cache -- no `.weight`, as in the reference.  Dead at the reference's CLI (main_no_ddp.py:612-621 builds
+                # the group without md_flag).
+                from .tricks.md_embedding_bag import PrEmbeddingBag
+                _m, base = int(m[i]), int(max(m))
+                EE = PrEmbeddingBag(n, _m, base)
+                W = np.random.uniform(low=-np.sqrt(1 / n), high=np.sqrt(1 / n), size=(n, _m)).astype(np.float32)
+                EE.embs.weight.data = torch.tensor(W, requires_grad=False)
+                emb_l.append(EE)
+                continue
+            if not isinstance(m, (int, np.integer)):
+                # the reference reaches nn.EmbeddingBag(n, <list>) here and raises the same TypeError
+                raise TypeError("a plain table needs one integer width, got %r (table %d is not above md_threshold)"
+                                % (m, i))
             if init == "numpy":
                 W = np.random.uniform(low=-np.sqrt(1 / n), high=np.sqrt(1 / n), size=(n, m)).astype(np.float32)
                 Wt = torch.from_numpy(W)
@@ -137,9 +149,10 @@ class Embedding_Table_Group(nn.Module):
     def _plain(self, E, k):
         if not hasattr(E, "weight"):
             # the reference fails the same way: fetch_unique_idx_slices reads E.weight (model_no_ddp.py:84), which a
-            # QREmbeddingBag (weight_q / weight_r) does not have -- QR tables cannot feed the cache
-            raise AttributeError("'%s' object has no attribute 'weight' (table %d is a quotient-remainder table; the "
-                                 "cached path needs plain host tables)" % (type(E).__name__, k))
+            # QREmbeddingBag (weight_q / weight_r) or PrEmbeddingBag (embs.weight) does not have -- such tables cannot feed
+            # the cache
+            raise AttributeError("'%s' object has no attribute 'weight' (table %d is a quotient-remainder / mixed-"
+                                 "dimension table; the cached path needs plain host tables)" % (type(E).__name__, k))
         return E
 
     def device_pointers(self) -> List[int]:

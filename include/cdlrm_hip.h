@@ -276,6 +276,16 @@ int cdlrm_qr_embbag_bwd(const int64_t* idx, const int64_t* offsets, int64_t n, i
                         const float* eq, const float* er, const float* grad_out, int64_t rows_q,
                         int32_t collisions, int32_t dim, int32_t op, float* gWq, float* gWr, void* stream);
 
+/* Plain EmbeddingBag(mode="sum") over one stand-alone table of ANY width, forward and dense backward: the `embs` of the
+ * mixed-dimension trick's PrEmbeddingBag (tricks/md_embedding_bag.py:60-78; its widths are powers of two down to 1).
+ * Stand-alone operator like the QR bag: the reference never wires it into the cached path (main_no_ddp.py:612-621).
+ *   out [n_bags, dim] = sum over the bag's indices of W[idx];  gW [rows, dim] += grad_out[bag] (float atomics).
+ *   err_word: device int32, bit 0 set when an index lies outside [0, rows). */
+int cdlrm_bag_fwd(const int64_t* idx, const int64_t* offsets, int64_t n, int64_t n_bags, const float* W, int64_t rows,
+                  int32_t dim, float* out, int32_t* err_word, void* stream);
+int cdlrm_bag_bwd(const int64_t* idx, const int64_t* offsets, int64_t n, int64_t n_bags, const float* grad_out,
+                  int64_t rows, int32_t dim, float* gW, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Table aggregation (broadcast_and_aggregate, main_no_ddp.py:250-292)
  * ------------------------------------------------------------------------------------------- */

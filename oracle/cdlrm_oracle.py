@@ -454,6 +454,43 @@ def qr_embedding_bag(idx, offsets, weight_q, weight_r, num_collisions: int, oper
 
 
 # --------------------------------------------------------------------------------------------------
+# a-16 mixed-dimension trick  (tricks/md_embedding_bag.py:20-78)
+# --------------------------------------------------------------------------------------------------
+
+
+def md_solver(n, alpha, d0=None, B=None, round_dim=True, k=None):
+    """md_embedding_bag.py:20-57 in numpy float32: sizes sorted ascending (result stays in that order), divided by the
+    query counts, d = lambda * n^-alpha with lambda = d0 * n_min^alpha or B / sum n^(1-alpha); clamp at 1, entry 0 = d0
+    when given; round half-to-even to long; optional round(log2) to a power of two (returned as float32)."""
+    n = np.asarray(n, dtype=np.int64)
+    order = np.argsort(n, kind="stable")
+    nf = n[order].astype(np.float32)
+    kk = np.ones(len(n), dtype=np.float32) if k is None else np.asarray(k, dtype=np.float32)[order]
+    nf = (nf / kk).astype(np.float32)
+    a = np.float32(alpha)
+    if d0 is not None:
+        lamb = np.float32(d0) * np.power(nf[0], a, dtype=np.float32)
+    elif B is not None:
+        lamb = np.float32(B) / np.sum(np.power(nf, np.float32(1) - a, dtype=np.float32), dtype=np.float32)
+    else:
+        raise ValueError("Must specify either d0 or B")
+    d = (np.float32(lamb) * np.power(nf, -a, dtype=np.float32)).astype(np.float32)
+    d = np.maximum(d, np.float32(1))
+    if d0 is not None:
+        d[0] = d0
+    d = np.rint(d).astype(np.int64)
+    if round_dim:
+        return np.power(np.float32(2), np.rint(np.log2(d.astype(np.float32)))).astype(np.float32)
+    return d
+
+
+def pr_embedding_bag(idx, offsets, weight, proj=None):
+    """md_embedding_bag.py:60-78: sum-pooled bag of width embedding_dim, then x @ proj^T (no bias) when given."""
+    e = torch.nn.functional.embedding_bag(idx, weight, offsets, mode="sum")
+    return e if proj is None else torch.nn.functional.linear(e, proj)
+
+
+# --------------------------------------------------------------------------------------------------
 # a-14 the whole training loop, W ranks emulated in-process  (main_no_ddp.py:324-502)
 # --------------------------------------------------------------------------------------------------
 

@@ -298,6 +298,40 @@ def test_qr_flag_builds_quotient_remainder_host_tables():
         eg.fetch_unique_idx_slices([torch.tensor([1, 2]) for _ in ln_emb])
 
 
+def test_md_flag_builds_mixed_dimension_host_tables():
+    """Embedding_Table_Group(md_flag=True) (model_no_ddp.py:57-66) with md_solver's per-table widths: tables above
+    md_threshold become PrEmbeddingBag(n, m[i], max(m)) drawn from the numpy stream; forward() runs the HIP operator and
+    every table comes out max(m) wide; a table at or below the threshold fails as in the reference (one width needed)."""
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    from cdlrm_amd.tricks.md_embedding_bag import PrEmbeddingBag, md_solver
+    from oracle import cdlrm_oracle as O
+    ln_emb = np.array([300, 90000, 2500])
+    m = md_solver(torch.tensor(ln_emb), 0.3, d0=16, round_dim=True).long().tolist()     # sorted-table order, as :612-618
+    assert m == [int(x) for x in O.md_solver(ln_emb, 0.3, d0=16)] and m[0] == 16 and m[-1] < 16
+    np.random.seed(9)
+    torch.manual_seed(9)
+    eg = Embedding_Table_Group(m, ln_emb, md_flag=True, md_threshold=200)
+    assert all(isinstance(E, PrEmbeddingBag) for E in eg.emb_l)
+    np.random.seed(9)
+    for k, n in enumerate(ln_emb):
+        want = np.random.uniform(low=-np.sqrt(1 / n), high=np.sqrt(1 / n), size=(n, m[k])).astype(np.float32)
+        assert np.array_equal(eg.emb_l[k].embs.weight.data.numpy(), want)
+    eg = eg.to(DEV)
+    rng = np.random.RandomState(2)
+    lS_i = [torch.from_numpy(rng.randint(0, n, 12)) for n in ln_emb]
+    lS_o = [torch.tensor([0, 3, 4, 9]) for _ in ln_emb]
+    ly = eg([o.to(DEV) for o in lS_o], [i.to(DEV) for i in lS_i])
+    for k, E in enumerate(eg.emb_l):
+        P = E.proj.weight.detach().cpu() if m[k] < max(m) else None
+        ref = O.pr_embedding_bag(lS_i[k], lS_o[k], E.embs.weight.detach().cpu(), P)
+        assert tuple(ly[k].shape) == (4, max(m))
+        np.testing.assert_allclose(ly[k].detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(AttributeError):
+        eg.fetch_unique_idx_slices([torch.tensor([1, 2]) for _ in ln_emb])
+    with pytest.raises(TypeError):
+        Embedding_Table_Group(m, ln_emb, md_flag=True, md_threshold=1000)
+
+
 # ---- two trainer processes: aggregate_gradients + broadcast_and_aggregate + load_caches_and_broadcast ----------------
 
 def _w2_worker(rid, port, name, host_shared, ret):

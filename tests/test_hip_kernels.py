@@ -605,6 +605,37 @@ def test_qr_embedding_bag_golden(ops, golden):
     assert int(g["big_q"][4]) == 10_000_000
 
 
+def test_md_embedding_bag_golden(ops, golden):
+    """PrEmbeddingBag (mixed-dimension trick) forward + gradients vs the reference's module: widths 1, 2, 4, 8, with and
+    without the projection, empty bags; md_solver's widths vs the reference's."""
+    from cdlrm_amd.tricks.md_embedding_bag import PrEmbeddingBag, md_solver
+    g = golden("md")
+    for name in ("criteo", "b_budget", "noround", "alpha0"):
+        d0, B = int(g[f"solver_{name}_d0"]), float(g[f"solver_{name}_B"])
+        d = md_solver(t(g[f"solver_{name}_n"]), float(g[f"solver_{name}_alpha"]), d0=None if d0 < 0 else d0,
+                      B=None if B < 0 else B, round_dim=bool(g[f"solver_{name}_round"]))
+        assert np.array_equal(d.double().numpy(), g[f"solver_{name}_d"].astype(np.float64)), name
+    d = md_solver(torch.tensor([100, 5000, 70, 900000]), 0.25, d0=16, k=t(g["solver_k_k"]))
+    assert np.array_equal(d.double().numpy(), g["solver_k_d"].astype(np.float64))
+    for name in ("proj", "ident", "w1", "w2"):
+        W = t(g[f"{name}_W"])
+        E = PrEmbeddingBag(W.shape[0], W.shape[1], int(g[f"{name}_base"])).to(DEV)
+        with torch.no_grad():
+            E.embs.weight.copy_(W)
+            if f"{name}_P" in g.files:
+                E.proj.weight.copy_(t(g[f"{name}_P"]))
+        V = E(t(g[f"{name}_idx"]).to(DEV), t(g[f"{name}_offs"]).to(DEV))
+        np.testing.assert_allclose(V.detach().cpu().numpy(), g[f"{name}_V"], rtol=1e-5, atol=1e-6)
+        V.backward(t(g[f"{name}_G"]).to(DEV))
+        np.testing.assert_allclose(E.embs.weight.grad.cpu().numpy(), g[f"{name}_gW"], rtol=1e-5, atol=1e-6)
+        if f"{name}_P" in g.files:
+            np.testing.assert_allclose(E.proj.weight.grad.cpu().numpy(), g[f"{name}_gP"], rtol=1e-5, atol=1e-5)
+    with pytest.raises(IndexError):
+        E(torch.tensor([W.shape[0]], device=DEV), torch.tensor([0], device=DEV))
+    with pytest.raises(ValueError):
+        PrEmbeddingBag(10, 16, 8)
+
+
 def test_sgd_and_agg(ops):
     p = torch.randn(100003, device=DEV)
     gr = torch.randn(100003, device=DEV)

@@ -299,6 +299,27 @@ def test_qr_operator(golden):
         np.testing.assert_allclose(wr.grad.numpy(), g[f"{op}_gr"], rtol=1e-6, atol=1e-7)
 
 
+def test_md_operator(golden):
+    """Mixed-dimension trick: the solver's widths and PrEmbeddingBag forward/gradients vs the reference's module."""
+    g = golden("md")
+    for name in ("criteo", "b_budget", "noround", "alpha0"):
+        d0, B = int(g[f"solver_{name}_d0"]), float(g[f"solver_{name}_B"])
+        d = O.md_solver(g[f"solver_{name}_n"], float(g[f"solver_{name}_alpha"]), d0=None if d0 < 0 else d0,
+                        B=None if B < 0 else B, round_dim=bool(g[f"solver_{name}_round"]))
+        assert np.array_equal(np.asarray(d, dtype=np.float64), g[f"solver_{name}_d"].astype(np.float64)), name
+    d = O.md_solver([100, 5000, 70, 900000], 0.25, d0=16, k=g["solver_k_k"])
+    assert np.array_equal(np.asarray(d, dtype=np.float64), g["solver_k_d"].astype(np.float64))
+    for name in ("proj", "ident", "w1", "w2"):
+        W = t(g[f"{name}_W"]).requires_grad_(True)
+        P = t(g[f"{name}_P"]).requires_grad_(True) if f"{name}_P" in g.files else None
+        V = O.pr_embedding_bag(t(g[f"{name}_idx"]), t(g[f"{name}_offs"]), W, P)
+        assert torch.equal(V, t(g[f"{name}_V"]))
+        V.backward(t(g[f"{name}_G"]))
+        np.testing.assert_allclose(W.grad.numpy(), g[f"{name}_gW"], rtol=1e-6, atol=1e-7)
+        if P is not None:
+            np.testing.assert_allclose(P.grad.numpy(), g[f"{name}_gP"], rtol=1e-6, atol=1e-7)
+
+
 def test_window_groups(golden):
     g = golden("window_groups")
     ci = 0

@@ -679,6 +679,43 @@ def g_qr(M, MD, CM, QR):
     save("qr", **out)
 
 
+def g_md(M, MD, CM, QR):
+    """Mixed-dimension trick: md_solver on a few size lists, PrEmbeddingBag forward/backward with and without the
+    projection, including widths 1 and 2."""
+    from tricks import md_embedding_bag as MDT  # noqa
+    torch.manual_seed(5)
+    out = {}
+    cases = [("criteo", [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145], 0.3, 16, None, True),
+             ("b_budget", [100, 5000, 70, 900000], 0.25, None, 40000.0, True),
+             ("noround", [12, 400, 33000, 7], 0.4, 32, None, False),
+             ("alpha0", [50, 60, 70], 0.0, 8, None, True)]
+    for name, n, alpha, d0, B, rd in cases:
+        d = MDT.md_solver(torch.tensor(n), alpha, d0=d0, B=B, round_dim=rd)
+        out[f"solver_{name}_n"] = np.array(n)
+        out[f"solver_{name}_alpha"] = alpha
+        out[f"solver_{name}_d0"] = -1 if d0 is None else d0
+        out[f"solver_{name}_B"] = -1.0 if B is None else B
+        out[f"solver_{name}_round"] = int(rd)
+        out[f"solver_{name}_d"] = d
+    k = torch.tensor([1.0, 2.0, 1.0, 4.0])
+    out["solver_k_d"] = MDT.md_solver(torch.tensor([100, 5000, 70, 900000]), 0.25, d0=16, k=k)
+    out["solver_k_k"] = k
+    for name, ncat, ed, bd in (("proj", 211, 4, 16), ("ident", 97, 8, 8), ("w1", 53, 1, 8), ("w2", 64, 2, 32)):
+        E = MDT.PrEmbeddingBag(ncat, ed, bd)
+        idx = torch.randint(0, ncat, (41,))
+        offs = torch.tensor([0, 1, 1, 4, 9, 20, 33, 41])       # an empty bag inside and at the end
+        V = E(idx, offs)
+        G = torch.randn_like(V)
+        V.backward(G)
+        out.update({f"{name}_W": E.embs.weight.detach().clone(), f"{name}_idx": idx, f"{name}_offs": offs,
+                    f"{name}_V": V.detach(), f"{name}_G": G, f"{name}_gW": E.embs.weight.grad.to_dense(),
+                    f"{name}_base": bd})
+        if ed < bd:
+            out[f"{name}_P"] = E.proj.weight.detach().clone()
+            out[f"{name}_gP"] = E.proj.weight.grad
+    save("md", **out)
+
+
 def g_window_groups(M, MD, CM, QR):
     """Drive the reference's Prefetcher.run() for real on a fake loader and record which batches end
     up in which FIFO entry (a-1)."""
@@ -748,7 +785,7 @@ def g_criteo_loader(M, MD, CM, QR):
 
 GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
             dense_variants=g_dense_variants, random_data=g_random_data,
-            embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_shapes=g_train_shapes, train_w2=g_train_w2, qr=g_qr,
+            embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_shapes=g_train_shapes, train_w2=g_train_w2, qr=g_qr, md=g_md,
             window_groups=g_window_groups)
 
 
