@@ -550,6 +550,9 @@ __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ 
 // MFMA steps (lane half lk holds contraction indices 8g + 4 lk .. +3, as in gemm.h).  No workgroup barrier: every
 // wave owns its LDS slice.  HBM-bound by design: 15.7 KB in + 1.9 KB out per sample against 64 MFMAs.
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifndef IA_ABL
+#define IA_ABL 0      // tools/interact_ablate.hip: 1 no MFMA, 2 no global loads in the loop, 3 no output stores
+#endif
 
 template <int D4>
 __device__ __forceinline__ void interact_prefetch(const float* __restrict__ feat, int64_t b, int FD4, int lane,
@@ -572,7 +575,7 @@ __device__ __forceinline__ void interact_stage(float* __restrict__ Ts, int FD4, 
     }
 }
 
-template <int D4>
+template <int D4, bool vec_out>
 __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict__ feat, int64_t B, int F, int itself,
                                                         float* __restrict__ R, int64_t ld_r) {
     constexpr int D = 4 * D4, PITCH = D + 4;
@@ -587,9 +590,11 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
     if (b >= B) return;
     v4f nxt[D4 / 2];
     interact_prefetch<D4>(feat, b, FD4, lane, nxt);
-    for (; b < B; b += nw) {
+    auto one = [&](int64_t b) __attribute__((always_inline)) {
         interact_stage<D4>(Ts, FD4, lane, nxt);
+#if IA_ABL != 2
         interact_prefetch<D4>(feat, min(b + nw, B - 1), FD4, lane, nxt);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // Z = T T^T is symmetric and only its lower triangle is stored: three 16x16 tiles -- (0,0), (1,0), (1,1) -- on
         // the 16x16x4 fp32 MFMA (same FLOP rate as 32x32x2) instead of one 32x32 tile: 96 MFMAs x 32 cycles against
@@ -598,8 +603,12 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
         v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
         const int l16 = lane & 15, g4 = lane >> 4;
         const float* tp = Ts + l16 * PITCH + 4 * g4;
+#if IA_ABL == 1
+        acc00[0] = tp[0];
+#else
 #pragma unroll 2
-        for (int g = 0; g < D / 16; ++g) {
+#endif
+        for (int g = 0; g < (IA_ABL == 1 ? 0 : D / 16); ++g) {
             const float4 a0 = *reinterpret_cast<const float4*>(tp + 16 * g);                  // rows 0..15
             const float4 a1 = *reinterpret_cast<const float4*>(tp + 16 * PITCH + 16 * g);     // rows 16..31
             acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, acc00, 0, 0, 0);
@@ -616,8 +625,120 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
             acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, acc11, 0, 0, 0);
         }
         float* out = R + b * ld_r;
-        for (int c = lane; c < D; c += 64) out[c] = Ts[c];
         const int off = itself ? 1 : 0;
+#if IA_ABL == 3
+        if (acc00[0] + acc10[1] + acc11[2] == 1.2345f) out[0] = 1.f;
+#else
+        if (vec_out) {
+            // The output row [dense D | pairs] is put together in LDS, behind row 0 of T (the other rows are dead until the
+            // next sample is staged), and leaves as whole float4 words: a fixed number of unconditional, fully coalesced
+            // stores.  (Storing the accumulators straight from their lanes is a dozen 4-byte stores under lane-dependent
+            // conditions; behind them the compiler can no longer count the outstanding memory operations and makes the
+            // next sample's staging wait for vmcnt(0) -- for these stores' acknowledgements -- in every iteration.)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
+                if (i0 < F && l16 < i0 + off) Ts[D + pair_base(i0, itself) + l16] = acc00[r];
+                if (i1 < F) Ts[D + pair_base(i1, itself) + l16] = acc10[r];
+                if (i1 < F && 16 + l16 < i1 + off) Ts[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
+            }
+            const int width = D + pair_base(F, itself);
+            if (lane < 4) Ts[width + lane] = 0.f;   // the row pitch's pad columns (ld_r >= width rounded up to 4)
+            const int W4 = (width + 3) >> 2;
+            constexpr int NS = (D4 + 132 + 63) / 64;                 // covers F = 32 with `itself`; a compile-time count
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int e = min(64 * k + lane, W4 - 1);            // clamped: spare lanes / passes repeat the last word
+                *reinterpret_cast<v4f*>(out + 4 * e) = *reinterpret_cast<const v4f*>(Ts + 4 * e);
+            }
+            // rows 1 .. of T are rewritten by the next interact_stage; its row pitch pad [D, D+4) too (never read)
+        } else {
+            for (int c = lane; c < D; c += 64) out[c] = Ts[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // accumulator register r of lane l: tile row 4 (l / 16) + r, tile column l % 16
+                const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
+                if (i0 < F && l16 < i0 + off) out[D + pair_base(i0, itself) + l16] = acc00[r];
+                if (i1 < F) out[D + pair_base(i1, itself) + l16] = acc10[r];
+                if (i1 < F && 16 + l16 < i1 + off) out[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
+            }
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // The first sample is peeled off the loop so that the loop is only ever entered with the same memory operations in
+    // flight as its own back edge leaves -- the next sample's loads, then this one's output stores: the wait in front of
+    // the staging then counts the loads alone.  (Entered straight from the prefetch, the compiler has to assume the
+    // smaller number and waits for the stores' acknowledgements in every iteration.)
+    one(b);
+    for (b += nw; b < B; b += nw) one(b);
+}
+
+// ---- register-direct forward (D = 32 / 64 / 128) -------------------------------------------------------------
+// The 16x16x4 MFMA wants, of lane l, row l % 16 of a row block and contraction indices 4 (l / 16) .. +3 of every
+// 16-wide group -- exactly one float4 of the feature matrix.  So a lane loads its fragments straight from global memory
+// (per instruction 16 rows x 64 contiguous bytes, the other half of each 128-byte line by the next instruction) and
+// no LDS is involved at all: occupancy is bounded by registers, not by a 17 KB staging slice per wave, and a CU keeps
+// 12-20 samples in flight instead of 8.  Rows >= F are loaded from row F-1 (their products never reach an output).
+template <int D4, bool PREF>
+__global__ void __launch_bounds__(256) k_interact_fwd_r(const float* __restrict__ feat, int64_t B, int F, int itself,
+                                                        float* __restrict__ R, int64_t ld_r, int vec_out) {
+    constexpr int D = 4 * D4, NG = D / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int r0 = min(l16, F - 1), r1 = min(16 + l16, F - 1);
+    const int64_t o0 = (int64_t)r0 * D + 4 * g4, o1 = (int64_t)r1 * D + 4 * g4;
+    const int64_t FD = (int64_t)F * D;
+    v4f c0[NG], c1[NG];
+    {
+        const float* base = feat + b * FD;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            c0[g] = *reinterpret_cast<const v4f*>(base + o0 + 16 * g);
+            c1[g] = *reinterpret_cast<const v4f*>(base + o1 + 16 * g);
+        }
+    }
+    const int off = itself ? 1 : 0;
+    for (; b < B; b += nw) {
+        v4f n0[NG], n1[NG];
+        if (PREF) {
+            const float* base = feat + min(b + nw, B - 1) * FD;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                n0[g] = *reinterpret_cast<const v4f*>(base + o0 + 16 * g);
+                n1[g] = *reinterpret_cast<const v4f*>(base + o1 + 16 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const v4f a0 = c0[g], a1 = c1[g];
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a0.x, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a1.x, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, a0.y, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a0.y, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a1.y, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, a0.z, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a0.z, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a1.z, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, a0.w, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a0.w, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, acc11, 0, 0, 0);
+        }
+        float* out = R + b * ld_r;
+        if (l16 == 0) {                             // row 0 = the dense feature, copied through
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float* o = out + 16 * g + 4 * g4;
+                if (vec_out) *reinterpret_cast<v4f*>(o) = c0[g];
+                else { o[0] = c0[g].x; o[1] = c0[g].y; o[2] = c0[g].z; o[3] = c0[g].w; }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // accumulator register r of lane l: tile row 4 (l / 16) + r, tile column l % 16
@@ -626,12 +747,26 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
             if (i1 < F) out[D + pair_base(i1, itself) + l16] = acc10[r];
             if (i1 < F && 16 + l16 < i1 + off) out[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (PREF) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { c0[g] = n0[g]; c1[g] = n1[g]; }
+        } else if (b + nw < B) {
+            const float* base = feat + (b + nw) * FD;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                c0[g] = *reinterpret_cast<const v4f*>(base + o0 + 16 * g);
+                c1[g] = *reinterpret_cast<const v4f*>(base + o1 + 16 * g);
+            }
+        }
     }
 }
 
 // backward: dR row staged as float4 (needs ld_r % 4 == 0 and a 16-byte aligned dR)
-template <int D4>
+// STAGED (F > 16): the 32x32 accumulator tile leaves through LDS -- 16 rows at a time into the part of the dR staging
+// row that is dead once the S fragments are built -- as whole float4 words of valid rows only: 4 unconditional, fully
+// coalesced stores per 32-column block instead of 16 four-byte stores under lane-dependent conditions (see the forward
+// kernel: behind conditional stores every iteration waits for the previous sample's store acknowledgements).
+template <int D4, bool STAGED>
 __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict__ feat, const float* __restrict__ dR,
                                                         int64_t ld_r, int64_t B, int F, int itself, int x_act,
                                                         float* __restrict__ dfeat) {
@@ -643,6 +778,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
     const int lr = lane & 31, lk = lane >> 5;
     float* Ts = smem + wave * (32 * PITCH + GMAX);
     float* Gs = Ts + 32 * PITCH;
+    float* Os = Gs + D;                         // [16][32] output staging (STAGED)
     for (int e = lane; e < 32 * PITCH; e += 64) Ts[e] = 0.f;
     const int FD4 = F * D4;
     const int off = itself ? 1 : 0;
@@ -655,7 +791,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
     interact_prefetch<D4>(feat, b, FD4, lane, nxt);
 #pragma unroll
     for (int i = 0; i < NG; ++i) gn[i] = reinterpret_cast<const v4f*>(dR + b * ld_r)[min(lane + 64 * i, G4 - 1)];
-    for (; b < B; b += nw) {
+    auto one = [&](int64_t b) __attribute__((always_inline)) {
         interact_stage<D4>(Ts, FD4, lane, nxt);
 #pragma unroll
         for (int i = 0; i < NG; ++i) *reinterpret_cast<v4f*>(Gs + 4 * min(lane + 64 * i, GMAX / 4 - 1)) = gn[i];
@@ -677,7 +813,8 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
             sreg[m] = v;
         }
         float* out = dfeat + b * F * D;
-#pragma unroll 1
+        // (STAGED: unrolled, so that the number of stores behind the prefetch loads is a compile-time count)
+#pragma unroll(STAGED ? D / 32 : 1)
         for (int n0 = 0; n0 < D; n0 += 32) {
             f32x16 acc;
 #pragma unroll
@@ -686,23 +823,52 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
 #pragma unroll
             for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sreg[m], tp[2 * m * PITCH], acc, 0, 0, 0);
             const int col = n0 + lr;
+            if (STAGED) {
+                {   // row 0 (register 0 of the lanes lk = 0): the dense feature: + direct path, * act'(bottom-MLP output)
+                    float v = acc[0] + Gs[col];
+                    const float y = Ts[col];
+                    if (x_act == 1) v = y > 0.f ? v : 0.f;
+                    else if (x_act == 2) v = v * ((1.0f - y) * y);
+                    acc[0] = lk == 0 ? v : acc[0];
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (i < F) {
-                    float v = acc[r];
-                    if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
-                        v += Gs[col];
-                        const float y = Ts[col];
-                        if (x_act == 1) v = y > 0.f ? v : 0.f;
-                        else if (x_act == 2) v = v * ((1.0f - y) * y);
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)      // accumulator register 8h + rr: row 16h + (rr&3) + 8 (rr>>2) + 4 lk
+                        Os[((rr & 3) + 8 * (rr >> 2) + 4 * lk) * 32 + lr] = acc[8 * h + rr];
+                    const int nvalid = min(F - 16 * h, 16) * 8;     // float4 words of valid rows (F > 16: >= 8)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int idx = min(64 * k + lane, nvalid - 1);     // clamped: spare lanes repeat the last word
+                        const int row = idx >> 3, c4 = idx & 7;
+                        *reinterpret_cast<v4f*>(out + (16 * h + row) * D + n0 + 4 * c4) =
+                            *reinterpret_cast<const v4f*>(Os + row * 32 + 4 * c4);
                     }
-                    out[i * D + col] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (i < F) {
+                        float v = acc[r];
+                        if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
+                            v += Gs[col];
+                            const float y = Ts[col];
+                            if (x_act == 1) v = y > 0.f ? v : 0.f;
+                            else if (x_act == 2) v = v * ((1.0f - y) * y);
+                        }
+                        out[i * D + col] = v;
+                    }
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    if (STAGED) {           // first sample peeled: see k_interact_fwd_p
+        one(b);
+        b += nw;
     }
+    for (; b < B; b += nw) one(b);
 }
 
 template <typename K>
@@ -719,17 +885,49 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
     CDLRM_REQUIRE(feat && R && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape (F<=32, D%4==0)");
     CDLRM_REQUIRE(aligned16(feat) && ld_r >= D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2), "alignment / ld_r");
     if (B == 0) return 0;
+    static const int fwd_mode = getenv("CDLRM_INTERACT_FWD") ? atoi(getenv("CDLRM_INTERACT_FWD")) : 0;
+    if (fwd_mode && (D == 32 || D == 64 || D == 128)) {
+        // mode 1: one pass of waves, as many as fit; 2: register prefetch, 3 workgroups per CU
+        const int vec_out = ld_r % 4 == 0 && aligned16(R);
+        int64_t gp = cdiv(B, 4);
+        const int64_t cap = fwd_mode == 2 ? 512 : (fwd_mode == 1 ? 4096 : fwd_mode);
+        if (gp > cap) gp = cap;
+#define IFWDR(D4_)                                                                                             \
+    do {                                                                                                       \
+        if (fwd_mode == 2)                                                                                     \
+            hipLaunchKernelGGL((k_interact_fwd_r<D4_, true>), dim3((unsigned)gp), dim3(256), 0, (hipStream_t)stream, \
+                               feat, B, F, itself, R, ld_r, vec_out);                                          \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_interact_fwd_r<D4_, false>), dim3((unsigned)gp), dim3(256), 0, (hipStream_t)stream, \
+                               feat, B, F, itself, R, ld_r, vec_out);                                          \
+    } while (0)
+        if (D == 32) IFWDR(8);
+        else if (D == 64) IFWDR(16);
+        else IFWDR(32);
+#undef IFWDR
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     if (D == 32 || D == 64 || D == 128 || D == 256) {
         const size_t ldsp = (size_t)4 * 32 * (D + 4) * sizeof(float);
+        const int width_p = D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2);
+        // whole-float4 output rows: the 32-row staging slice must hold one (F >= 4 does), the row pitch its last word
+        const int vec_out_p = ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width_p + 3) & ~3) && width_p + 4 <= 32 * (D + 4) &&
+                              !getenv("CDLRM_INTERACT_SCALAR_OUT");
         int64_t gp = cdiv(B, 4);
         if (gp > 512) gp = 512;             // 2 workgroups per CU (LDS), each wave streams ~4 samples
-        static size_t a32 = 0, a64 = 0, a128 = 0, a256 = 0;
+        static size_t a32 = 0, a64 = 0, a128 = 0, a256 = 0, a32v = 0, a64v = 0, a128v = 0, a256v = 0;
 #define IFWD(D4_, A_)                                                                                          \
     do {                                                                                                       \
-        int rc = interact_set_lds(k_interact_fwd_p<D4_>, ldsp, &A_);                                           \
+        int rc = interact_set_lds(k_interact_fwd_p<D4_, false>, ldsp, &A_);                                    \
+        if (!rc) rc = interact_set_lds(k_interact_fwd_p<D4_, true>, ldsp, &A_##v);                             \
         if (rc) return rc;                                                                                     \
-        hipLaunchKernelGGL(k_interact_fwd_p<D4_>, dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, feat, B, \
-                           F, itself, R, ld_r);                                                                \
+        if (vec_out_p)                                                                                         \
+            hipLaunchKernelGGL((k_interact_fwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
+                               feat, B, F, itself, R, ld_r);                                                   \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_interact_fwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
+                               feat, B, F, itself, R, ld_r);                                                   \
     } while (0)
         if (D == 32) IFWD(8, a32);
         else if (D == 64) IFWD(16, a64);
@@ -762,13 +960,19 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         const size_t ldsp = (size_t)4 * (32 * (D + 4) + D + 528) * sizeof(float);
         int64_t gp = cdiv(B, 4);
         if (gp > 512) gp = 512;
-        static size_t b32 = 0, b64 = 0, b128 = 0;
+        static size_t b32 = 0, b64 = 0, b128 = 0, b32s = 0, b64s = 0, b128s = 0;
+        const bool staged = F > 16 && aligned16(dfeat) && !getenv("CDLRM_INTERACT_SCALAR_OUT");
 #define IBWD(D4_, A_)                                                                                          \
     do {                                                                                                       \
-        int rc = interact_set_lds(k_interact_bwd_p<D4_>, ldsp, &A_);                                           \
+        int rc = interact_set_lds(k_interact_bwd_p<D4_, false>, ldsp, &A_);                                    \
+        if (!rc) rc = interact_set_lds(k_interact_bwd_p<D4_, true>, ldsp, &A_##s);                             \
         if (rc) return rc;                                                                                     \
-        hipLaunchKernelGGL(k_interact_bwd_p<D4_>, dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, feat, dR, \
-                           ld_r, B, F, itself, x_act, dfeat);                                                  \
+        if (staged)                                                                                            \
+            hipLaunchKernelGGL((k_interact_bwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
+                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                                    \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_interact_bwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
+                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                                    \
     } while (0)
         if (D == 32) IBWD(8, b32);
         else if (D == 64) IBWD(16, b64);
@@ -978,14 +1182,20 @@ extern "C" int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n
 // that layer's input gradient.  At a local batch of 1024 the three stand-alone kernels (256 -> 1 GEMM, loss, 1 -> 256
 // outer product) cost 8.7 + 7.4 + 7.5 us of fixed latency for 2 MB of traffic.  One wave per row: dot over K by
 // lanes, sigmoid, loss term, dz (pre-activation gradient of the last layer), then dY[row, :] = dz * w, times the
-// derivative of the activation that produced Y.  Loss: per-workgroup partials, summed in index order by the
-// workgroup that arrives last (reproducible).  scratch: [0] arrival counter (zero before the first call; the kernel
-// leaves it zero), [1 .. grid] partial sums.
+// derivative of the activation that produced Y.  Loss: per-workgroup partials in `scratch`, summed in index order
+// (reproducible) by cdlrm_head_finish -- on the same stream, or (finish = 0) wherever the caller launches it behind
+// this kernel: nothing on the training step's critical path reads the loss value.
 // -------------------------------------------------------------------------------------------------
 
-// <= 256 workgroups: every workgroup ends with one atomic on the arrival counter, and 2048 of them serialised there
-// cost more (78 us at B = 8192) than the rows; a wave takes 4 rows per pass instead (independent load chains)
-#define HEAD_MAX_BLOCKS 256
+// The loss: per-workgroup partial sums, added up in index order by k_head_finish, a second one-workgroup launch.  (One
+// launch with a "last workgroup to arrive sums" tail needs agent-scope release/acquire fences, which on the 8-XCD part
+// write back / invalidate a whole L2 -- freshly filled with this kernel's 8 MB of dY: the tail cost 16 of the kernel's
+// 24 us at B = 8192, whatever the arrangement of the arrival counters.)  A wave takes 4 rows per pass (independent load
+// chains).
+#ifndef HEAD_ABL
+#define HEAD_ABL 0        // tools/head_ablate.hip: 1 no partial sums, 2 no dY stores
+#endif
+#define HEAD_MAX_BLOCKS 1024
 
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ w,
@@ -995,7 +1205,6 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
                                               int64_t lddy, float* __restrict__ loss, float* __restrict__ scratch) {
     __shared__ float red[4];
     __shared__ int redc[4];
-    __shared__ unsigned last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float b0 = bias ? bias[0] : 0.f;
     float lsum = 0.f;
@@ -1050,7 +1259,7 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
                 if (Zc) Zc[row] = zc;
                 dZ[row] = d;
             }
-            if (!dY) continue;
+            if (!dY || HEAD_ABL == 2) continue;
             const float* y = Y + row * ldy;
             float* dy = dY + row * lddy;
             if (one) {
@@ -1090,46 +1299,52 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
             }
         }
     }
+#if HEAD_ABL == 1
+    if (lsum == 1.2345f) scratch[0] = lsum;
+    return;
+#endif
     if (lane == 0) { red[wave] = lsum; redc[wave] = nok; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        scratch[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        scratch[1 + HEAD_MAX_BLOCKS + blockIdx.x] = (float)(redc[0] + redc[1] + redc[2] + redc[3]);
-        __threadfence();
-        last = atomicAdd(reinterpret_cast<unsigned*>(scratch), 1u);
-    }
-    __syncthreads();
-    if (last == gridDim.x - 1 && wave == 0) {
-        // fixed order for a given grid: lane i sums partials i, i + 64, ..., then a butterfly over the lanes
-        __threadfence();
-        float s = 0.f, cnt = 0.f;
-        for (unsigned i = lane; i < gridDim.x; i += 64) {
-            s += __builtin_nontemporal_load(scratch + 1 + i);
-            cnt += __builtin_nontemporal_load(scratch + 1 + HEAD_MAX_BLOCKS + i);     // integers < 2^24: exact
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d, 64); cnt += __shfl_xor(cnt, d, 64); }
-        if (lane == 0) {
-            loss[0] = s / (float)B;
-            loss[1] = cnt;                              // correct predictions of this batch
-            loss[2] = (s / (float)B) * (float)B;        // L * mbs as the reference accumulates it (:433), in fp32
-            *reinterpret_cast<unsigned*>(scratch) = 0u;
-        }
+        scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        scratch[HEAD_MAX_BLOCKS + blockIdx.x] = (float)(redc[0] + redc[1] + redc[2] + redc[3]);
     }
 }
 
-extern "C" int64_t cdlrm_head_scratch_floats(void) { return 1 + 2 * HEAD_MAX_BLOCKS; }
+// fixed order for a given number of partials: lane i sums partials i, i + 64, ..., then a butterfly over the lanes
+__global__ void __launch_bounds__(64) k_head_finish(const float* __restrict__ scratch, int nparts, int64_t B,
+                                                    float* __restrict__ loss) {
+    const int lane = threadIdx.x;
+    float s = 0.f, cnt = 0.f;
+    for (int i = lane; i < nparts; i += 64) {
+        s += scratch[i];
+        cnt += scratch[HEAD_MAX_BLOCKS + i];         // integers < 2^24: exact
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+    if (lane == 0) {
+        loss[0] = s / (float)B;
+        loss[1] = cnt;                              // correct predictions of this batch
+        loss[2] = (s / (float)B) * (float)B;        // L * mbs as the reference accumulates it (:433), in fp32
+    }
+}
+
+extern "C" int64_t cdlrm_head_scratch_floats(void) { return 2 * HEAD_MAX_BLOCKS; }
+
+static int64_t head_grid(int64_t B) {
+    int64_t gx = cdiv(B, 16);                       // 4 waves x 4 rows per pass
+    return gx > HEAD_MAX_BLOCKS ? HEAD_MAX_BLOCKS : gx;     // B > 16384: more passes
+}
 
 extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
                                   int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold,
                                   int32_t x_act, float* Z, float* Zc, float* dZ, float* dY, int64_t lddy,
-                                  float* loss_out, float* scratch, void* stream) {
+                                  float* loss_out, float* scratch, int32_t finish, void* stream) {
     CDLRM_REQUIRE(Y && w && target && Z && dZ && loss_out && scratch && B >= 1 && K >= 1, "bad argument");
     CDLRM_REQUIRE(kind >= 0 && kind <= 2 && x_act >= 0 && x_act <= 2, "bad loss kind / activation");
     LossCfg c;
     c.kind = kind; c.w0 = w0; c.w1 = w1; c.thr = threshold;
-    int64_t gx = cdiv(B, 16);                       // 4 waves x 4 rows per pass
-    if (gx > HEAD_MAX_BLOCKS) gx = HEAD_MAX_BLOCKS;
+    const int64_t gx = head_grid(B);
     const bool vec = K % 4 == 0 && ldy % 4 == 0 && (!dY || lddy % 4 == 0) && (((uintptr_t)Y | (uintptr_t)w | (uintptr_t)dY) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(k_head<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B,
@@ -1137,6 +1352,14 @@ extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, c
     else
         hipLaunchKernelGGL(k_head<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B,
                            (int)K, c, (int)x_act, Z, Zc, dZ, dY, lddy, loss_out, scratch);
+    CDLRM_LAUNCH_CHECK();
+    if (finish) return cdlrm_head_finish(scratch, B, loss_out, stream);
+    return 0;
+}
+
+extern "C" int cdlrm_head_finish(const float* scratch, int64_t B, float* loss_out, void* stream) {
+    CDLRM_REQUIRE(scratch && loss_out && B >= 1, "bad argument");
+    hipLaunchKernelGGL(k_head_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, (int)head_grid(B), B, loss_out);
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

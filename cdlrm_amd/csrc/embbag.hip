@@ -533,6 +533,10 @@ extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t 
 
 // the per-iteration remainder: slot ids of one batch out of the window's resolved ids (misses move to the aux region of
 // `aux_phase`), rows of its misses from the victim rows (or the host table) into their aux rows
+// One lane per lookup for the slot ids (a wave takes 64 consecutive lookups of one table: coalesced 256-byte reads and
+// writes), then the wave's misses, found by ballot, are copied 64 / LPR rows at a time by LPR lanes each.  (The first
+// version gave every lookup LPR lanes: 6.8 M threads for 213 k lookups at c3, 62 us beside the first top-MLP GEMM,
+// which it slowed by a third.)
 template <int LPR>
 __global__ void __launch_bounds__(256) k_take(const TableDesc* __restrict__ tab, int ways, int aux_first, int D4,
                                               float4* __restrict__ weight, float* const* __restrict__ host_rows,
@@ -540,24 +544,50 @@ __global__ void __launch_bounds__(256) k_take(const TableDesc* __restrict__ tab,
                                               const int32_t* __restrict__ wslots, const int32_t* __restrict__ wsrc,
                                               int64_t ld_w, int64_t n, const float* __restrict__ v_rows,
                                               int32_t* __restrict__ slots_out) {
+    constexpr int RPW = 64 / LPR;                   // rows copied per pass of a wave
     const int t = blockIdx.y;
     const TableDesc d = tab[t];
     const int32_t first_aux = (int32_t)(d.P * ways);
-    const int c = threadIdx.x % LPR;
-    const int gpb = blockDim.x / LPR;
-    const int gid = threadIdx.x / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % LPR, gid = lane / LPR;
     const float4* vr = reinterpret_cast<const float4*>(v_rows);
     const float4* hr = reinterpret_cast<const float4*>(host_rows[t]);
-    for (int64_t i = (int64_t)blockIdx.x * gpb + gid; i < n; i += (int64_t)gridDim.x * gpb) {
-        int32_t sl = wslots[(int64_t)t * ld_w + i];
-        if (sl >= first_aux) {
-            sl += aux_first;
-            const int32_t src = wsrc[(int64_t)t * ld_w + i];
-            const float4* from = src >= 0 ? vr + (int64_t)src * D4 : hr + idx[(int64_t)t * ld_idx + i] * D4;
-            float4* to = weight + (d.row_base + sl) * D4;
-            for (int cc = c; cc < D4; cc += LPR) to[cc] = from[cc];
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < n; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + lane;
+        int32_t sl = 0, src = 0;
+        int64_t id = 0;
+        bool aux = false;
+        if (i < n) {
+            sl = wslots[(int64_t)t * ld_w + i];
+            aux = sl >= first_aux;
+            if (aux) {
+                sl += aux_first;
+                src = wsrc[(int64_t)t * ld_w + i];
+                id = idx[(int64_t)t * ld_idx + i];
+            }
+            slots_out[(int64_t)t * n + i] = sl;
         }
-        if (c == 0) slots_out[(int64_t)t * n + i] = sl;
+        unsigned long long mask = __ballot(aux);
+        while (mask) {                              // wave-uniform
+            int mine = -1;
+#pragma unroll
+            for (int g = 0; g < RPW; ++g) {
+                if (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    if (gid == g) mine = b;
+                }
+            }
+            const int from_lane = mine < 0 ? 0 : mine;
+            const int32_t r_sl = __shfl(sl, from_lane, 64), r_src = __shfl(src, from_lane, 64);
+            const int64_t r_id = ((int64_t)__shfl((int)(id >> 32), from_lane, 64) << 32) |
+                                 (uint32_t)__shfl((int)(id & 0xffffffff), from_lane, 64);
+            if (mine >= 0) {
+                const float4* from = r_src >= 0 ? vr + (int64_t)r_src * D4 : hr + r_id * D4;
+                float4* to = weight + (d.row_base + r_sl) * D4;
+                for (int cc = c; cc < D4; cc += LPR) to[cc] = from[cc];
+            }
+        }
     }
 }
 
@@ -572,7 +602,7 @@ extern "C" int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, 
     hipStream_t s = (hipStream_t)stream;
     const int D4 = ctx->D / 4;
     const int lpr = lanes_per_row(D4);
-    int64_t gx = cdiv(n, 256 / lpr);
+    int64_t gx = cdiv(n, 256);
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)ctx->T);
 #define TAKE_CALL(L) hipLaunchKernelGGL(k_take<L>, grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, aux_phase * ctx->aux, D4, reinterpret_cast<float4*>(ctx->weight), ctx->d_host_rows, idx, ld_idx, wslots, wsrc, ld_w, n, ctx->vict_rows, slots_out)

@@ -433,6 +433,7 @@ class TrainEngine:
         self._res = self._next_res = None
         self._tapes = {}
         self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
+        self.chain_take = os.environ.get("CDLRM_CHAIN_TAKE", "1") != "0"
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -478,6 +479,12 @@ class TrainEngine:
     def _side_gather(self, B: int) -> bool:
         """Short local batches run the gather on the side stream (see _fwd_bwd)."""
         return B < self.gather_alone_min and not (self.defer_top and self.cat)
+
+    def _chain(self, B: int, next_idx, lS_o) -> bool:
+        """Long batches on the window-resident probe: the next batch's take rides behind this step's embedding update on
+        the side stream (see _fwd_bwd)."""
+        return (self.chain_take and not self._side_gather(B) and next_idx is not None and self._next_res is not None
+                and lS_o is None)
 
     def _reduce_avg(self) -> bool:
         """grad /= W followed by all-reduce(SUM) (main_no_ddp.py:239-244) as ONE all-reduce(AVG): on RCCL, for a
@@ -645,6 +652,9 @@ class TrainEngine:
         if res is not None:
             # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
             self.side.wait_event(res[2])
+        if self._next_res is not None and next_res[2] is not (res[2] if res is not None else None):
+            # the next batch's take may run on the side stream too (single aux region / chained take): behind ITS chunk
+            self.side.wait_event(next_res[2])
         if self.use_tape and lS_o is None:
             sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
@@ -716,13 +726,23 @@ class TrainEngine:
         side = self.side
         ev = self._events
         two_phase = ctx.aux_phases >= 2
+        # Long batches with the window-resident probe: the next batch's take costs ~10 us stand-alone, so it no longer needs
+        # a stream and an aux region of its own (that pipeline hid 250 us of PCIe reads).  It follows this step's embedding
+        # update in order on the side stream, and ONE event recorded there -- after the take and, on one rank, after the
+        # deferred top-MLP update -- is all the next step's gather waits for: the main queue carries one wait per step
+        # instead of three (probe, top update, embedding update) plus a record, each a 6-8 us bubble (measured).
+        chain = self._chain(B, next_idx, lS_o)
+        if chain:
+            two_phase = False
         if self.defer_top and self.cat:
             # the previous step's top weight gradients read R = the feature block this step's first kernels overwrite
             rec(main.wait_event, ev["top_updated"])
         pref, self._pref = self._pref, None
+        top_waited = False
         if pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape):
             slots, miss_pos, miss_count, probed = pref["res"]
             self._phase = pref["phase"]
+            top_waited = bool(pref.get("chained_top"))
         else:
             rec(side.wait_stream, main)
             if self._res is not None and lS_o is None:
@@ -794,9 +814,10 @@ class TrainEngine:
         if not side_gather:
             rec(side.wait_event, probed)
         ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
-        if self.defer_top and not self.cat:
+        if self.defer_top and not self.cat and not top_waited:
             # the previous step's top-MLP update (weight gradients read R / top_y / top_dy, then all-reduce and SGD on
             # the side stream) has to have landed before this step overwrites those buffers and reads the weights
+            # (top_waited: the event this step's gather waited for was recorded behind that update)
             rec(main.wait_event, ev["top_updated"])
         if not self.cat:
             ops.interact_fwd(feat, self.itself, R)
@@ -879,10 +900,13 @@ class TrainEngine:
                 ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=0, stream=side)
             else:
                 res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
+            chained_top = chain and self.defer_top and self.world == 1 and split is not None
+            if chained_top:
+                rec(side.wait_event, ev["top_updated"])     # recorded above, behind this step's top-MLP SGD
             evp = ev["probed"][which]
             rec(evp.record, side)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
-                              res=(res[0], res[1], res[2], evp))
+                              res=(res[0], res[1], res[2], evp), chained_top=chained_top)
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
@@ -907,6 +931,8 @@ class TrainEngine:
             return False # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
         if next_idx is None:
             rec(main.wait_stream, side)      # full join
+        elif chain:
+            pass                             # the next gather waits for the take's event, recorded behind emb_done
         elif not (side_gather and two_phase):
             rec(main.wait_event, emb_done)   # cache rows are updated; the prefetched probe keeps running
         # else: the next step's gather runs on the side stream, in order behind this embedding update, and its probe waits
@@ -973,7 +999,9 @@ class TrainEngine:
         phase = pref["phase"] if hit else self._phase
         nxt = next_idx is not None
         key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
-               next_idx.stride(0) if nxt else 0, (self.iter & 1) if self.ctx.aux_phases < 2 else 0,
+               next_idx.stride(0) if nxt else 0,
+               (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
+               bool(hit and pref.get("chained_top")),
                self._gslot is not None,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
@@ -1009,7 +1037,7 @@ class TrainEngine:
                     prog.append((fn, args, False))
             post = self._pref
             self._tapes[key] = dict(prog=prog, cells=cells, phase=self._phase,
-                                    pref=None if post is None else (post["phase"], post["res"]))
+                                    pref=None if post is None else (post["phase"], post["res"], post.get("chained_top", False)))
             return self.world == 1
         cells = tape["cells"]
         cells["X"].value = X.data_ptr()
@@ -1034,7 +1062,8 @@ class TrainEngine:
         self._emb_done = self._events["emb_done"]
         self._pref = None
         if tape["pref"] is not None:
-            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1])
+            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1],
+                              chained_top=tape["pref"][2])
         return self.world == 1
 
     def table_aggregate(self):

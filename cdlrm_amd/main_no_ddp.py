@@ -384,7 +384,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
             dist.barrier()
     eng = TrainEngine(cache_group, dlrm, emb_tables, lr=args.learning_rate, lr_embeds=args.lr_embeds, world_size=world,
                       rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op,
-                      loss=args.loss_function, loss_weights=loss_ws, defer_top_update=world > 1)
+                      loss=args.loss_function, loss_weights=loss_ws, defer_top_update=os.environ.get("CDLRM_DEFER_TOP", "1") != "0")
     L = args.lookahead
     # --device-rng (performance mode): the plan of window w+1 is made while window w trains -- what the reference's
     # Prefetcher process is for (cache_manager.py:66-115) -- with its rows gathered by CPU threads in the background.  The

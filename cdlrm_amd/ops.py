@@ -454,15 +454,20 @@ def head_scratch(device) -> torch.Tensor:
 def head_fwd_bwd(Y: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], target: torch.Tensor, Z: torch.Tensor,
                  dZ: torch.Tensor, dY: Optional[torch.Tensor], loss_buf: torch.Tensor, scratch: torch.Tensor, *,
                  x_act: int = 0, kind: int = 0, weights=(1.0, 1.0), threshold: float = 0.0,
-                 Zc: Optional[torch.Tensor] = None, stream=None):
-    """Last top layer (out_features 1, sigmoid) + loss + the layer's input gradient in one launch."""
+                 Zc: Optional[torch.Tensor] = None, finish: bool = True, stream=None):
+    """Last top layer (out_features 1, sigmoid) + loss + the layer's input gradient in one launch.  finish=False leaves
+    the loss as partial sums in `scratch`: head_finish() on a stream ordered behind this call completes loss_buf."""
     B, K = Y.shape
     assert Y.stride(1) == 1 and w.numel() >= K and Z.numel() == B and dZ.numel() == B and target.numel() == B
     assert dY is None or (dY.shape == Y.shape and dY.stride(1) == 1)
     check(_lib.lib().cdlrm_head_fwd_bwd(Y.data_ptr(), Y.stride(0), w.data_ptr(), ptr(bias), target.data_ptr(), B, K,
                                         int(kind), float(weights[0]), float(weights[1]), float(threshold), int(x_act),
                                         Z.data_ptr(), ptr(Zc), dZ.data_ptr(), ptr(dY), 0 if dY is None else dY.stride(0),
-                                        loss_buf.data_ptr(), scratch.data_ptr(), stream_ptr(stream)))
+                                        loss_buf.data_ptr(), scratch.data_ptr(), 1 if finish else 0, stream_ptr(stream)))
+
+
+def head_finish(scratch: torch.Tensor, B: int, loss_buf: torch.Tensor, stream=None):
+    check(_lib.lib().cdlrm_head_finish(scratch.data_ptr(), int(B), loss_buf.data_ptr(), stream_ptr(stream)))
 
 
 def act_bwd(dX: torch.Tensor, X: torch.Tensor, act: int, stream=None):

@@ -312,7 +312,9 @@ int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count,
  * ------------------------------------------------------------------------------------------- */
 
 /* interact_features "dot" (model_no_ddp.py:272-293): feat fp32 [B, F, D] (feature 0 = bottom-MLP
- * output x); R[b] = [x_b, <f_i, f_j> for i in 0..F-1 for j in 0..i-1(+itself)] fp32 [B, ld_r]. */
+ * output x); R[b] = [x_b, <f_i, f_j> for i in 0..F-1 for j in 0..i-1(+itself)] fp32 [B, ld_r].  Columns of the row
+ * pitch beyond the row's width are left alone or, up to the next multiple of 4, set to 0 (rows leave as whole float4
+ * words when ld_r % 4 == 0 and R is 16-byte aligned). */
 int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32_t itself,
                        float* R, int64_t ld_r, void* stream);
 /* dfeat[b] = (G + G^T) feat_b with G the strictly-lower (or lower) triangle filled from dR, plus dR's
@@ -375,13 +377,16 @@ int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t k
  * NULL), the loss above, and the layer's input gradient.  Y [B, K] (row pitch ldy) is the layer's input, produced
  * by activation x_act (0 none, 1 ReLU, 2 sigmoid).  Outputs: Z [B] = sigmoid(Y w + b), Zc [B] (may be NULL) clamped
  * prediction, dZ [B] = dL/d(pre-activation of the last layer), dY [B, K] (pitch lddy; may be NULL) = dZ w^T times
- * the derivative of x_act, loss_out[0..2] as for cdlrm_loss_fwd_bwd.  scratch: cdlrm_head_scratch_floats() floats,
- * zeroed once by the caller. */
+ * the derivative of x_act, loss_out[0..2] as for cdlrm_loss_fwd_bwd.  scratch: cdlrm_head_scratch_floats() floats
+ * (per-workgroup partial sums of the loss).  finish != 0: loss_out is complete when the call's work on `stream` is;
+ * finish == 0: the partial sums are left in `scratch` and cdlrm_head_finish(scratch, B, loss_out, any stream ordered
+ * behind this call) turns them into loss_out -- the training step runs it beside the backward, not in front of it. */
 int64_t cdlrm_head_scratch_floats(void);
 int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
                        int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold, int32_t x_act,
                        float* Z, float* Zc, float* dZ, float* dY, int64_t lddy, float* loss_out, float* scratch,
-                       void* stream);
+                       int32_t finish, void* stream);
+int cdlrm_head_finish(const float* scratch, int64_t B, float* loss_out, void* stream);
 
 /* p -= lr * g over a flat fp32 buffer (optim.SGD without momentum, main_no_ddp.py:375, 415). */
 int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float lr, void* stream);

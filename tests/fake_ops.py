@@ -294,7 +294,7 @@ def head_scratch(device):
 
 
 def head_fwd_bwd(Y, w, bias, target, Z, dZ, dY, loss_buf, scratch, *, x_act=0, kind=0, weights=(1.0, 1.0),
-                 threshold=0.0, Zc=None, stream=None):
+                 threshold=0.0, Zc=None, finish=True, stream=None):
     K = Y.shape[1]
     wrow = w.reshape(-1)[:K]
     pre = Y @ wrow.view(K, 1) + (bias if bias is not None else 0.0)
@@ -303,6 +303,10 @@ def head_fwd_bwd(Y, w, bias, target, Z, dZ, dY, loss_buf, scratch, *, x_act=0, k
                  sigmoid_bwd=True)
     if dY is not None:
         dY[:, :K].copy_(_act_bwd(dZ.view(-1, 1) * wrow.view(1, K), Y, x_act))
+
+
+def head_finish(scratch, B, loss_buf, stream=None):
+    pass                                   # the stand-in's head_fwd_bwd always completes the loss
 
 
 def sgd_step2(param, grad, off0, n0, off1, n1, lr, stream=None):

@@ -102,6 +102,54 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, reso
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("name,defer", [("train_small", True), ("train_small", False), ("train_c1", True),
+                                        ("train_stream", True)])
+def test_chained_take_long_batch_path(golden, name, defer):
+    """The long-batch schedule (gather alone on the main stream, B >= gather_alone_min) on the window-resident probe: the
+    next batch's take follows the embedding update on the side stream and the next gather waits for ONE event recorded
+    behind it (and behind the deferred top-MLP update).  Forced here at the goldens' small batches; same trajectory,
+    tags and weights as the reference, taped and untaped steps alike."""
+    from cdlrm_amd.engine import TrainEngine, WindowResolver
+    g = golden(name)
+    host, cg, dl, eng0, pipe = build(g, aux_phases=2)
+    eng = TrainEngine(cg, dl, host, lr=eng0.lr, lr_embeds=eng0.lr_embeds, table_agg_freq=eng0.agg_freq,
+                      table_agg_op=eng0.agg_op, defer_top_update=defer)
+    eng.gather_alone_min = 1
+    assert eng.chain_take
+    L = int(g["L"])
+    batches = make_batches(g)
+    dev_idx = [b[1].to(DEV) for b in batches]
+    losses, chained = [], 0
+    for j, (X, lS_i, Tt) in enumerate(batches):
+        if j % L == 0:
+            win = torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV)
+            if "reseed" not in g.files or bool(g["reseed"]):
+                torch.manual_seed(5000 + j)
+            pipe.plan_window(win)
+            pipe.commit()
+            pipe.wait_writeback()
+            rs = WindowResolver(eng, win, int(g["B"]), chunk=2)
+        nxt = dev_idx[j + 1] if j + 1 < len(batches) and (j + 1) % L != 0 else None
+        loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt, res=rs.batch(j % L),
+                        next_res=rs.batch(j % L + 1) if nxt is not None else None)
+        chained += int(eng._pref is not None and bool(eng._pref.get("chained_top")) == (defer and eng.world == 1))
+        rs.ensure(j % L + rs.CH + 2)
+        losses.append(loss[0:1].clone())
+    eng.finish()
+    losses = [float(x) for x in losses]
+    cg.ctx.check()
+    assert chained >= len(batches) - len(batches) // L - 1
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-5)
+    occ = cg.occupancy_tables
+    for k in range(len(g["ln_emb"])):
+        assert torch.equal(occ[k].cpu(), t(g[f"occ_{k}"])), k
+        w = cg.emb_l[k].weight[: int(g["ways"]) * cg.cache_sizes[k]].double().sum().item()
+        np.testing.assert_allclose(w, float(g[f"weight_sum_{k}"]), rtol=1e-5, atol=1e-4)
+    from cdlrm_amd.model_no_ddp import _linears
+    for i, l in enumerate(_linears(dl.top_l)):
+        np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
+
+
 def test_host_gather_plan_equals_device_fetch(golden):
     """WindowPipeline(host_gather=True) -- CPU threads gather the winners' / victims' rows, one DMA copy each, from a
     background thread -- leaves exactly the cache, tag and victim state of the default plan (GPU waves reading the
