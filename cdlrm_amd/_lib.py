@@ -105,6 +105,15 @@ PROTOTYPES = {
     "cdlrm_scatter_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, C.c_int, vp]),
     "cdlrm_blend_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_mark_rows": (C.c_int, [vp, vp, c_i64, vp, vp]),
+    "cdlrm_tape_create": (vp, [c_i32]),
+    "cdlrm_tape_destroy": (None, [vp]),
+    "cdlrm_tape_add": (C.c_int, [vp, vp, c_i32, vp, vp, c_i32, vp]),
+    "cdlrm_tape_cells": (vp, [vp]),
+    "cdlrm_tape_length": (c_i64, [vp]),
+    "cdlrm_tape_replay": (C.c_int, [vp]),
+    "cdlrm_tape_selftest": (C.c_int, []),
+    "cdlrm_event_record": (C.c_int, [vp, vp]),
+    "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -182,6 +191,120 @@ def lib():
         _lib = l
         _proxy = _Recording(l)
     return _proxy
+
+
+class TapeUnsupported(Exception):
+    """A recorded call the native tape cannot hold (the engine then replays that step's tape from Python)."""
+
+
+_native_ok: Optional[bool] = None
+
+
+def native_tape_ok() -> bool:
+    """csrc/tape.hip's generic call works on this machine (x86-64 System V) and is not switched off."""
+    global _native_ok
+    if _native_ok is None:
+        _native_ok = os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0" and raw().cdlrm_tape_selftest() == 0
+    return _native_ok
+
+
+class NativeTape:
+    """A recorded step as a C-side tape: `prog` is the engine's list of (function, arguments, is_library_call) with the
+    per-step pointers already replaced by shared ctypes cells; replay() re-issues all of it with ONE library call.
+    Library calls are stored by address with their arguments split by register class (ctypes argtypes tell which);
+    torch stream / event calls become cdlrm_stream_wait_event / cdlrm_event_record on the raw HIP handles."""
+
+    def __init__(self, prog, cells: dict):
+        import torch
+        L = raw()
+        order = list(cells.values())
+        index = {id(c): i for i, c in enumerate(order)}
+        self._cells_py = order
+        self._keep = []                          # torch events created for wait_stream: must outlive the tape
+        h = L.cdlrm_tape_create(len(order))
+        if not h:
+            raise CdlrmError(-22, L.cdlrm_last_error().decode("utf-8", "replace"))
+        self._h = h
+        try:
+            for fn, args, _ in prog:
+                for target, cargs in self._translate(fn, args, torch):
+                    self._add(L, target, cargs, index)
+        except Exception:
+            L.cdlrm_tape_destroy(h)
+            self._h = None
+            raise
+        self._cells = (C.c_int64 * max(1, len(order))).from_address(L.cdlrm_tape_cells(h))
+        self._replay = L.cdlrm_tape_replay
+
+    def _translate(self, fn, args, torch):
+        if getattr(fn, "argtypes", None) is not None:
+            return [(fn, args)]
+        L = raw()
+        obj, name = getattr(fn, "__self__", None), getattr(fn, "__name__", "")
+        if isinstance(obj, torch.cuda.Stream) and name == "wait_event":
+            return [(L.cdlrm_stream_wait_event, (obj.cuda_stream, self._event(args[0])))]
+        if isinstance(obj, torch.cuda.Event) and name == "record":
+            return [(L.cdlrm_event_record, (self._event(obj), args[0].cuda_stream))]
+        if isinstance(obj, torch.cuda.Stream) and name == "wait_stream":
+            ev = torch.cuda.Event()
+            ev.record(args[0])                    # creates the HIP event (torch makes them lazily)
+            self._keep.append(ev)
+            return [(L.cdlrm_event_record, (ev.cuda_event, args[0].cuda_stream)),
+                    (L.cdlrm_stream_wait_event, (obj.cuda_stream, ev.cuda_event))]
+        raise TapeUnsupported(repr(fn))
+
+    @staticmethod
+    def _event(ev) -> int:
+        h = ev.cuda_event
+        if not h:
+            raise TapeUnsupported("an event that was never recorded has no HIP handle yet")
+        return int(h)
+
+    def _add(self, L, fn, args, index):
+        types = fn.argtypes
+        if len(types) != len(args):
+            raise TapeUnsupported("argument count of %r" % fn)
+        ia, ci, fa = [], [], []
+        for a, ty in zip(args, types):
+            if ty is C.c_float:
+                fa.append(float(a))
+                continue
+            if ty is C.c_double:
+                raise TapeUnsupported("double argument")
+            cell = -1
+            if a is None:
+                v = 0
+            elif isinstance(a, C.c_void_p) and id(a) in index:
+                cell, v = index[id(a)], 0
+            elif isinstance(a, C.Array):
+                v = C.addressof(a)
+            elif isinstance(a, C._SimpleCData):
+                v = a.value or 0
+            elif isinstance(a, (bytes, str)):
+                raise TapeUnsupported("string argument")
+            else:
+                v = int(a)
+            ia.append(v)
+            ci.append(cell)
+        n = len(ia)
+        IA = (C.c_int64 * max(1, n))(*ia)
+        CI = (C.c_int32 * max(1, n))(*ci)
+        FA = (C.c_float * max(1, len(fa)))(*fa)
+        rc = L.cdlrm_tape_add(self._h, C.cast(fn, C.c_void_p), n, IA, CI, len(fa), FA)
+        if rc:
+            raise TapeUnsupported(L.cdlrm_last_error().decode("utf-8", "replace"))
+
+    def replay(self) -> int:
+        """Patch the cells from the shared ctypes cells the Python tape uses, re-issue the step."""
+        cs = self._cells
+        for i, c in enumerate(self._cells_py):
+            cs[i] = c.value or 0
+        return self._replay(self._h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.cdlrm_tape_destroy(h)
 
 
 def check(rc: int) -> None:

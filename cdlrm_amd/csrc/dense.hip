@@ -550,6 +550,14 @@ __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ 
 // MFMA steps (lane half lk holds contraction indices 8g + 4 lk .. +3, as in gemm.h).  No workgroup barrier: every
 // wave owns its LDS slice.  HBM-bound by design: 15.7 KB in + 1.9 KB out per sample against 64 MFMAs.
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifdef IA_STAMP     // tools/interact_ablate.hip: s_memtime stamps of wave 0 of workgroup 0 (4 per sample)
+__device__ long long g_ia_stamp[64];
+#define IA_STAMP_DECL int ia_n = 0;
+#define IA_STAMP_AT(k) { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0 && ia_n < 60) g_ia_stamp[ia_n++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define IA_STAMP_DECL
+#define IA_STAMP_AT(k)
+#endif
 #ifndef IA_ABL
 #define IA_ABL 0      // tools/interact_ablate.hip: 1 no MFMA, 2 no global loads in the loop, 3 no output stores
 #endif
@@ -590,8 +598,11 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
     if (b >= B) return;
     v4f nxt[D4 / 2];
     interact_prefetch<D4>(feat, b, FD4, lane, nxt);
+    IA_STAMP_DECL
     auto one = [&](int64_t b) __attribute__((always_inline)) {
+        IA_STAMP_AT(0)
         interact_stage<D4>(Ts, FD4, lane, nxt);
+        IA_STAMP_AT(1)
 #if IA_ABL != 2
         interact_prefetch<D4>(feat, min(b + nw, B - 1), FD4, lane, nxt);
 #endif
@@ -624,6 +635,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
             acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a0.w, acc10, 0, 0, 0);
             acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, acc11, 0, 0, 0);
         }
+        IA_STAMP_AT(2)
         float* out = R + b * ld_r;
         const int off = itself ? 1 : 0;
 #if IA_ABL == 3
@@ -665,6 +677,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
+        IA_STAMP_AT(3)
     };
     // The first sample is peeled off the loop so that the loop is only ever entered with the same memory operations in
     // flight as its own back edge leaves -- the next sample's loads, then this one's output stores: the wait in front of
@@ -814,7 +827,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
         }
         float* out = dfeat + b * F * D;
         // (STAGED: unrolled, so that the number of stores behind the prefetch loads is a compile-time count)
-#pragma unroll(STAGED ? D / 32 : 1)
+#pragma unroll STAGED ? D / 32 : 1
         for (int n0 = 0; n0 < D; n0 += 32) {
             f32x16 acc;
 #pragma unroll

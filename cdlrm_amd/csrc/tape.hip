@@ -1,0 +1,142 @@
+// Launch tapes: the recorded call sequence of one training step, replayed by ONE library call.
+//
+// The engine (cdlrm_amd/engine.py, _step_taped) records the ~45 calls of a step once per control path -- kernel launches
+// through this library's entry points, event records and stream waits -- and re-issues them every step.  Replayed from
+// Python, each call costs 3-5 us of interpreter and ctypes marshalling: 0.22 ms per step, which at a per-rank batch of
+// 1024 (8192 over 8 GPUs) is MORE than the GPU needs for the step.  A tape holds the same calls as (function pointer,
+// arguments) records; arguments that change from step to step (the batch's tensors) are "cells" the host patches before
+// a replay.
+//
+// The generic call: on the x86-64 System V ABI the k-th integer/pointer argument and the k-th floating-point argument of
+// a call travel in fixed places (rdi, rsi, rdx, rcx, r8, r9, then the stack in order; xmm0-7) whatever their positions
+// in the parameter list, the caller removes the stack arguments, and a callee ignores what it does not declare.  So
+// every entry point of this library (scalar arguments only, at most 8 floats) can be called through ONE function type
+// with its integer-class arguments and its float arguments given separately.  cdlrm_tape_selftest() checks exactly
+// that against a probe with interleaved float / int32 / pointer / stack arguments; the engine falls back to replaying
+// from Python when it fails.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+#define TAPE_MAX_INT 24
+#define TAPE_MAX_FLT 8
+
+typedef int (*tape_fn)(float, float, float, float, float, float, float, float, int64_t, int64_t, int64_t, int64_t,
+                       int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                       int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+
+struct TapeOp {
+    tape_fn fn;
+    int32_t n_int, n_flt;
+    int64_t iargs[TAPE_MAX_INT];
+    int32_t cell[TAPE_MAX_INT];     // -1: literal, else index of the cell whose value is the argument
+    float fargs[TAPE_MAX_FLT];
+};
+
+struct cdlrm_tape {
+    std::vector<TapeOp> ops;
+    std::vector<int64_t> cells;
+};
+
+static inline int tape_call(const TapeOp& o, const int64_t* a) {
+    const float* f = o.fargs;
+    return o.fn(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20], a[21], a[22], a[23]);
+}
+
+extern "C" cdlrm_tape* cdlrm_tape_create(int32_t n_cells) {
+    if (n_cells < 0 || n_cells > 64) { cdlrm_set_error("cdlrm_tape_create: 0..64 cells"); return nullptr; }
+    cdlrm_tape* t = new (std::nothrow) cdlrm_tape();
+    if (!t) { cdlrm_set_error("cdlrm_tape_create: out of memory"); return nullptr; }
+    t->cells.assign((size_t)n_cells, 0);
+    return t;
+}
+
+extern "C" void cdlrm_tape_destroy(cdlrm_tape* t) { delete t; }
+
+extern "C" int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int64_t* iargs, const int32_t* cell,
+                              int32_t n_flt, const float* fargs) {
+    CDLRM_REQUIRE(t && fn, "null argument");
+    CDLRM_REQUIRE(n_int >= 0 && n_int <= TAPE_MAX_INT && n_flt >= 0 && n_flt <= TAPE_MAX_FLT, "too many arguments for a tape call");
+    TapeOp o;
+    o.fn = (tape_fn)fn;
+    o.n_int = n_int; o.n_flt = n_flt;
+    for (int i = 0; i < TAPE_MAX_INT; ++i) {
+        o.iargs[i] = i < n_int ? iargs[i] : 0;
+        o.cell[i] = i < n_int ? cell[i] : -1;
+        CDLRM_REQUIRE(o.cell[i] < (int)t->cells.size(), "cell index outside the tape's cells");
+    }
+    for (int i = 0; i < TAPE_MAX_FLT; ++i) o.fargs[i] = i < n_flt ? fargs[i] : 0.f;
+    t->ops.push_back(o);
+    return 0;
+}
+
+extern "C" int64_t* cdlrm_tape_cells(cdlrm_tape* t) { return t ? t->cells.data() : nullptr; }
+
+extern "C" int64_t cdlrm_tape_length(cdlrm_tape* t) { return t ? (int64_t)t->ops.size() : -1; }
+
+// Re-issues the recorded calls in order; stops at the first call that fails and returns its code (the failing entry
+// point has set cdlrm_last_error()).
+extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
+    CDLRM_REQUIRE(t, "null tape");
+    const int64_t* cells = t->cells.data();
+    for (const TapeOp& o : t->ops) {
+        int64_t a[TAPE_MAX_INT];
+        for (int i = 0; i < TAPE_MAX_INT; ++i) a[i] = o.cell[i] >= 0 ? cells[o.cell[i]] : o.iargs[i];
+        const int rc = tape_call(o, a);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// the stream-ordering calls of a step, as entry points a tape can hold
+extern "C" int cdlrm_event_record(void* event, void* stream) {
+    CDLRM_REQUIRE(event, "null event");
+    CDLRM_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int cdlrm_stream_wait_event(void* stream, void* event) {
+    CDLRM_REQUIRE(event, "null event");
+    CDLRM_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return 0;
+}
+
+// ---- self-test of the generic call ----------------------------------------------------------------------------
+static int64_t g_probe_sum;
+static double g_probe_fsum;
+
+extern "C" int cdlrm_tape_probe(float f0, int64_t a0, float f1, int32_t a1, void* a2, int64_t a3, float f2, int32_t a4,
+                                int64_t a5, int64_t a6, void* a7, int32_t a8, float f3, int64_t a9) {
+    g_probe_sum = a0 + 3 * (int64_t)a1 + 5 * (int64_t)(intptr_t)a2 + 7 * a3 + 11 * (int64_t)a4 + 13 * a5 + 17 * a6 +
+                  19 * (int64_t)(intptr_t)a7 + 23 * (int64_t)a8 + 29 * a9;
+    g_probe_fsum = (double)f0 + 2.0 * f1 + 4.0 * f2 + 8.0 * f3;
+    return 0;
+}
+
+extern "C" int cdlrm_tape_selftest(void) {
+    cdlrm_tape* t = cdlrm_tape_create(2);
+    if (!t) return CDLRM_EINVAL;
+    const int64_t ia[10] = {1000000000007LL, -5, 0x7f00deadbeefLL, 0, 77, -(1LL << 40), 12345, 0, -9, 1LL << 50};
+    int32_t cell[10] = {-1, -1, -1, 0, -1, -1, -1, 1, -1, -1};
+    const float fa[4] = {1.5f, -2.25f, 1024.f, 0.125f};
+    int rc = cdlrm_tape_add(t, (void*)cdlrm_tape_probe, 10, ia, cell, 4, fa);
+    if (!rc) {
+        cdlrm_tape_cells(t)[0] = 424242424242LL;
+        cdlrm_tape_cells(t)[1] = 0x7e00cafe0000LL;
+        g_probe_sum = 0; g_probe_fsum = 0;
+        rc = cdlrm_tape_replay(t);
+        const int64_t want = ia[0] + 3 * ia[1] + 5 * ia[2] + 7 * 424242424242LL + 11 * ia[4] + 13 * ia[5] + 17 * ia[6] +
+                             19 * 0x7e00cafe0000LL + 23 * ia[8] + 29 * ia[9];
+        const double wantf = 1.5 + 2.0 * -2.25 + 4.0 * 1024.0 + 8.0 * 0.125;
+        if (!rc && (g_probe_sum != want || g_probe_fsum != wantf)) {
+            cdlrm_set_error("cdlrm_tape_selftest: the generic call does not reach its arguments on this ABI");
+            rc = CDLRM_EINVAL;
+        }
+    }
+    cdlrm_tape_destroy(t);
+    return rc;
+}

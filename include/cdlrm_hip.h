@@ -404,6 +404,28 @@ int cdlrm_sgd_step2(float* param, const float* grad, int64_t off0, int64_t n0, i
 /* x /= divisor (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239, 244). */
 int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream);
 
+/* ---- launch tapes -------------------------------------------------------------------------------------------------
+ * A training step's call sequence (this library's entry points + event records / stream waits), recorded once per control
+ * path by the host and re-issued by ONE call per step (the reference issues the same ops from Python every iteration,
+ * main_no_ddp.py:404-415; at a per-rank batch of 1024 the interpreter alone costs more than the GPU work).  Calls are
+ * stored as (function, integer-class arguments, float arguments); an integer argument may be a "cell" -- a slot of the
+ * tape's cell array that the host patches before a replay (the batch's tensors).  x86-64 System V only: see
+ * csrc/tape.hip; cdlrm_tape_selftest() returns 0 where the generic call works. */
+typedef struct cdlrm_tape cdlrm_tape;
+cdlrm_tape* cdlrm_tape_create(int32_t n_cells);
+void cdlrm_tape_destroy(cdlrm_tape* t);
+/* fn: any entry point of this header with scalar arguments (<= 24 integer-class, <= 8 float); iargs/fargs in parameter
+ * order per class; cell[i] >= 0 takes iargs[i] from that cell at replay time. */
+int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int64_t* iargs, const int32_t* cell, int32_t n_flt,
+                   const float* fargs);
+int64_t* cdlrm_tape_cells(cdlrm_tape* t);
+int64_t cdlrm_tape_length(cdlrm_tape* t);
+int cdlrm_tape_replay(cdlrm_tape* t);      /* first non-zero return code of a replayed call, else 0 */
+int cdlrm_tape_selftest(void);
+/* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
+int cdlrm_event_record(void* event, void* stream);
+int cdlrm_stream_wait_event(void* stream, void* event);
+
 #ifdef __cplusplus
 }
 #endif

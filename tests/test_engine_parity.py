@@ -150,6 +150,52 @@ def test_chained_take_long_batch_path(golden, name, defer):
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["train_small", "train_c1"])
+def test_native_tape_replays_the_recorded_step(golden, name):
+    """The C-side launch tape (csrc/tape.hip: one library call re-issues the ~45 recorded calls of a step, event records
+    and stream waits included) against the same tape replayed from Python: bit-identical losses, tags and weights; and
+    the native tapes really are the ones that ran."""
+    from cdlrm_amd import _lib
+    from cdlrm_amd.engine import WindowResolver
+    assert _lib.native_tape_ok()
+    g = golden(name)
+    L = int(g["L"])
+    batches = make_batches(g)
+    runs = []
+    for native in (False, True):
+        host, cg, dl, eng, pipe = build(g, aux_phases=2)
+        eng.native_tape = native
+        dev_idx = [b[1].to(DEV) for b in batches]
+        losses = []
+        for j, (X, lS_i, Tt) in enumerate(batches):
+            if j % L == 0:
+                win = torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV)
+                if "reseed" not in g.files or bool(g["reseed"]):
+                    torch.manual_seed(5000 + j)
+                pipe.plan_window(win)
+                pipe.commit()
+                pipe.wait_writeback()
+                rs = WindowResolver(eng, win, int(g["B"]), chunk=3)
+            nxt = dev_idx[j + 1] if j + 1 < len(batches) and (j + 1) % L != 0 else None
+            loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt, res=rs.batch(j % L),
+                            next_res=rs.batch(j % L + 1) if nxt is not None else None)
+            rs.ensure(j % L + rs.CH + 2)
+            losses.append(loss[0:1].clone())
+        eng.finish()
+        torch.cuda.synchronize()
+        n_native = sum(1 for t in eng._tapes.values() if t["native"] is not None)
+        assert (n_native > 0) == native and len(eng._tapes) > 0
+        if native:
+            assert all(int(_lib.raw().cdlrm_tape_length(t["native"]._h)) >= len(t["prog"]) for t in eng._tapes.values())
+        runs.append((torch.cat(losses).cpu(), cg.tags.cpu().clone(), cg.weight.data.cpu().clone(),
+                     [l.weight.data.cpu().clone() for l in dl.top_l if hasattr(l, "weight")]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    for a, b in zip(runs[0][3], runs[1][3]):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(runs[1][0].numpy(), g["losses"], rtol=1e-5)
+
+
 def test_host_gather_plan_equals_device_fetch(golden):
     """WindowPipeline(host_gather=True) -- CPU threads gather the winners' / victims' rows, one DMA copy each, from a
     background thread -- leaves exactly the cache, tag and victim state of the default plan (GPU waves reading the

@@ -802,7 +802,14 @@ def test_head_vs_torch_fp32(ops, B, K, x_act):
     np.testing.assert_allclose(float(lb[0]), float(E), rtol=1e-5)
     np.testing.assert_allclose(dZ.cpu().numpy(), pre.grad.numpy(), rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(dYd[:, :K].cpu().numpy(), (Yr.grad * mask).numpy(), rtol=1e-4, atol=1e-9)
-    assert float(scratch[0]) == 0.0
+    # the two-call form: partial sums first, the loss when cdlrm_head_finish has run
+    lb2 = torch.full((65,), -1.0, device=DEV)
+    ops.head_fwd_bwd(Yd[:, :K], w.to(DEV), b.to(DEV), tt.to(DEV), Z, dZ, dYd[:, :K], lb2, scratch, x_act=x_act, finish=False)
+    torch.cuda.synchronize()
+    assert float(lb2[0]) == -1.0
+    ops.head_finish(scratch, B, lb2)
+    torch.cuda.synchronize()
+    assert torch.equal(lb2[:3], lb[:3])
 
 
 def test_streamed_window_unique_equals_one_shot(ops):

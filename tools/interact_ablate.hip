@@ -29,6 +29,15 @@ int main(int argc, char** argv) {
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("ABL %d %s %.1f us\n", IA_ABL, which ? "bwd" : "fwd", ms / 30 * 1e3);
+#ifdef IA_STAMP
+        if (which == 0) {
+            long long st[64];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ia_stamp), sizeof(st));
+            for (int i = 0; i + 3 < 60 && st[i + 3] > st[0]; i += 4)
+                printf("  sample %d: start +%lld | stage %lld | mfma %lld | out %lld  (memtime ticks)\n", i / 4, st[i] - st[0],
+                       st[i + 1] - st[i], st[i + 2] - st[i + 1], st[i + 3] - st[i + 2]);
+        }
+#endif
     }
     return 0;
 }
