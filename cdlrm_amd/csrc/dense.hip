@@ -1209,8 +1209,9 @@ extern "C" int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n
 #define HEAD_ABL 0        // tools/head_ablate.hip: 1 no partial sums, 2 no dY stores
 #endif
 #define HEAD_MAX_BLOCKS 1024
+#define HEAD_TAIL_BLOCKS 128
 
-template <bool VEC>
+template <bool VEC, bool TAIL>
 __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ w,
                                               const float* __restrict__ bias, const float* __restrict__ T, int64_t B,
                                               int K, LossCfg c, int x_act, float* __restrict__ Zout,
@@ -1322,6 +1323,32 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
         scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
         scratch[HEAD_MAX_BLOCKS + blockIdx.x] = (float)(redc[0] + redc[1] + redc[2] + redc[3]);
     }
+    if (!TAIL) return;
+    // Short batches (<= HEAD_TAIL_BLOCKS workgroups, little dirty data in the L2s): the workgroup that arrives last sums the
+    // partials itself -- a second launch costs its 5 us floor, more than the fences do here.  Same summation order as
+    // k_head_finish.  scratch[2 * HEAD_MAX_BLOCKS] is the arrival counter: zero before the first call, left zero.
+    __shared__ unsigned last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(scratch + 2 * HEAD_MAX_BLOCKS), 1u);
+    }
+    __syncthreads();
+    if (last == gridDim.x - 1 && wave == 0) {
+        __threadfence();
+        float s = 0.f, cnt = 0.f;
+        for (unsigned i = lane; i < gridDim.x; i += 64) {
+            s += __builtin_nontemporal_load(scratch + i);
+            cnt += __builtin_nontemporal_load(scratch + HEAD_MAX_BLOCKS + i);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+        if (lane == 0) {
+            loss[0] = s / (float)B;
+            loss[1] = cnt;
+            loss[2] = (s / (float)B) * (float)B;
+            *reinterpret_cast<unsigned*>(scratch + 2 * HEAD_MAX_BLOCKS) = 0u;
+        }
+    }
 }
 
 // fixed order for a given number of partials: lane i sums partials i, i + 64, ..., then a butterfly over the lanes
@@ -1342,7 +1369,7 @@ __global__ void __launch_bounds__(64) k_head_finish(const float* __restrict__ sc
     }
 }
 
-extern "C" int64_t cdlrm_head_scratch_floats(void) { return 2 * HEAD_MAX_BLOCKS; }
+extern "C" int64_t cdlrm_head_scratch_floats(void) { return 2 * HEAD_MAX_BLOCKS + 1; }
 
 static int64_t head_grid(int64_t B) {
     int64_t gx = cdiv(B, 16);                       // 4 waves x 4 rows per pass
@@ -1359,13 +1386,17 @@ extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, c
     c.kind = kind; c.w0 = w0; c.w1 = w1; c.thr = threshold;
     const int64_t gx = head_grid(B);
     const bool vec = K % 4 == 0 && ldy % 4 == 0 && (!dY || lddy % 4 == 0) && (((uintptr_t)Y | (uintptr_t)w | (uintptr_t)dY) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL(k_head<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B,
-                           (int)K, c, (int)x_act, Z, Zc, dZ, dY, lddy, loss_out, scratch);
-    else
-        hipLaunchKernelGGL(k_head<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B,
-                           (int)K, c, (int)x_act, Z, Zc, dZ, dY, lddy, loss_out, scratch);
+    const bool tail = finish && gx <= HEAD_TAIL_BLOCKS;
+#define HEAD_CALL(V_, T_)                                                                                      \
+    hipLaunchKernelGGL((k_head<V_, T_>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, Y, ldy, w, bias, target, B, \
+                       (int)K, c, (int)x_act, Z, Zc, dZ, dY, lddy, loss_out, scratch)
+    if (vec && tail) HEAD_CALL(true, true);
+    else if (vec) HEAD_CALL(true, false);
+    else if (tail) HEAD_CALL(false, true);
+    else HEAD_CALL(false, false);
+#undef HEAD_CALL
     CDLRM_LAUNCH_CHECK();
+    if (tail) return 0;
     if (finish) return cdlrm_head_finish(scratch, B, loss_out, stream);
     return 0;
 }

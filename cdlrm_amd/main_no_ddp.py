@@ -597,8 +597,9 @@ def main(argv=None):
         sys.exit("ERROR: cdlrm_amd.main_no_ddp runs on one node (RANK %d != LOCAL_RANK %d), like the reference"
                  % (rank, local_rank))
     ln_bot = np.fromstring(args.arch_mlp_bot, dtype=int, sep="-")
-    if args.data_generation not in ("random", "criteo-synthetic", "dataset"):
-        sys.exit("ERROR: --data-generation=%s is not supported (dataset | criteo-synthetic | random)" % args.data_generation)
+    if args.data_generation not in ("random", "synthetic", "criteo-synthetic", "dataset"):
+        sys.exit("ERROR: --data-generation=%s is not supported (dataset | criteo-synthetic | random | synthetic)"
+                 % args.data_generation)
     train_ld = test_ld = None
     if args.data_generation == "dataset":
         # the pre-processed day files of the reference's terabyte path (dlrm_data_pytorch.py:440-492): table sizes
@@ -649,8 +650,9 @@ def main(argv=None):
     emb_tables = make_host_tables(ln_emb, m_spa, device=dev, seed=args.numpy_rand_seed, rank=rank, world=args.world_size,
                                   shm_name="cdlrm_run_%d" % args.master_port,
                                   barrier=(dist.barrier if args.world_size > 1 else (lambda: None)))
-    if train_ld is None and args.data_generation == "random":
-        # the reference's random front end (dlrm_data_pytorch.py:658-684): uniform multi-hot bags, ragged tables
+    if train_ld is None and args.data_generation in ("random", "synthetic"):
+        # the reference's random front ends (dlrm_data_pytorch.py:658-684): uniform multi-hot bags, or bags with the reuse
+        # profile of a recorded trace (--data-trace-file, "j" = table number); ragged tables either way
         from .dlrm_data_pytorch import make_random_data_and_loader
         _, train_ld = make_random_data_and_loader(args, ln_emb, m_den)
         train_ld.multi_hot = True

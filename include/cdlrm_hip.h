@@ -377,8 +377,8 @@ int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t k
  * NULL), the loss above, and the layer's input gradient.  Y [B, K] (row pitch ldy) is the layer's input, produced
  * by activation x_act (0 none, 1 ReLU, 2 sigmoid).  Outputs: Z [B] = sigmoid(Y w + b), Zc [B] (may be NULL) clamped
  * prediction, dZ [B] = dL/d(pre-activation of the last layer), dY [B, K] (pitch lddy; may be NULL) = dZ w^T times
- * the derivative of x_act, loss_out[0..2] as for cdlrm_loss_fwd_bwd.  scratch: cdlrm_head_scratch_floats() floats
- * (per-workgroup partial sums of the loss).  finish != 0: loss_out is complete when the call's work on `stream` is;
+ * the derivative of x_act, loss_out[0..2] as for cdlrm_loss_fwd_bwd.  scratch: cdlrm_head_scratch_floats() floats,
+ * zeroed once by the caller (per-workgroup partial sums of the loss + one arrival counter the kernel leaves zero).  finish != 0: loss_out is complete when the call's work on `stream` is;
  * finish == 0: the partial sums are left in `scratch` and cdlrm_head_finish(scratch, B, loss_out, any stream ordered
  * behind this call) turns them into loss_out -- the training step runs it beside the backward, not in front of it. */
 int64_t cdlrm_head_scratch_floats(void);

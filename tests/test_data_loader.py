@@ -57,3 +57,46 @@ def test_random_dataset_matches_reference(golden, tag, fixed):
     assert len(lens) > 1, "the fixture must be ragged"
     Xc, oc, ic, Tc = DP.collate_wrapper_random([ds[1]])
     assert oc.shape == (len(ln_emb), 12) and isinstance(ic, list)
+
+
+def test_synthetic_trace_front_end_matches_reference(golden, tmp_path):
+    """`--data-generation=synthetic` (dlrm_data_pytorch.py:808-1129): trace -> stack-distance profile -> dist file -> LRU
+    trace generation -> RandomDataset batches, each stage against the reference's output for the same numpy seed; with and
+    without padding, fixed and drawn bag sizes."""
+    from cdlrm_amd import dlrm_data_pytorch as DP
+    g = golden("synthetic_data")
+    ln_emb = np.array(g["ln_emb"])
+    d = str(tmp_path)
+    assert "j" not in d, "the reference replaces every letter j of the path by the table number"
+    for pad in (0, 1):
+        for i in range(len(ln_emb)):
+            tag = "p%d_t%d" % (pad, i)
+            trace = g[tag + "_trace"].tolist()
+            uniq, list_sd, cumm_sd = DP.trace_distribution(trace, bool(pad))
+            assert [int(x) for x in uniq] == g[tag + "_uniq"].tolist()
+            assert list_sd == g[tag + "_list_sd"].tolist()
+            assert cumm_sd == g[tag + "_cumm_sd"].tolist()                      # the same float sums, bit for bit
+            path = os.path.join(d, "dist%d_%d.log" % (pad, i))
+            DP.write_dist_to_file(path, uniq, list_sd, cumm_sd)
+            assert open(path, "rb").read() == g[tag + "_file"].tobytes()        # byte-identical profile file
+            assert DP.read_dist_from_file(path) == ([int(x) for x in uniq], list_sd, cumm_sd)
+        for fixed in (0, 1):
+            ds = DP.RandomDataset(3, ln_emb, 0, 2, 6, 5, bool(fixed), 1, True, "synthetic",
+                                  os.path.join(d, "dist%d_j.log" % pad), bool(pad), reset_seed_on_access=True, rand_seed=19)
+            for b in range(2):
+                X, lS_o, lS_i, T = ds[b]
+                tag = "p%d_f%d_b%d" % (pad, fixed, b)
+                assert np.array_equal(X.numpy(), g[tag + "_X"]) and np.array_equal(T.numpy(), g[tag + "_T"])
+                for k in range(len(ln_emb)):
+                    assert np.array_equal(lS_o[k].numpy(), g[tag + "_o%d" % k]), (tag, k)
+                    assert np.array_equal(lS_i[k].numpy(), g[tag + "_i%d" % k]), (tag, k)
+    uniq, list_sd, cumm_sd = DP.read_dist_from_file(os.path.join(d, "dist0_0.log"))
+    np.random.seed(5)
+    assert [int(x) for x in DP.trace_generate_lru(list(uniq), list_sd, cumm_sd, 200, False)] == g["lru_trace"].tolist()
+    np.random.seed(5)
+    assert [int(x) for x in DP.trace_generate_rand(list(uniq), list_sd, cumm_sd, 200, False)] == g["rand_trace"].tolist()
+    # trace files, both encodings
+    for binary in (False, True):
+        p = os.path.join(d, "trace_%d" % int(binary))
+        DP.write_trace_to_file(p, g["lru_trace"].tolist(), binary)
+        assert [int(x) for x in DP.read_trace_from_file(p, binary)] == g["lru_trace"].tolist()

@@ -372,6 +372,64 @@ def g_random_data(M, MD, CM, QR):
     save("random_data", **out)
 
 
+def g_synthetic_data(M, MD, CM, QR):
+    """The reference's `synthetic` front end (dlrm_data_pytorch.py:808-1129): two recorded traces profiled into their
+    stack-distance distributions (trace_profile + the module's main, :1086-1117), written with write_dist_to_file, then
+    batches of RandomDataset(data_generation="synthetic") over them -- non-fixed and fixed bag sizes, with and without
+    padding -- and a stand-alone trace_generate_lru / trace_generate_rand run."""
+    import collections
+    import operator
+    import tempfile
+    import dlrm_data_pytorch as DP
+    rng = np.random.RandomState(77)
+    out = {}
+    ln_emb = np.array([40, 9])
+    traces = [(rng.zipf(1.4, 300) % 40).astype(np.uint64).tolist(), (rng.randint(0, 9, 120)).astype(np.uint64).tolist()]
+    td = "/tmp/cdlrm_synth_golden"        # no letter "j" anywhere in the path: the reference replaces every one of them
+    os.makedirs(td, exist_ok=True)
+    if True:
+        for pad in (False, True):
+            for i, trace in enumerate(traces):
+                _, sds, uniq = DP.trace_profile(trace, pad)
+                sds.reverse()
+                uniq.reverse()
+                l = len(sds)
+                dc = sorted(collections.Counter(sds).items(), key=operator.itemgetter(0))
+                list_sd = [x for x, _ in dc]
+                cumm_sd = []
+                for q, (_, k) in enumerate(dc):
+                    cumm_sd.append(k / float(l) if q == 0 else cumm_sd[q - 1] + (k / float(l)))
+                # file name template: every "j" becomes the table number
+                # (ints: under numpy 2 str([np.uint64(3)]) is "np.uint64(3)", which the reference's reader cannot parse;
+                #  the numpy 1.x it was written for prints "3")
+                DP.write_dist_to_file(os.path.join(td, "dist%d_%d.log" % (int(pad), i)), [int(x) for x in uniq], list_sd,
+                                      cumm_sd)
+                tag = "p%d_t%d" % (int(pad), i)
+                out[tag + "_trace"] = np.array(trace, dtype=np.uint64)
+                out[tag + "_uniq"] = np.array(uniq, dtype=np.uint64)
+                out[tag + "_list_sd"] = np.array(list_sd)
+                out[tag + "_cumm_sd"] = np.array(cumm_sd, dtype=np.float64)
+                out[tag + "_file"] = np.frombuffer(open(os.path.join(td, "dist%d_%d.log" % (int(pad), i)), "rb").read(),
+                                                   dtype=np.uint8)
+            for fixed in (False, True):
+                ds = DP.RandomDataset(3, ln_emb, 0, 2, 6, 5, fixed, 1, True, "synthetic",
+                                      os.path.join(td, "dist%d_j.log" % int(pad)), pad, reset_seed_on_access=True,
+                                      rand_seed=19)
+                for b in range(2):
+                    X, lS_o, lS_i, T = ds[b]
+                    tag = "p%d_f%d_b%d" % (int(pad), int(fixed), b)
+                    out[tag + "_X"], out[tag + "_T"] = X, T
+                    for k in range(len(ln_emb)):
+                        out[tag + "_o%d" % k], out[tag + "_i%d" % k] = lS_o[k], lS_i[k]
+        uniq, list_sd, cumm_sd = DP.read_dist_from_file(os.path.join(td, "dist0_0.log"))
+        np.random.seed(5)
+        out["lru_trace"] = np.array(DP.trace_generate_lru(list(uniq), list_sd, cumm_sd, 200, False), dtype=np.uint64)
+        np.random.seed(5)
+        out["rand_trace"] = np.array(DP.trace_generate_rand(list(uniq), list_sd, cumm_sd, 200, False), dtype=np.uint64)
+    out["ln_emb"] = ln_emb
+    save("synthetic_data", **out)
+
+
 def g_embbag_sgd(M, MD, CM, QR):
     """nn.EmbeddingBag(sum, sparse) backward + optim.SGD step on cache rows (a-7), with repeated
     slots and a multi-hot case."""
@@ -784,7 +842,7 @@ def g_criteo_loader(M, MD, CM, QR):
 
 
 GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
-            dense_variants=g_dense_variants, random_data=g_random_data,
+            dense_variants=g_dense_variants, random_data=g_random_data, synthetic_data=g_synthetic_data,
             embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_shapes=g_train_shapes, train_w2=g_train_w2, qr=g_qr, md=g_md,
             window_groups=g_window_groups)
 
