@@ -30,8 +30,14 @@ def is_hip(device) -> bool:
     return torch.device(device).type == "cuda"
 
 
-def new_stream(device):
-    return torch.cuda.Stream(device=device) if is_hip(device) else _NullStream()
+def new_stream(device, priority=None):
+    """A side stream; CDLRM_SIDE_PRIORITY (an integer, lower = more urgent) sets the priority of all of them."""
+    if not is_hip(device):
+        return _NullStream()
+    import os
+    if priority is None and os.environ.get("CDLRM_SIDE_PRIORITY"):
+        priority = int(os.environ["CDLRM_SIDE_PRIORITY"])
+    return torch.cuda.Stream(device=device) if priority is None else torch.cuda.Stream(device=device, priority=priority)
 
 
 def current_stream(device):

@@ -350,6 +350,10 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", rank=rank, world_size=world)
     local_batch_size = math.ceil(args.mini_batch_size / world)
+    prio = int(os.environ.get("CDLRM_MAIN_PRIORITY", "-1"))
+    if prio != 0:
+        # the trainer's queue outranks the engine's side queues (see bench.py)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=prio))
 
     # multi-hot bags (--data-generation=random): a batch has up to mini_batch_size * num_indices_per_lookup lookups per
     # table, each miss takes its own aux row (model_no_ddp.py:176-179) -- the reference sizes the aux region for one
