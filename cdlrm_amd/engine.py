@@ -435,6 +435,7 @@ class TrainEngine:
         self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
         self.chain_take = os.environ.get("CDLRM_CHAIN_TAKE", "1") != "0"
         self.native_tape = os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0"
+        self.wgrad_late = os.environ.get("CDLRM_WGRAD_LATE", "0") == "1"
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -865,19 +866,25 @@ class TrainEngine:
             ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, None, None, act,
                            buf["lin_work"], x_act=(self.top[i - 1][1] if i > 0 else 0))
             dY = dX
-        if split is not None:
-            # Every top-layer dZ is final: the top MLP's weight gradients start now, on their own stream, beside the
-            # interaction backward and the bottom MLP's backward.  (Launching each layer's weight gradient as soon as
-            # ITS dZ exists -- beside the dgrad chain itself -- measured slower: 0.810 vs 0.782 ms at B=8192; the
-            # chain is the critical path and loses CUs to them.)
-            rec(ev["top_dz"].record, main)
-            rec(wst.wait_event, ev["top_dz"])
+        def top_wgrad(after):
+            # Every top-layer dZ is final: the top MLP's weight gradients run on their own stream, beside the bottom MLP's
+            # backward.  (Launching each layer's weight gradient as soon as ITS dZ exists -- beside the dgrad chain itself
+            # -- measured slower: 0.810 vs 0.782 ms at B=8192; the chain is the critical path and loses CUs to them.)
+            rec(wst.wait_event, after)
             ops.mlp_wgrad(split[1], stream=wst)
             if not self.defer_top:
                 rec(ev["wgrad_done"].record, wst)
             elif self.world == 1:
                 ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
                 rec(ev["top_updated"].record, wst)
+
+        # CDLRM_WGRAD_LATE=1: one event on the main queue for both side streams (recorded behind the interaction backward)
+        # instead of one in front of it for the weight gradients and one behind it for the embedding backward.  Measured
+        # slower at c3 (0.698 vs 0.675 ms): the saved bubble is worth less than the 57 us the weight gradients start later.
+        wgrad_late = self.wgrad_late and split is not None and not self.cat
+        if split is not None and not wgrad_late:
+            rec(ev["top_dz"].record, main)
+            top_wgrad(ev["top_dz"])
         if self.cat:
             # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
             # derivative (the dot path applies it in the interaction backward's epilogue)
@@ -887,6 +894,8 @@ class TrainEngine:
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
         rec(ev["interacted"].record, main)
+        if wgrad_late:
+            top_wgrad(ev["interacted"])
         rec(side.wait_event, ev["interacted"])
         ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
                              cg.touched if self.world > 1 else None, stream=side)
