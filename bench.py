@@ -238,11 +238,13 @@ def main():
     ev_pairs = []
     ev_flags = []                           # per sampled launch: did a window plan run beside it?
     refills = {"commits": 0, "plans": 0, "merges": 0, "first_plan_ms": None, "first_commit_ms": None}
-    # the roofline kernel is sampled with HIP events on its own stream: every launch of a short run (the driver's
-    # 20-step run would otherwise keep 3 samples), every k-th of a long one
-    sample_every = 1 if a.steps < 64 else max(1, a.gather_sample)
-    # the timing events exist before the timed region starts; the two records per sampled step ride on the engine's tape
-    ev_pool = {j: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    # the roofline kernel is timed with HIP events ATTACHED TO ITS LAUNCH (cdlrm_ctx_time_next_gather -> hipExtLaunchKernel:
+    # the kernel's own start / stop timestamps, no marker packets on the queue), so every launch of the timed region can be
+    # sampled without moving it; runs beyond 4096 steps keep every --gather-sample'th
+    sample_every = 1 if a.steps <= 4096 else max(1, a.gather_sample)
+    # the events exist before the timed region starts; their handles are cells of the engine's launch tape
+    from cdlrm_amd import ops as _ops
+    ev_pool = {j: (_ops.TimingEvent(), _ops.TimingEvent())
                for j in range(a.warmup, total_steps) if a.gather_sample > 0 and j % sample_every == 0}
 
     def begin_window(w, timed):
@@ -330,7 +332,7 @@ def main():
     loss = float(eng._bufs[lbs]["loss"][0])
 
     if rank == 0:
-        g_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in ev_pairs]
+        g_us = [e0.elapsed_us(e1) for e0, e1 in ev_pairs]
         gather_ms = float(np.mean(g_us)) * 1e-3 if g_us else float("nan")
         lookups = lbs * len(ln_emb)
         alg_bytes = lookups * (8 * D + 16)          # fp32 row read + fp32 row write + int64 index + int64 offset

@@ -114,6 +114,10 @@ PROTOTYPES = {
     "cdlrm_tape_selftest": (C.c_int, []),
     "cdlrm_event_record": (C.c_int, [vp, vp]),
     "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
+    "cdlrm_event_create": (vp, [c_i32]),
+    "cdlrm_event_destroy": (C.c_int, [vp]),
+    "cdlrm_event_elapsed_us": (C.c_int, [vp, vp, vp]),
+    "cdlrm_ctx_time_next_gather": (C.c_int, [vp, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -41,6 +41,8 @@ struct cdlrm_ctx {
     const int64_t* vict_off = nullptr;
     const float* vict_rows = nullptr;
     int* d_err = nullptr;                // device error word
+    void* ev_start = nullptr;            // cdlrm_ctx_time_next_gather: events of the NEXT cdlrm_embbag_fwd launch
+    void* ev_stop = nullptr;
     int64_t* d_scan = nullptr;           // block sums for the scans of the window plan (plan stream)
     int64_t scan_cap = 0;
     // block sums for the table-agg / sync-to-rank-0 compaction: those run on the MAIN stream while the plan of the

@@ -5,6 +5,7 @@
 // 16-byte lanes), one flat int64 tag buffer, tags of a set contiguous (ways*8 bytes = one 128-B line
 // at 16 ways).  Every kernel covers all T tables in one launch: blockIdx.y = table.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 // ---------------------------------------------------------------------------------------------
 // K6a: tag probe.  LPL lanes cooperate on one lookup: lane g reads ways g, g+LPL, ... (8-byte tags,
@@ -612,6 +613,13 @@ extern "C" int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, 
     return 0;
 }
 
+extern "C" int cdlrm_ctx_time_next_gather(cdlrm_ctx* ctx, void* start_event, void* stop_event) {
+    CDLRM_REQUIRE(ctx && start_event && stop_event, "null argument");
+    ctx->ev_start = start_event;
+    ctx->ev_stop = stop_event;
+    return 0;
+}
+
 extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,
                                 int64_t n_bags, int64_t ld_off, float* out, int64_t ld_bag, int64_t ld_table,
                                 void* stream) {
@@ -626,6 +634,8 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
     const int lpr = lanes_per_row(D4);
     const int gpb = 256 / lpr;
     const float4* w = reinterpret_cast<const float4*>(ctx->weight);
+    hipEvent_t ev0 = (hipEvent_t)ctx->ev_start, ev1 = (hipEvent_t)ctx->ev_stop;
+    ctx->ev_start = ctx->ev_stop = nullptr;
     static int variant = -1;
     static int pgrid = 4096;     // measured on MI355X (c3 shape): persistent U=4, 4096 workgroups 33 us vs 45 us one-shot
     if (variant < 0) {
@@ -643,14 +653,17 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
         const int U = variant;
         int64_t total = cdiv(n, (int64_t)gpb * U) * ctx->T;
         int64_t gx = total < pgrid ? total : pgrid;
+        // the launch's own start / stop timestamps land in the caller's events (cdlrm_ctx_time_next_gather): no marker
+        // packets on the queue, so timing a launch does not move it or its neighbours
 #define PFWD_CALL(L)                                                                                                  \
-    if (U == 4) hipLaunchKernelGGL((k_embbag_fwd_arange_p<L, 4>), dim3((unsigned)gx), dim3(256), 0, s, ctx->d_tab,   \
-                                   ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt);                              \
-    else hipLaunchKernelGGL((k_embbag_fwd_arange_p<L, 8>), dim3((unsigned)gx), dim3(256), 0, s, ctx->d_tab, ctx->T,  \
-                            D4, w, slots, n, out, ld_bag, ld_table, nt)
+    if (U == 4) hipExtLaunchKernelGGL((k_embbag_fwd_arange_p<L, 4>), dim3((unsigned)gx), dim3(256), 0, s, ev0, ev1, 0, \
+                                      ctx->d_tab, ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt);               \
+    else hipExtLaunchKernelGGL((k_embbag_fwd_arange_p<L, 8>), dim3((unsigned)gx), dim3(256), 0, s, ev0, ev1, 0,     \
+                               ctx->d_tab, ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt)
         DISPATCH_LPR(lpr, PFWD_CALL)
 #undef PFWD_CALL
     } else if (!offsets) {
+        if (ev0) CDLRM_HIP_CHECK(hipEventRecord(ev0, s));
         int64_t gx = cdiv(n, (int64_t)gpb * FWD_UNROLL);
         if (gx > 65535) gx = 65535;
         dim3 grid((unsigned)gx, (unsigned)ctx->T);
@@ -658,6 +671,7 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
         DISPATCH_LPR(lpr, FWD_CALL)
 #undef FWD_CALL
     } else {
+        if (ev0) CDLRM_HIP_CHECK(hipEventRecord(ev0, s));
         int64_t gx = cdiv(n_bags, gpb);
         if (gx > 65535) gx = 65535;
         dim3 grid((unsigned)gx, (unsigned)ctx->T);
@@ -665,6 +679,7 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
         DISPATCH_LPR(lpr, FWD_CALL)
 #undef FWD_CALL
     }
+    if (ev1 && (offsets || !(variant == 4 || variant == 8))) CDLRM_HIP_CHECK(hipEventRecord(ev1, s));
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

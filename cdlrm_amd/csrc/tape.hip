@@ -105,6 +105,31 @@ extern "C" int cdlrm_stream_wait_event(void* stream, void* event) {
     return 0;
 }
 
+// timing events of the library's own (a torch event has no HIP handle before its first record; a tape needs the handle
+// when it is built)
+extern "C" void* cdlrm_event_create(int32_t timing) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) {
+        cdlrm_set_error("cdlrm_event_create: hipEventCreateWithFlags failed");
+        return nullptr;
+    }
+    return (void*)e;
+}
+
+extern "C" int cdlrm_event_destroy(void* event) {
+    if (event) CDLRM_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+    return 0;
+}
+
+extern "C" int cdlrm_event_elapsed_us(void* start, void* stop, float* us) {
+    CDLRM_REQUIRE(start && stop && us, "null argument");
+    float ms = 0.f;
+    CDLRM_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    CDLRM_HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+    *us = ms * 1e3f;
+    return 0;
+}
+
 // ---- self-test of the generic call ----------------------------------------------------------------------------
 static int64_t g_probe_sum;
 static double g_probe_fsum;

@@ -556,10 +556,6 @@ class TrainEngine:
         self._bufs[B] = b
         return b
 
-    def _gather_mark(self, which, stream):
-        """Record the current step's start / stop timing event (a taped call: the event pair changes per step)."""
-        self._gslot[which].record(stream)
-
     def _probe_bufs(self, n, which):
         """(slots, miss_pos, miss_count) of one pipeline stage, allocated once: they are written and read on side
         streams, where the caching allocator's per-stream reuse rules would not protect per-call temporaries."""
@@ -642,14 +638,15 @@ class TrainEngine:
         # (the row merge at the end of a table-agg step leaves aux rows alone -- the backward never flags them --, so the
         #  next batch's probe / aux fill may run ahead across it like across any other step)
         sgd_done = False
-        # bench.py: HIP timing events around the roofline kernel, on ITS stream -- a pre-created (start, stop) pair, or a
-        # list that receives a new pair.  The two records ride on the step's tape through `_gather_mark`.
+        # bench.py: HIP timing events of the roofline kernel -- a pre-created (start, stop) pair of ops.TimingEvent, or a list
+        # that receives a new pair.  They are attached to the gather's launch (cdlrm_ctx_time_next_gather); on a tape the
+        # pair's handles are cells.
         if gather_events is None:
             self._gslot = None
         elif isinstance(gather_events, tuple):
             self._gslot = gather_events
         else:
-            self._gslot = (S.new_event(self.dev, True), S.new_event(self.dev, True))
+            self._gslot = (ops.TimingEvent(), ops.TimingEvent())
             gather_events.append(self._gslot)
         if res is not None:
             # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
@@ -740,11 +737,12 @@ class TrainEngine:
             # the previous step's top weight gradients read R = the feature block this step's first kernels overwrite
             rec(main.wait_event, ev["top_updated"])
         pref, self._pref = self._pref, None
-        top_waited = False
+        top_waited = prepared = False
         if pref is not None and pref["ptr"] == lS_i.data_ptr() and pref["shape"] == tuple(lS_i.shape):
             slots, miss_pos, miss_count, probed = pref["res"]
             self._phase = pref["phase"]
             top_waited = bool(pref.get("chained_top"))
+            prepared = bool(pref.get("prepared"))
         else:
             rec(side.wait_stream, main)
             if self._res is not None and lS_o is None:
@@ -758,12 +756,9 @@ class TrainEngine:
         n_bags = B if lS_o is None else lS_o.shape[1]
 
         def gather(st):
-            if self._gslot is not None:         # bench.py: HIP events around the roofline kernel, on ITS stream
-                rec(self._gather_mark, 0, st)
-                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
-                rec(self._gather_mark, 1, st)
-            else:
-                ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
+            if self._gslot is not None:         # bench.py: the roofline kernel's own start / stop timestamps
+                ops.time_next_gather(ctx, self._gslot[0], self._gslot[1])
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
 
         # Short local batches: the gather (6 us at 1024) goes to the SIDE stream, beside the bottom MLP's forward -- it
         # needs the probe result and the previous step's embedding update, which ran on that very stream (in order: no
@@ -815,7 +810,8 @@ class TrainEngine:
         emb_work = self._emb_work(n)
         if not side_gather:
             rec(side.wait_event, probed)
-        ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
+        if not prepared:        # (a chained take sorted this batch's slots right behind itself, in the previous step)
+            ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         if self.defer_top and not self.cat and not top_waited:
             # the previous step's top-MLP update (weight gradients read R / top_y / top_dy, then all-reduce and SGD on
             # the side stream) has to have landed before this step overwrites those buffers and reads the weights
@@ -910,13 +906,17 @@ class TrainEngine:
                 ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=0, stream=side)
             else:
                 res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
+            if chain:
+                # ... and the sort of the next batch's slot ids for ITS backward: here it ends well before the step does; issued
+                # by the next step it ran late enough to share HBM with that step's gather (the roofline kernel)
+                ops.embbag_bwd_prepare(ctx, res[0], emb_work, stream=side)
             chained_top = chain and self.defer_top and self.world == 1 and split is not None
             if chained_top:
                 rec(side.wait_event, ev["top_updated"])     # recorded above, behind this step's top-MLP SGD
             evp = ev["probed"][which]
             rec(evp.record, side)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
-                              res=(res[0], res[1], res[2], evp), chained_top=chained_top)
+                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain)
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
@@ -1011,7 +1011,7 @@ class TrainEngine:
         key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
-               bool(hit and pref.get("chained_top")),
+               bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
                self._gslot is not None,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
@@ -1035,6 +1035,8 @@ class TrainEngine:
             if self._next_res is not None:
                 cells["nws"] = C.c_void_p(self._next_res[0].data_ptr())
                 cells["nwsrc"] = C.c_void_p(self._next_res[1].data_ptr())
+            if self._gslot is not None:
+                cells["g0"], cells["g1"] = C.c_void_p(self._gslot[0].handle), C.c_void_p(self._gslot[1].handle)
             by_value = {c.value: c for c in cells.values()}
             if len(by_value) != len(cells):
                 return self.world == 1      # aliased inputs: stay on the untaped path
@@ -1047,7 +1049,7 @@ class TrainEngine:
                     prog.append((fn, args, False))
             post = self._pref
             native = None
-            if self.native_tape and self._gslot is None and _lib.native_tape_ok():
+            if self.native_tape and _lib.native_tape_ok():
                 # the same calls as a C-side tape: one library call per step instead of ~45 interpreted ones (0.22 ms of
                 # host time per step, more than the GPU needs at a per-rank batch of 1024)
                 try:
@@ -1055,7 +1057,8 @@ class TrainEngine:
                 except _lib.TapeUnsupported:
                     native = None
             self._tapes[key] = dict(prog=prog, cells=cells, phase=self._phase, native=native,
-                                    pref=None if post is None else (post["phase"], post["res"], post.get("chained_top", False)))
+                                    pref=None if post is None else (post["phase"], post["res"], post.get("chained_top", False),
+                                                                    post.get("prepared", False)))
             return self.world == 1
         cells = tape["cells"]
         cells["X"].value = X.data_ptr()
@@ -1069,6 +1072,8 @@ class TrainEngine:
         if "nws" in cells:
             cells["nws"].value = self._next_res[0].data_ptr()
             cells["nwsrc"].value = self._next_res[1].data_ptr()
+        if "g0" in cells:
+            cells["g0"].value, cells["g1"].value = self._gslot[0].handle, self._gslot[1].handle
         bufs = self._buffers(B)
         (bufs["wgrad_split"][0] if bufs["wgrad_split"] is not None else bufs["wgrad"]).set_x(0, X)
         if tape["native"] is not None:
@@ -1086,7 +1091,7 @@ class TrainEngine:
         self._pref = None
         if tape["pref"] is not None:
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1],
-                              chained_top=tape["pref"][2])
+                              chained_top=tape["pref"][2], prepared=tape["pref"][3])
         return self.world == 1
 
     def table_aggregate(self):

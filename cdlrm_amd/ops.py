@@ -132,6 +132,36 @@ def embbag_take(ctx: CacheCtx, idx: torch.Tensor, wslots: torch.Tensor, wsrc: to
                                        wslots.stride(0), slots_out.data_ptr(), int(aux_phase), stream_ptr(stream)))
 
 
+class TimingEvent:
+    """A HIP timing event of the library's own (its handle exists from creation on, so a launch tape can hold it)."""
+
+    def __init__(self):
+        h = _lib.raw().cdlrm_event_create(1)
+        if not h:
+            raise _lib.CdlrmError(-22, _lib.raw().cdlrm_last_error().decode("utf-8", "replace"))
+        self.handle = int(h)
+
+    def elapsed_us(self, stop: "TimingEvent") -> float:
+        """Microseconds from this event to `stop` (waits for `stop`)."""
+        us = C.c_float(0.0)
+        check(_lib.raw().cdlrm_event_elapsed_us(self.handle, stop.handle, C.byref(us)))
+        return float(us.value)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _lib.raw().cdlrm_event_destroy(h)
+            except Exception:
+                pass
+
+
+def time_next_gather(ctx: CacheCtx, start: TimingEvent, stop: TimingEvent):
+    """The next embbag_fwd on this context leaves its own start / stop timestamps in the two events (attached to the
+    launch: nothing is added to the queue)."""
+    check(_lib.lib().cdlrm_ctx_time_next_gather(ctx.handle, start.handle, stop.handle))
+
+
 def embbag_fwd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.Tensor], out: torch.Tensor,
                ld_bag: int, ld_table: int, n_bags: Optional[int] = None, stream=None):
     n = slots.shape[1]

@@ -425,6 +425,14 @@ int cdlrm_tape_selftest(void);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
 int cdlrm_event_record(void* event, void* stream);
 int cdlrm_stream_wait_event(void* stream, void* event);
+/* events of the library's own (handles exist from creation on); elapsed time in microseconds, waits for `stop` */
+void* cdlrm_event_create(int32_t timing);
+int cdlrm_event_destroy(void* event);
+int cdlrm_event_elapsed_us(void* start, void* stop, float* us);
+/* Measurement: the NEXT cdlrm_embbag_fwd on this context leaves its start / stop timestamps in the two (timing) events --
+ * attached to the launch itself (hipExtLaunchKernel), no marker packets around it -- so bench.py can price the gather
+ * (the roofline kernel) live, per launch, without moving it. */
+int cdlrm_ctx_time_next_gather(cdlrm_ctx* ctx, void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

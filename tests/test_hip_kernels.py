@@ -812,6 +812,36 @@ def test_head_vs_torch_fp32(ops, B, K, x_act):
     assert torch.equal(lb2[:3], lb[:3])
 
 
+def test_gather_launch_timing_events(ops):
+    """cdlrm_ctx_time_next_gather: the next gather leaves its own start / stop timestamps in the caller's events (attached
+    to the launch), once; the result of the gather is unchanged and agrees with events recorded around it."""
+    T, P, ways, D, n = 3, 64, 4, 128, 4096
+    ln = [5000, 300, 70000]
+    ctx = ops.CacheCtx(ln, [P] * T, D, ways, n, DEV)
+    tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+    weight = torch.randn(ctx.total_rows, D, device=DEV)
+    ctx.bind_cache(tags, weight)
+    g = torch.Generator().manual_seed(3)
+    slots = torch.stack([torch.randint(0, P * ways, (n,), generator=g) for _ in range(T)]).to(torch.int32).to(DEV)
+    out0 = torch.empty(n, T + 1, D, device=DEV)
+    out1 = torch.empty_like(out0)
+    ops.embbag_fwd(ctx, slots, None, out0[:, 1:, :], (T + 1) * D, D)
+    e0, e1 = ops.TimingEvent(), ops.TimingEvent()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ops.time_next_gather(ctx, e0, e1)
+    t0.record()
+    ops.embbag_fwd(ctx, slots, None, out1[:, 1:, :], (T + 1) * D, D)
+    t1.record()
+    torch.cuda.synchronize()
+    us, around = e0.elapsed_us(e1), t0.elapsed_time(t1) * 1e3
+    assert 0.5 < us <= around + 1.0, (us, around)
+    assert torch.equal(out0[:, 1:, :], out1[:, 1:, :])
+    ops.embbag_fwd(ctx, slots, None, out1[:, 1:, :], (T + 1) * D, D)        # not timed again: the events keep their stamps
+    torch.cuda.synchronize()
+    assert abs(e0.elapsed_us(e1) - us) < 1e-3
+
+
 def test_streamed_window_unique_equals_one_shot(ops):
     """cdlrm_window_unique_add x k + _finish (a window fed in chunks) gives the sorted unique lists of the one-shot
     scan over the concatenated window, and leaves the bitmap ready for the next window."""
