@@ -389,6 +389,14 @@ static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
         CDLRM_LAUNCH_CHECK();
         return 0;
     }
+    if (g.N <= 32 || g.M <= 32) {
+        // a 13-wide (or 1-wide) side that the DMA kernel cannot load: the LDS-free kernel's 32x32 tiles waste less of the
+        // MFMA than the 64x64 staged tile, whatever the number of slabs (the 512 x 13 weight gradient at M = 65536, 128
+        // slabs: 1100 us on the tiled kernel, c5's longest launch)
+        launch_gemm_direct<A_KC, B_KC>(g, splits, s);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
     int tm, tn;
     gemm_pick_tile(g.M, g.N, splits, &tm, &tn);
     if (g.N <= 32) tn = 1;

@@ -45,7 +45,7 @@ def main():
             int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]),
             short(r["Kernel_Name"])))
     # steady-state step time over the last anchors
-    d = [(rows[anchors[k + 1]]["s"] - rows[anchors[k]]["s"]) / 1e3 for k in range(len(anchors) - 60, len(anchors) - 1)]
+    d = [(rows[anchors[k + 1]]["s"] - rows[anchors[k]]["s"]) / 1e3 for k in range(max(0, len(anchors) - 60), len(anchors) - 1)]
     d.sort()
     print("median step (anchor to anchor) %.1f us" % d[len(d) // 2])
 
