@@ -105,6 +105,10 @@ PROTOTYPES = {
     "cdlrm_scatter_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, C.c_int, vp]),
     "cdlrm_blend_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_mark_rows": (C.c_int, [vp, vp, c_i64, vp, vp]),
+    "cdlrm_chain_sync_ints": (c_i64, []),
+    "cdlrm_chain_err_index": (c_i64, []),
+    "cdlrm_mlp_fwd_chain": (C.c_int, [c_i32, vp, c_i64, vp, vp, vp, vp, c_i64, vp, vp, vp, vp, vp]),
+    "cdlrm_mlp_dgrad_chain": (C.c_int, [c_i32, vp, c_i64, vp, vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp]),
     "cdlrm_tape_create": (vp, [c_i32]),
     "cdlrm_tape_destroy": (None, [vp]),
     "cdlrm_tape_add": (C.c_int, [vp, vp, c_i32, vp, vp, c_i32, vp]),

@@ -5,6 +5,7 @@
 // fp32 everywhere (1e-5 loss-trajectory parity): v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32
 // fma chain at the fp32 vector peak (MI355X_MICROARCH.md "Matrix cores").
 #include "gemm_glds.h"
+#include "chain.h"
 
 
 // Linear forward with a short contraction (K <= 32: the first bottom layer reads the 13 dense features).  An MFMA
@@ -79,6 +80,127 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
     g.vecA = aligned16(X) && ld_x % 4 == 0 && K % 4 == 0;
     g.vecB = aligned16(W) && K % 4 == 0;
     return launch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+// ---- layer chains (local batches <= 2048) ----------------------------------------------------------------------
+extern "C" int64_t cdlrm_chain_sync_ints(void) { return CHAIN_SYNC_INTS; }
+extern "C" int64_t cdlrm_chain_err_index(void) { return CHAIN_ERR; }
+
+static bool chain_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("CDLRM_MLP_CHAIN");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on != 0;
+}
+
+// Y[i] = act_i(Y[i-1] W[i]^T + b[i]), Y[-1] = X: n consecutive Linear layers (main_no_ddp.py / model_no_ddp.py:264-283, one
+// nn.Sequential) -- one launch when the chain applies (sync != NULL, M <= 2048, every layer on the staged kernel's shape
+// conditions), layer by layer through cdlrm_linear_fwd otherwise.  Same arithmetic per element either way.
+extern "C" int cdlrm_mlp_fwd_chain(int32_t n, const float* X, int64_t ld_x, const float* const* W, const float* const* bias,
+                                   float* const* Y, const int64_t* ld_y, int64_t M, const int32_t* N, const int32_t* K,
+                                   const int32_t* act, int32_t* sync, void* stream) {
+    CDLRM_REQUIRE(n >= 0 && (n == 0 || (X && W && bias && Y && ld_y && N && K && act)) && M >= 0, "bad argument");
+    if (n == 0 || M == 0) return 0;
+    ChainArgs c;
+    memset(&c, 0, sizeof(c));
+    bool ok = sync != nullptr && chain_enabled() && n <= CHAIN_MAX_OPS && n >= 2;
+    const float* in = X;
+    int64_t ld_in = ld_x;
+    for (int i = 0; i < n; ++i) {
+        CDLRM_REQUIRE(W[i] && Y[i] && N[i] >= 1 && K[i] >= 1 && ld_in >= K[i] && ld_y[i] >= N[i], "bad layer argument");
+        CDLRM_REQUIRE(i == 0 || K[i] == N[i - 1], "layer i reads layer i-1's output");
+        if (ok) {
+            GemmArgs g = gemm_args();
+            g.A = in; g.lda = ld_in; g.B = W[i]; g.ldb = K[i]; g.C = Y[i]; g.ldc = ld_y[i]; g.slab = 0;
+            g.M = M; g.N = N[i]; g.K = K[i]; g.kchunk = K[i]; g.bias = bias[i]; g.act = act[i];
+            g.vecA = aligned16(in) && ld_in % 4 == 0 && K[i] % 4 == 0;
+            g.vecB = aligned16(W[i]) && K[i] % 4 == 0;
+            g.vecC = aligned16(Y[i]) && ld_y[i] % 4 == 0;
+            ok = chain_layer_ok<true, true>(g);
+            c.g[i] = g;
+            c.ntn[i] = (int)cdiv(N[i], 32);
+            c.mode[i] = direct_mode(K[i], true);
+        }
+        in = Y[i];
+        ld_in = ld_y[i];
+    }
+    if (ok) {
+        c.n_ops = n;
+        c.rbs = (int)cdiv(M, 32);
+        c.sync = sync;
+        return launch_chain<true, true>(c, (hipStream_t)stream);
+    }
+    in = X;
+    ld_in = ld_x;
+    for (int i = 0; i < n; ++i) {
+        int rc = cdlrm_linear_fwd(in, ld_in, W[i], bias[i], Y[i], ld_y[i], M, N[i], K[i], act[i], stream);
+        if (rc) return rc;
+        in = Y[i];
+        ld_in = ld_y[i];
+    }
+    return 0;
+}
+
+// The input-gradient chain of n consecutive layers, top-most first: dX[i][M, K[i]] = dZ[i] W[i] (W[i] is [N[i], K[i]]),
+// times the derivative of the activation that produced the layer's input Xin[i] (x_act[i]; 0: none), and dZ[i+1] = dX[i]
+// (so N[i+1] == K[i]); dZ[0] = dY.  What cdlrm_linear_bwd(dW = NULL) does layer after layer, in one launch when the chain
+// applies.
+extern "C" int cdlrm_mlp_dgrad_chain(int32_t n, const float* dY, int64_t ld_dy, const float* const* W,
+                                     const float* const* Xin, const int64_t* ld_xin, const int32_t* x_act,
+                                     float* const* dX, const int64_t* ld_dx, int64_t M, const int32_t* N, const int32_t* K,
+                                     int32_t* sync, void* stream) {
+    CDLRM_REQUIRE(n >= 0 && (n == 0 || (dY && W && Xin && ld_xin && x_act && dX && ld_dx && N && K)) && M >= 0, "bad argument");
+    if (n == 0 || M == 0) return 0;
+    ChainArgs c;
+    memset(&c, 0, sizeof(c));
+    bool ok = sync != nullptr && chain_enabled() && n <= CHAIN_MAX_OPS && n >= 2;
+    const float* in = dY;
+    int64_t ld_in = ld_dy;
+    for (int i = 0; i < n; ++i) {
+        CDLRM_REQUIRE(W[i] && dX[i] && N[i] >= 1 && K[i] >= 1 && ld_in >= N[i] && ld_dx[i] >= K[i], "bad layer argument");
+        CDLRM_REQUIRE(x_act[i] >= 0 && x_act[i] <= 2 && (x_act[i] == 0 || (Xin[i] && ld_xin[i] >= K[i])), "bad activation / input");
+        CDLRM_REQUIRE(i == 0 || N[i] == K[i - 1], "layer i reads layer i-1's input gradient");
+        if (i < CHAIN_MAX_OPS) {
+            GemmArgs g = gemm_args();
+            g.A = in; g.lda = ld_in; g.B = W[i]; g.ldb = K[i]; g.C = dX[i]; g.ldc = ld_dx[i]; g.slab = 0;
+            g.M = M; g.N = K[i]; g.K = N[i]; g.kchunk = N[i]; g.bias = nullptr; g.act = 0;
+            g.vecA = aligned16(in) && ld_in % 4 == 0 && N[i] % 4 == 0;
+            g.vecB = aligned16(W[i]) && K[i] % 4 == 0;
+            g.vecC = aligned16(dX[i]) && ld_dx[i] % 4 == 0;
+            g.mask = x_act[i] ? Xin[i] : nullptr; g.ldmask = ld_xin[i]; g.mask_act = x_act[i];
+            if (ok) {
+                ok = chain_layer_ok<true, false>(g);
+                c.g[i] = g;
+                c.ntn[i] = (int)cdiv(K[i], 32);
+                c.mode[i] = direct_mode(N[i], true);
+            }
+        }
+        in = dX[i];
+        ld_in = ld_dx[i];
+    }
+    if (ok) {
+        c.n_ops = n;
+        c.rbs = (int)cdiv(M, 32);
+        c.sync = sync;
+        return launch_chain<true, false>(c, (hipStream_t)stream);
+    }
+    in = dY;
+    ld_in = ld_dy;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs g = gemm_args();
+        g.A = in; g.lda = ld_in; g.B = W[i]; g.ldb = K[i]; g.C = dX[i]; g.ldc = ld_dx[i]; g.slab = 0;
+        g.M = M; g.N = K[i]; g.K = N[i]; g.kchunk = N[i]; g.bias = nullptr; g.act = 0;
+        g.vecA = aligned16(in) && ld_in % 4 == 0 && N[i] % 4 == 0;
+        g.vecB = aligned16(W[i]) && K[i] % 4 == 0;
+        g.mask = x_act[i] ? Xin[i] : nullptr; g.ldmask = ld_xin[i]; g.mask_act = x_act[i];
+        int rc = launch_gemm<true, false>(g, 1, (hipStream_t)stream);
+        if (rc) return rc;
+        in = dX[i];
+        ld_in = ld_dx[i];
+    }
+    return 0;
 }
 
 // ---- backward helpers -----------------------------------------------------------------------------

@@ -477,6 +477,53 @@ def loss_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, 
                                         1 if sigmoid_bwd else 0, stream_ptr(stream)))
 
 
+class ChainPlan:
+    """Argument block of one layer chain (cdlrm_mlp_fwd_chain / cdlrm_mlp_dgrad_chain): pointer tables built once over
+    persistent buffers, plus the chain's own device sync words.  kind "fwd": layers = [(W, bias, Y, act)], x = the first
+    layer's input; kind "dgrad": layers = [(W, Xin or None, x_act, dX)] top-most first, x = dY of the first."""
+
+    def __init__(self, kind: str, x: torch.Tensor, layers, M: int, device, chained: bool = True):
+        assert kind in ("fwd", "dgrad") and len(layers) >= 1
+        self.kind, self.n, self.M = kind, len(layers), int(M)
+        n = self.n
+        P, I64, I32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+        self.x, self.ld_x = x.data_ptr(), x.stride(0)
+        self._keep = [x, layers]
+        if kind == "fwd":
+            self.W = P(*[l[0].data_ptr() for l in layers])
+            self.bias = P(*[ptr(l[1]) for l in layers])
+            self.Y = P(*[l[2].data_ptr() for l in layers])
+            self.ld_y = I64(*[l[2].stride(0) for l in layers])
+            self.N = I32(*[l[0].shape[0] for l in layers])
+            self.K = I32(*[l[0].shape[1] for l in layers])
+            self.act = I32(*[int(l[3]) for l in layers])
+        else:
+            self.W = P(*[l[0].data_ptr() for l in layers])
+            self.Xin = P(*[ptr(l[1]) for l in layers])
+            self.ld_xin = I64(*[(l[1].stride(0) if l[1] is not None else 0) for l in layers])
+            self.x_act = I32(*[int(l[2]) for l in layers])
+            self.dX = P(*[l[3].data_ptr() for l in layers])
+            self.ld_dx = I64(*[l[3].stride(0) for l in layers])
+            self.N = I32(*[l[0].shape[0] for l in layers])
+            self.K = I32(*[l[0].shape[1] for l in layers])
+        self.sync = torch.zeros(int(_lib.lib().cdlrm_chain_sync_ints()), dtype=torch.int32, device=device) if chained else None
+
+    def error(self) -> int:
+        """The chain's device error word (synchronises): 0, or 1 = a bounded wait gave up, 2 = an XCD had no workgroups."""
+        return 0 if self.sync is None else int(self.sync[int(_lib.lib().cdlrm_chain_err_index())].item())
+
+
+def mlp_chain(plan: ChainPlan, stream=None):
+    """Run the chain: one launch where it applies, layer by layer otherwise (decided inside the library)."""
+    L = _lib.lib()
+    if plan.kind == "fwd":
+        check(L.cdlrm_mlp_fwd_chain(plan.n, plan.x, plan.ld_x, plan.W, plan.bias, plan.Y, plan.ld_y, plan.M, plan.N, plan.K,
+                                    plan.act, ptr(plan.sync), stream_ptr(stream)))
+    else:
+        check(L.cdlrm_mlp_dgrad_chain(plan.n, plan.x, plan.ld_x, plan.W, plan.Xin, plan.ld_xin, plan.x_act, plan.dX,
+                                      plan.ld_dx, plan.M, plan.N, plan.K, ptr(plan.sync), stream_ptr(stream)))
+
+
 def head_scratch(device) -> torch.Tensor:
     return torch.zeros(int(_lib.lib().cdlrm_head_scratch_floats()), dtype=torch.float32, device=device)
 

@@ -404,6 +404,26 @@ int cdlrm_sgd_step2(float* param, const float* grad, int64_t off0, int64_t n0, i
 /* x /= divisor (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239, 244). */
 int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream);
 
+/* ---- layer chains: n consecutive Linear layers in ONE launch at local batches <= 2048 ---------------------------------
+ * (the per-rank shapes of a multi-GPU run: a layer is 3-4 us of MFMA work inside a launch that holds its queue for >= 5 us).
+ * A persistent kernel over (layer, 32-row block, 32-column tile) items; a row block moves on to the next layer when ITS
+ * tiles of the previous one are done, and stays on one XCD (row block % 8) through all layers, so the hand-off needs no
+ * L2 write-back (csrc/chain.h).  `sync`: cdlrm_chain_sync_ints() int32 on the device, zeroed once by the caller, one
+ * buffer per chain that may be in flight; sync[cdlrm_chain_err_index()] != 0 after a launch = a bounded wait gave up (1)
+ * or an XCD got no workgroups (2).  sync == NULL, M > 2048, n < 2 or a layer off the staged kernel's shape conditions:
+ * the layers are launched one by one (same results).
+ *   fwd:   Y[i] = act_i(Y[i-1] W[i]^T + b[i]), Y[-1] = X       (model_no_ddp.py:264-283, one nn.Sequential)
+ *   dgrad: dX[i] = dZ[i] W[i] * act'(Xin[i]) (x_act[i]; 0 none), dZ[i+1] = dX[i], dZ[0] = dY; layers top-most first,
+ *          W[i] is [N[i], K[i]]                                  (what cdlrm_linear_bwd(dW = NULL) does per layer) */
+int64_t cdlrm_chain_sync_ints(void);
+int64_t cdlrm_chain_err_index(void);
+int cdlrm_mlp_fwd_chain(int32_t n, const float* X, int64_t ld_x, const float* const* W, const float* const* bias,
+                        float* const* Y, const int64_t* ld_y, int64_t M, const int32_t* N, const int32_t* K,
+                        const int32_t* act, int32_t* sync, void* stream);
+int cdlrm_mlp_dgrad_chain(int32_t n, const float* dY, int64_t ld_dy, const float* const* W, const float* const* Xin,
+                          const int64_t* ld_xin, const int32_t* x_act, float* const* dX, const int64_t* ld_dx, int64_t M,
+                          const int32_t* N, const int32_t* K, int32_t* sync, void* stream);
+
 /* ---- launch tapes -------------------------------------------------------------------------------------------------
  * A training step's call sequence (this library's entry points + event records / stream waits), recorded once per control
  * path by the host and re-issued by ONE call per step (the reference issues the same ops from Python every iteration,

@@ -812,6 +812,60 @@ def test_head_vs_torch_fp32(ops, B, K, x_act):
     assert torch.equal(lb2[:3], lb[:3])
 
 
+@pytest.mark.parametrize("M", [1024, 1000, 2048, 96, 33])
+def test_mlp_layer_chains_equal_per_layer_launches(ops, M):
+    """cdlrm_mlp_fwd_chain / cdlrm_mlp_dgrad_chain (one persistent launch, row blocks pinned to an XCD, per-row-block
+    dependency counters) against the same layers launched one by one: bit-identical outputs (same tile arithmetic), on the
+    top MLP's shapes and a ragged last row block; repeated launches reuse the sync words; the error word stays 0."""
+    g = torch.Generator().manual_seed(M)
+    dims = [480, 512, 512, 256]
+    X = (torch.randn(M, dims[0], generator=g) * 0.5).to(DEV)
+    Ws = [(torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i])).to(DEV) for i in range(3)]
+    bs = [torch.randn(dims[i + 1], generator=g).to(DEV) for i in range(3)]
+    Yc = [torch.empty(M, dims[i + 1], device=DEV) for i in range(3)]
+    Yl = [torch.empty(M, dims[i + 1], device=DEV) for i in range(3)]
+    plan = ops.ChainPlan("fwd", X, [(Ws[i], bs[i], Yc[i], 1) for i in range(3)], M, DEV)
+    for rep in range(3):
+        for y in Yc:
+            y.fill_(float("nan"))
+        ops.mlp_chain(plan)
+    cur = X
+    for i in range(3):
+        ops.linear_fwd(cur, Ws[i], bs[i], Yl[i], 1)
+        cur = Yl[i]
+    torch.cuda.synchronize()
+    assert plan.error() == 0
+    for i in range(3):
+        assert torch.equal(Yc[i], Yl[i]), i
+    ref = X.double()
+    for i in range(3):
+        ref = torch.relu(ref @ Ws[i].double().t() + bs[i].double())
+    np.testing.assert_allclose(Yc[2].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    # input-gradient chain, top-most layer first: dZ3 [M, 256] -> dX3 [M, 512] -> dX2 [M, 512] -> dX1 [M, 480]
+    dY = torch.randn(M, dims[3], generator=g).to(DEV)
+    ins = [X, Yl[0], Yl[1]]                      # input of layer i (ReLU outputs for i >= 1)
+    dXc = [torch.empty(M, dims[i], device=DEV) for i in range(3)]
+    dXl = [torch.empty(M, dims[i], device=DEV) for i in range(3)]
+    layers = [(Ws[i], ins[i] if i > 0 else None, 1 if i > 0 else 0, dXc[i]) for i in (2, 1, 0)]
+    dplan = ops.ChainPlan("dgrad", dY, layers, M, DEV)
+    for rep in range(2):
+        ops.mlp_chain(dplan)
+    cur = dY.clone()
+    for i in (2, 1, 0):
+        work = ops.linear_bwd_work(M, dims[i + 1], dims[i], DEV)
+        ops.linear_bwd(ins[i], Ws[i], None, cur, dXl[i], None, None, 0, work, x_act=1 if i > 0 else 0)
+        cur = dXl[i]
+    torch.cuda.synchronize()
+    assert dplan.error() == 0
+    for i in range(3):
+        assert torch.equal(dXc[i], dXl[i]), i
+    # sync == None (chained=False) and a single layer take the per-layer path inside the library
+    plan1 = ops.ChainPlan("fwd", X, [(Ws[0], bs[0], Yc[0], 1)], M, DEV)
+    Yc[0].fill_(0.0)
+    ops.mlp_chain(plan1)
+    assert torch.equal(Yc[0], Yl[0])
+
+
 def test_gather_launch_timing_events(ops):
     """cdlrm_ctx_time_next_gather: the next gather leaves its own start / stop timestamps in the caller's events (attached
     to the launch), once; the result of the gather is unchanged and agrees with events recorded around it."""
