@@ -289,7 +289,12 @@ __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup grp) {
 static int wgrad_splits(int64_t M, int N, int K) {
     if (M <= WGRAD_DIRECT_MAX_M) return 1;
     const int64_t tiles = cdiv(N, 64) * cdiv(K, 64);    // the 64x64 tile launch_gemm picks for these shapes
-    int64_t s = cdiv(1024, tiles);                    // aim at ~4 workgroups per CU
+    static int64_t target = 0;
+    if (target == 0) {
+        const char* e = getenv("CDLRM_WGRAD_TARGET");
+        target = e && atol(e) > 0 ? atol(e) : 1024;
+    }
+    int64_t s = cdiv(target, tiles);                  // aim at ~4 workgroups of 64x64 per CU (2 of 128x64)
     const int64_t smax = cdiv(M, 8 * GBK);
     if (s > smax) s = smax;
     if (s < 1) s = 1;
