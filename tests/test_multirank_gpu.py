@@ -14,18 +14,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, host_shared, ret, defer=False, chunk=0):
+def _worker(rank, world, port, name, host_shared, ret, defer=False, chunk=0, long_batch=False):
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)        # a stuck worker says where, instead of a silent time-out
     try:
-        _worker_body(rank, world, port, name, host_shared, ret, defer, chunk)
+        _worker_body(rank, world, port, name, host_shared, ret, defer, chunk, long_batch)
     except BaseException as e:      # a dead worker must fail the test, not hang it
         import traceback
         ret.put((rank, {"error": traceback.format_exc()}))
         raise
 
 
-def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0):
+def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0, long_batch=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -55,6 +55,8 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0
     pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
     if chunk:       # the touched-row merge in chunks of `chunk` rows: gather i+1 / reduce i / scatter i-1 pipelined
         eng.agg_chunk_rows = chunk
+    if long_batch:  # the long-batch schedule (gather alone on the main stream, chained take on the window-resident probe)
+        eng.gather_alone_min = 1
     lbs = B // world
     losses = []
     dev_idx = {}
@@ -66,6 +68,8 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0
             pipe.plan_window(torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(dev))
             pipe.commit()
             pipe.wait_writeback()
+            rs = engine.WindowResolver(eng, torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(dev), B, chunk=2) \
+                if long_batch else None
         sl = slice(rank * lbs, (rank + 1) * lbs)
         if j not in dev_idx:
             dev_idx[j] = lS_i[:, sl].contiguous().to(dev)
@@ -73,7 +77,12 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0
         if j + 1 < len(batches) and (j + 1) % L != 0:       # same window: pipeline the next batch's probe / aux fill
             dev_idx[j + 1] = batches[j + 1][1][:, sl].contiguous().to(dev)
             nxt = dev_idx[j + 1]
-        loss = eng.step(X[sl].to(dev), dev_idx[j], Tt[sl].to(dev), j=j, next_idx=nxt)
+        loss = eng.step(X[sl].to(dev), dev_idx[j], Tt[sl].to(dev), j=j, next_idx=nxt,
+                        res=rs.batch(j % L) if rs is not None else None,
+                        next_res=rs.batch(j % L + 1) if (rs is not None and nxt is not None) else None)
+        if rs is not None:
+            rs.ensure(j % L + rs.CH + 2)
+            assert nxt is None or eng._pref is not None       # the chained take was issued
         losses.append(float(loss[0]))
     eng.finish()
     cg.ctx.check()
@@ -84,17 +93,20 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,port,defer,chunk", [("train_w2_mean", 29821, False, 0), ("train_w2_max", 29822, False, 0),
-                                                   ("train_w2_mean", 29823, True, 0), ("train_w2_freq1", 29824, True, 16),
-                                                   ("train_w2_max", 29825, False, 8), ("train_w2_sum", 29826, True, 0)])
-def test_two_ranks_one_gpu_match_reference(golden, name, port, defer, chunk):
+@pytest.mark.parametrize("name,port,defer,chunk,long_batch", [
+    ("train_w2_mean", 29821, False, 0, False), ("train_w2_max", 29822, False, 0, False),
+    ("train_w2_mean", 29823, True, 0, False), ("train_w2_freq1", 29824, True, 16, False),
+    ("train_w2_max", 29825, False, 8, False), ("train_w2_sum", 29826, True, 0, False),
+    # the long-batch schedule on two ranks: chained take + window-resident probe, a row merge every step / every other
+    ("train_w2_freq1", 29827, True, 0, True), ("train_w2_mean", 29828, False, 0, True)])
+def test_two_ranks_one_gpu_match_reference(golden, name, port, defer, chunk, long_batch):
     from oracle import cdlrm_oracle as O
     g = golden(name)
     np.random.seed(int(g["seed"]))
     host = [h.share_memory_() for h in O.init_host_tables([int(x) for x in g["ln_emb"]], int(g["m_spa"]))]
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret, defer, chunk)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, host, ret, defer, chunk, long_batch)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
