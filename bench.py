@@ -246,6 +246,7 @@ def main():
     from cdlrm_amd import ops as _ops
     ev_pool = {j: (_ops.TimingEvent(), _ops.TimingEvent())
                for j in range(a.warmup, total_steps) if a.gather_sample > 0 and j % sample_every == 0}
+    warm_pair = (_ops.TimingEvent(), _ops.TimingEvent())
 
     def begin_window(w, timed):
         if state["next"] is None:           # very first window: plan it synchronously
@@ -304,7 +305,10 @@ def main():
         if timed and world > 1 and jj > 0 and jj % cfg["agg"] == 0:
             refills["merges"] += 1
         rs = state.get("res")
-        eng.step(X, idx, T, j=jj, gather_events=ev_pool[j] if sample else None, next_idx=nxt,
+        # (warm-up steps time their gather into a scratch pair: the launch tapes the timed steps replay -- a timed launch is
+        #  another control path than an untimed one -- are then recorded before the timed region starts)
+        gev = ev_pool[j] if sample else (warm_pair if (not timed and a.gather_sample > 0 and sample_every == 1) else None)
+        eng.step(X, idx, T, j=jj, gather_events=gev, next_idx=nxt,
                  res=rs.batch(jloc) if rs is not None else None,
                  next_res=rs.batch(jloc + 1) if (rs is not None and nxt is not None) else None)
         if rs is not None:

@@ -85,6 +85,54 @@ def main():
         print("  prepare (slot sort) %7.1f us | apply (sums + row update) %7.1f us = %.1f GB/s = %.1f%% of 8 TB/s" % (
             us_p, us_a, look * (12 * D + 8) / us_a / 1e3, look * (12 * D + 8) / us_a / 1e3 / 80))
 
+    if want("gather_beside"):
+        # how much does the gather (the roofline kernel) lose when it runs beside MFMA-bound GEMMs on another stream?
+        ln_emb = synth.TERABYTE_COUNTS
+        T = len(ln_emb)
+        P = 150001
+        cs = [min(n, P) for n in ln_emb]
+        ctx = ops.CacheCtx(ln_emb, cs, D, 16, B, DEV)
+        tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+        weight = torch.randn(ctx.total_rows, D, device=DEV)
+        ctx.bind_cache(tags, weight)
+        syn = synth.CriteoSynth(ln_emb, 13, B, alpha=a.alpha, device=DEV)
+        idx = syn.window(0, 1)
+        slots = torch.stack([(idx[k] % (cs[k] * 16)).to(torch.int32) for k in range(T)]).contiguous()
+        feat = torch.empty(B, T + 1, D, device=DEV)
+        X = torch.randn(B, 512, device=DEV)
+        W = torch.randn(512, 512, device=DEV) / 22.0
+        b = torch.randn(512, device=DEV)
+        Y = torch.empty(B, 512, device=DEV)
+        dW, db = torch.empty(512, 512, device=DEV), torch.empty(512, device=DEV)
+        work = ops.linear_bwd_work(B, 512, 512, DEV)
+        for prio in (0, -1):
+            gs = torch.cuda.Stream(priority=prio)
+            for mode in ("alone", "beside forward GEMMs", "beside weight-gradient GEMMs"):
+                us = []
+                for rep in range(12):
+                    e0, e1 = ops.TimingEvent(), ops.TimingEvent()
+                    torch.cuda.synchronize()
+                    if mode != "alone":
+                        for _ in range(6):
+                            if mode.startswith("beside forward"):
+                                ops.linear_fwd(X, W, b, Y, 1)
+                            else:
+                                ops.linear_bwd(X, W, None, Y, None, dW, db, 0, work)
+                    gs.wait_stream(torch.cuda.current_stream())
+                    if mode != "alone":
+                        # the GEMM stream keeps going: more GEMMs queued behind the fork
+                        for _ in range(6):
+                            if mode.startswith("beside forward"):
+                                ops.linear_fwd(X, W, b, Y, 1)
+                            else:
+                                ops.linear_bwd(X, W, None, Y, None, dW, db, 0, work)
+                    ops.time_next_gather(ctx, e0, e1)
+                    ops.embbag_fwd(ctx, slots, None, feat[:, 1:, :], (T + 1) * D, D, stream=gs)
+                    torch.cuda.synchronize()
+                    if rep >= 2:
+                        us.append(e0.elapsed_us(e1))
+                print("gather stream priority %2d, %-30s: %6.1f us (min %.1f max %.1f)" % (prio, mode, np.mean(us), min(us), max(us)))
+
     if want("interact"):
         F = 27
         feat = torch.randn(B, F, D, device=DEV)
