@@ -38,9 +38,14 @@ CONFIGS = {
     "c2": dict(name="criteo-kaggle-shape synthetic, 26 tables, D=32, B=2048, L=200, cache 50k x 8-way",
                tables="kaggle", D=32, bot=[13, 512, 256, 32], top=[512, 256, 1], B=2048, L=200, cache=50000, ways=8,
                agg=100, lr=0.1, lr_emb=0.3),
-    # BASELINE.json configs[3] (embed-dim 256) is NOT a bench configuration: its host tables are 192 GB of pinned memory
-    # (the one full-size attempt ended with the box lost before the first step; not repeated) and BASELINE.json lists it as a
-    # parity case: tests/test_engine_parity.py::test_embed_dim_256_engine_vs_oracle covers the 256-wide path.
+    # BASELINE.json configs[3] (embed-dim 256) at full size is NOT a bench configuration: its host tables are 192 GB of pinned
+    # memory (the one full-size attempt ended with the box lost before the first step; not repeated) and BASELINE.json lists
+    # it as a parity case: tests/test_engine_parity.py::test_embed_dim_256_engine_vs_oracle covers the 256-wide path.  "c4" is
+    # the same step shape for timing the 256-wide kernels; run it with --max-ind-range 2000000 (tables capped at 2 M rows:
+    # 29 GB of host tables) -- the QR trick itself is a stand-alone operator in the reference and here.
+    "c4": dict(name="criteo-terabyte-shape synthetic, 26 tables, D=256, B=8192, L=3000, cache 150k x 16-way, agg 100",
+               tables="terabyte", D=256, bot=[13, 512, 256, 256], top=[512, 512, 256, 1], B=8192, L=3000,
+               cache=150000, ways=16, agg=100, lr=0.8, lr_emb=0.8),
     # BASELINE.json configs[4]
     "c5": dict(name="criteo-terabyte-shape synthetic large batch, D=128, B=65536, L=8000, cache 500k x 16-way",
                tables="terabyte", D=128, bot=[13, 512, 256, 128], top=[512, 512, 256, 1], B=65536, L=8000,
