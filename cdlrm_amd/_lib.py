@@ -92,6 +92,7 @@ PROTOTYPES = {
                                    c_i32, c_i32, vp, vp]),
     "cdlrm_mlp_wgrad_work_bytes": (c_u64, [c_i32, c_i64, vp, vp]),
     "cdlrm_mlp_wgrad": (C.c_int, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp]),
+    "cdlrm_mlp_wgrad_sgd": (C.c_int, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_f32, c_i64, vp, vp, vp, vp]),
     "cdlrm_bce_fwd_bwd": (C.c_int, [vp, vp, c_i64, vp, vp, c_i32, vp]),
     "cdlrm_loss_fwd_bwd": (C.c_int, [vp, vp, c_i64, c_i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, c_i32, vp]),
     "cdlrm_head_scratch_floats": (c_i64, []),

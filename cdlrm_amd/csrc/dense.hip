@@ -223,10 +223,13 @@ __global__ void __launch_bounds__(256) k_act_grad(const float* __restrict__ Y, i
 
 // Two reductions in one job (dW slabs and the bias-gradient partials of the same layer): logical blocks [0, gxa) work
 // on part A, the rest on part B.  Fixed summation order (slab 0, 1, 2, ...): reproducible; 4 slabs in flight.
+// (pA / pB: the parameters the gradients belong to, updated in the same pass -- p -= lr * g, the dense SGD step -- when the
+//  caller has no exchange between the two: cdlrm_mlp_wgrad_sgd; NULL: gradients only)
 __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restrict__ partA, int64_t countA, int splitsA,
                                                   float* __restrict__ outA, int gxa, const float* __restrict__ partB,
                                                   int64_t countB, int splitsB, float* __restrict__ outB,
-                                                  float (*red)[64]) {
+                                                  float (*red)[64], float* __restrict__ pA = nullptr,
+                                                  float* __restrict__ pB = nullptr, float lr = 0.f) {
     if (bid >= gxa) {
         // part B (bias gradient): few elements, many partials -> 4 lanes per element, each summing every 4th
         // partial, combined in a fixed order through LDS
@@ -237,7 +240,11 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
             for (int z = sub; z < splitsB; z += 4) s += partB[(int64_t)z * countB + e];
         red[sub][c] = s;
         __syncthreads();
-        if (sub == 0 && e < countB) outB[e] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        if (sub == 0 && e < countB) {
+            const float g = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+            outB[e] = g;
+            if (pB) pB[e] = fmaf(-lr, g, pB[e]);
+        }
         return;
     }
     for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < countA; e += (int64_t)gxa * blockDim.x) {
@@ -250,6 +257,7 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
         }
         for (; z < splitsA; ++z) s += partA[(int64_t)z * countA + e];
         outA[e] = s;
+        if (pA) pA[e] = fmaf(-lr, s, pA[e]);
     }
 }
 
@@ -266,6 +274,7 @@ struct ReduceJob {
     const float* partA; int64_t countA; float* outA; int gxa;
     const float* partB; int64_t countB; float* outB;
     int splits;
+    float* pA; float* pB; float lr;         // fused SGD step (NULL: none)
 };
 struct ReduceGroup {
     int n;
@@ -280,7 +289,7 @@ __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup grp) {
         if (q < grp.n && blockIdx.x >= grp.first[q]) p = q;
     const ReduceJob& r = grp.j[p];
     reduce_slabs_body((int)(blockIdx.x - grp.first[p]), r.partA, r.countA, r.splits, r.outA, r.gxa, r.partB, r.countB,
-                      r.splits, r.outB, red);
+                      r.splits, r.outB, red, r.pA, r.pB, r.lr);
 }
 
 // Weight-gradient contraction (over the batch) is cut into slabs when the batch is long: small batches go to the
@@ -380,12 +389,31 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
 // left behind (cdlrm_linear_bwd with dW = NULL): dW[i] = dZ[i]^T X[i], db[i] = column sums of dZ[i].
 // Small batches: all layers in one grouped launch of the LDS-free kernel (no slabs, no reduction); long batches: the
 // tiled split-M path, layer after layer.
-extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
-                               const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
-                               const int32_t* K, void* work, void* stream) {
+__global__ void __launch_bounds__(256) k_sgd(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr);
+
+// P_w / P_b (both or neither): the layers' parameters, stepped by -lr * gradient in the reduction pass (layers whose
+// gradient needs no reduction: one elementwise launch behind it)
+static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
+                          const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
+                          const int32_t* K, void* work, void* stream, float* const* P_w, float* const* P_b, float lr) {
     CDLRM_REQUIRE(n_layers >= 0 && (n_layers == 0 || (X && ld_x && dZ && ld_dz && dW && db && N && K)) && M >= 1,
                   "bad argument");
     hipStream_t s = (hipStream_t)stream;
+    std::vector<char> stepped((size_t)(n_layers > 0 ? n_layers : 0), 0);
+    auto step_rest = [&]() -> int {             // layers the reduction did not cover
+        if (!P_w) return 0;
+        for (int i = 0; i < n_layers; ++i) {
+            if (stepped[i]) continue;
+            const int64_t cnt = (int64_t)N[i] * K[i];
+            int64_t gx = cdiv(cnt, 256);
+            if (gx > 2048) gx = 2048;
+            hipLaunchKernelGGL(k_sgd, dim3((unsigned)gx), dim3(256), 0, s, P_w[i], (const float*)dW[i], cnt, lr);
+            if (db[i] && P_b && P_b[i])
+                hipLaunchKernelGGL(k_sgd, dim3((unsigned)cdiv(N[i], 256)), dim3(256), 0, s, P_b[i], (const float*)db[i], (int64_t)N[i], lr);
+        }
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    };
     if (M <= WGRAD_DIRECT_MAX_M) {
         // Small batches, all layers at once.  Layers whose operands are 16-byte loadable go through the LDS-tiled
         // kernel as ONE grouped launch, the contraction (the batch) cut into slabs so that the group has ~1000
@@ -453,6 +481,8 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
             r.gxa = (int)gxa;
             r.partB = cs; r.countB = db[li] ? N[li] : 0; r.outB = db[li];
             r.splits = zs;
+            r.pA = P_w ? P_w[li] : nullptr; r.pB = (P_w && P_b && db[li]) ? P_b[li] : nullptr; r.lr = lr;
+            if (P_w) stepped[li] = 1;
             jobs.push_back(r);
         };
         for (size_t q = 0; q < direct.size(); ++q) slabbed(direct[q], direct_layer[q]);
@@ -488,7 +518,7 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
             hipLaunchKernelGGL(k_reduce_group, dim3(rblocks), dim3(256), 0, s, red);
         }
         CDLRM_LAUNCH_CHECK();
-        return 0;
+        return step_rest();
     }
     // Long batches: per layer one split-M GEMM of the tiled (or, for degenerate shapes, the LDS-free) kernel into the
     // layer's own slabs, then ONE grouped reduction of all layers' slabs and bias partials.
@@ -523,6 +553,8 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
             r.gxa = (int)gxa;
             r.partB = cs; r.countB = db[i] ? N[i] : 0; r.outB = db[i];
             r.splits = zs;
+            r.pA = P_w ? P_w[i] : nullptr; r.pB = (P_w && P_b && db[i]) ? P_b[i] : nullptr; r.lr = lr;
+            if (P_w) stepped[i] = 1;
             jobs.push_back(r);
         }
         int rc = launch_gemm<false, false>(g, zs, s);
@@ -542,7 +574,24 @@ extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const in
         hipLaunchKernelGGL(k_reduce_group, dim3(rblocks), dim3(256), 0, s, red);
     }
     CDLRM_LAUNCH_CHECK();
-    return 0;
+    return step_rest();
+}
+
+extern "C" int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
+                               const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
+                               const int32_t* K, void* work, void* stream) {
+    return mlp_wgrad_impl(n_layers, X, ld_x, dZ, ld_dz, dW, db, M, N, K, work, stream, nullptr, nullptr, 0.f);
+}
+
+// cdlrm_mlp_wgrad followed by the dense SGD step of the same layers (W[i] -= lr * dW[i], b[i] -= lr * db[i]:
+// optimizer_mlps.step(), main_no_ddp.py:415) in the same launches -- for callers with nothing between the two (one rank: no
+// gradient exchange).  Same arithmetic as cdlrm_mlp_wgrad + cdlrm_sgd_step.
+extern "C" int cdlrm_mlp_wgrad_sgd(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
+                                   const int64_t* ld_dz, float* const* dW, float* const* db, float* const* W,
+                                   float* const* b, float lr, int64_t M, const int32_t* N, const int32_t* K, void* work,
+                                   void* stream) {
+    CDLRM_REQUIRE(n_layers == 0 || (W && b), "parameters missing");
+    return mlp_wgrad_impl(n_layers, X, ld_x, dZ, ld_dz, dW, db, M, N, K, work, stream, W, b, lr);
 }
 
 // =================================================================================================

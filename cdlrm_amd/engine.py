@@ -436,6 +436,7 @@ class TrainEngine:
         self.chain_take = os.environ.get("CDLRM_CHAIN_TAKE", "1") != "0"
         self.native_tape = os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0"
         self.wgrad_late = os.environ.get("CDLRM_WGRAD_LATE", "0") == "1"
+        self.fuse_sgd = os.environ.get("CDLRM_FUSE_SGD", "1") != "0"
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -553,6 +554,10 @@ class TrainEngine:
             wk = lambda ls: ops.mlp_wgrad_work(B, [l.out_features for l in ls], [self.W[l].shape[1] for l in ls], dev)
             b["wgrad_split"] = (ops.WgradPlan(xs[:nb], dzs[:nb], gw[:nb], gb[:nb], wk(layers[:nb])),
                                 ops.WgradPlan(xs[nb:], dzs[nb:], gw[nb:], gb[nb:], wk(layers[nb:])))
+            # one rank: nothing sits between a sub-network's weight gradients and its SGD step, so the step rides in the
+            # gradients' reduction pass (cdlrm_mlp_wgrad_sgd) -- one launch less per sub-network and step
+            b["wgrad_split"][0].set_params([self.W[l] for l in layers[:nb]], [l.bias.data for l in layers[:nb]])
+            b["wgrad_split"][1].set_params([self.W[l] for l in layers[nb:]], [l.bias.data for l in layers[nb:]])
         self._bufs[B] = b
         return b
 
@@ -867,11 +872,13 @@ class TrainEngine:
             # backward.  (Launching each layer's weight gradient as soon as ITS dZ exists -- beside the dgrad chain itself
             # -- measured slower: 0.810 vs 0.782 ms at B=8192; the chain is the critical path and loses CUs to them.)
             rec(wst.wait_event, after)
-            ops.mlp_wgrad(split[1], stream=wst)
+            fused = self.defer_top and self.world == 1 and self.fuse_sgd
+            ops.mlp_wgrad(split[1], stream=wst, lr=self.lr if fused else None)
             if not self.defer_top:
                 rec(ev["wgrad_done"].record, wst)
             elif self.world == 1:
-                ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
+                if not fused:
+                    ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
                 rec(ev["top_updated"].record, wst)
 
         # CDLRM_WGRAD_LATE=1: one event on the main queue for both side streams (recorded behind the interaction backward)
@@ -927,11 +934,13 @@ class TrainEngine:
         sgd_included = False
         if split is not None:
             split[0].set_x(0, X)
-            ops.mlp_wgrad(split[0])
+            fused = self.defer_top and self.world == 1 and self.fuse_sgd
+            ops.mlp_wgrad(split[0], lr=self.lr if fused else None)
             if not self.defer_top:
                 rec(main.wait_event, ev["wgrad_done"])
             elif self.world == 1:
-                ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
+                if not fused:
+                    ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
                 sgd_included = True
         else:
             plan = buf["wgrad"]

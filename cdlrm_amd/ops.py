@@ -451,11 +451,29 @@ class WgradPlan:
         self.ld_x[i] = x.stride(0)
         self._keep[0][i] = x
 
+    def set_params(self, Ws, bs):
+        """The layers' parameters (W[i] [N, K] contiguous, b[i] [N] or None), for mlp_wgrad(..., lr=): the SGD step then
+        happens in the weight-gradient launches."""
+        import ctypes as C
+        assert len(Ws) == self.n and len(bs) == self.n
+        for i, w in enumerate(Ws):
+            assert w.is_contiguous() and tuple(w.shape) == (int(self.N[i]), int(self.K[i]))
+        PA = C.c_void_p * self.n
+        self.P_w = PA(*[w.data_ptr() for w in Ws])
+        self.P_b = PA(*[ptr(b) for b in bs])
+        self._params = (list(Ws), list(bs))
 
-def mlp_wgrad(plan: WgradPlan, stream=None):
-    """dW[i] = dZ[i]^T X[i], db[i] = column sums of dZ[i] for every layer of the plan (one grouped launch at small M)."""
-    check(_lib.lib().cdlrm_mlp_wgrad(plan.n, plan.X, plan.ld_x, plan.dZ, plan.ld_dz, plan.dW, plan.db, plan.M, plan.N,
-                                     plan.K, plan.work.data_ptr(), stream_ptr(stream)))
+
+def mlp_wgrad(plan: WgradPlan, stream=None, lr: Optional[float] = None):
+    """dW[i] = dZ[i]^T X[i], db[i] = column sums of dZ[i] for every layer of the plan (one grouped launch at small M).
+    lr given (and plan.set_params called): W[i] -= lr * dW[i], b[i] -= lr * db[i] in the same launches."""
+    if lr is None:
+        check(_lib.lib().cdlrm_mlp_wgrad(plan.n, plan.X, plan.ld_x, plan.dZ, plan.ld_dz, plan.dW, plan.db, plan.M, plan.N,
+                                         plan.K, plan.work.data_ptr(), stream_ptr(stream)))
+    else:
+        check(_lib.lib().cdlrm_mlp_wgrad_sgd(plan.n, plan.X, plan.ld_x, plan.dZ, plan.ld_dz, plan.dW, plan.db, plan.P_w,
+                                             plan.P_b, float(lr), plan.M, plan.N, plan.K, plan.work.data_ptr(),
+                                             stream_ptr(stream)))
 
 
 def bce_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, dZ: Optional[torch.Tensor], stream=None,

@@ -353,6 +353,14 @@ uint64_t cdlrm_mlp_wgrad_work_bytes(int32_t n_layers, int64_t M, const int32_t* 
 int cdlrm_mlp_wgrad(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
                     const int64_t* ld_dz, float* const* dW, float* const* db, int64_t M, const int32_t* N,
                     const int32_t* K, void* work, void* stream);
+/* cdlrm_mlp_wgrad followed by the dense SGD step of the same layers -- W[i] -= lr * dW[i], b[i] -= lr * db[i]
+ * (optimizer_mlps.step(), main_no_ddp.py:415) -- inside the same launches (the slab reduction writes the gradient and steps
+ * the parameter): for callers with nothing between the two, i.e. one rank (no gradient exchange, :412-414).  W[i] [N[i], K[i]]
+ * and b[i] [N[i]] (b[i] may be NULL where db[i] is); gradients are still left in dW / db.  Same arithmetic as
+ * cdlrm_mlp_wgrad + cdlrm_sgd_step. */
+int cdlrm_mlp_wgrad_sgd(int32_t n_layers, const float* const* X, const int64_t* ld_x, const float* const* dZ,
+                        const int64_t* ld_dz, float* const* dW, float* const* db, float* const* W, float* const* b,
+                        float lr, int64_t M, const int32_t* N, const int32_t* K, void* work, void* stream);
 
 /* BCELoss(mean) forward + backward on the sigmoid output (torch clamps log at -100):
  * loss_out device fp32 [65]: [0] = loss, [1..64] = partial sums (fixed-order, reproducible);

@@ -240,14 +240,21 @@ class WgradPlan:
     def set_x(self, i, x):
         self.Xs[i] = x
 
+    def set_params(self, Ws, bs):
+        self.Ws, self.bs = list(Ws), list(bs)
 
-def mlp_wgrad(plan, stream=None):
-    for x, dz, dw, db in zip(plan.Xs, plan.dZs, plan.dWs, plan.dbs):
+
+def mlp_wgrad(plan, stream=None, lr=None):
+    for i, (x, dz, dw, db) in enumerate(zip(plan.Xs, plan.dZs, plan.dWs, plan.dbs)):
         dw[:, :x.shape[1]].copy_(dz.t() @ x)
         if dw.shape[1] > x.shape[1]:
             dw[:, x.shape[1]:].zero_()
         if db is not None:
             db.copy_(dz.sum(0))
+        if lr is not None:
+            plan.Ws[i].add_(dw, alpha=-lr)
+            if db is not None and plan.bs[i] is not None:
+                plan.bs[i].add_(db, alpha=-lr)
 
 
 def bce_fwd_bwd(Z, target, loss_buf, dZ, stream=None, sigmoid_bwd=False):

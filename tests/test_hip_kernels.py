@@ -573,6 +573,39 @@ def test_mlp_wgrad_group(ops, M):
                                        atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 8192])
+def test_mlp_wgrad_with_fused_sgd_step(ops, M):
+    """cdlrm_mlp_wgrad_sgd: the dense SGD step inside the weight-gradient launches (slab reduction; elementwise pass for
+    layers without slabs) = cdlrm_mlp_wgrad followed by p -= lr * g, bit for bit, gradients still left in dW / db."""
+    rng = np.random.RandomState(M + 1)
+    shapes = [(512, 13), (256, 512), (128, 256), (512, 480), (1, 256), (70, 33)]
+    lr = 0.37
+    Xs, dZs, dWs, dbs, Ws, bs = [], [], [], [], [], []
+    for n, (N, K) in enumerate(shapes):
+        Xs.append(torch.from_numpy(rng.randn(M, K).astype(np.float32)).to(DEV))
+        dZs.append(torch.from_numpy(rng.randn(M, N).astype(np.float32)).to(DEV))
+        dWs.append(torch.empty(N, K, device=DEV))
+        dbs.append(None if n == 2 else torch.empty(N, device=DEV))
+        Ws.append(torch.from_numpy(rng.randn(N, K).astype(np.float32)).to(DEV))
+        bs.append(None if n == 2 else torch.from_numpy(rng.randn(N).astype(np.float32)).to(DEV))
+    W0, b0 = [w.clone() for w in Ws], [None if b is None else b.clone() for b in bs]
+    work = ops.mlp_wgrad_work(M, [s[0] for s in shapes], [s[1] for s in shapes], DEV)
+    plan = ops.WgradPlan(Xs, dZs, dWs, dbs, work)
+    plan.set_params(Ws, bs)
+    ops.mlp_wgrad(plan, lr=lr)
+    torch.cuda.synchronize()
+    gW, gb = [w.clone() for w in dWs], [None if b is None else b.clone() for b in dbs]
+    ops.mlp_wgrad(plan)                                  # gradients alone
+    for i in range(len(shapes)):
+        assert torch.equal(dWs[i], gW[i])
+        ops.sgd_step(W0[i].view(-1), dWs[i].view(-1), lr)
+        assert torch.equal(W0[i], Ws[i]), i
+        if dbs[i] is not None:
+            assert torch.equal(dbs[i], gb[i])
+            ops.sgd_step(b0[i], dbs[i], lr)
+            assert torch.equal(b0[i], bs[i]), i
+
+
 def test_qr_embedding_bag_golden(ops, golden):
     """QREmbeddingBag forward + gradients vs the reference's module, incl. the float32-division quirk."""
     from cdlrm_amd.tricks.qr_embedding_bag import QREmbeddingBag
