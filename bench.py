@@ -382,6 +382,9 @@ def main():
                                        "commit_ms_per_step_amortised": (refills["first_commit_ms"] / L)
                                        if refills["first_commit_ms"] is not None else None}},
             "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
+                         "basis": "achieved / frac price ALGORITHMIC bytes (SURVEY 8d: 8D+16 per lookup); repeated rows of a "
+                                  "skewed batch are served by L2 / Infinity Cache, so the HBM counters see fewer bytes: "
+                                  "traffic, achieved_counter and frac_counter are the same launch time on those",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          # `achieved` / `frac` count ALGORITHMIC bytes (every lookup reads a row); `traffic` is what the
