@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd(const float* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ feat, const float* __restrict__ dR,
                                                       int64_t ld_r, int64_t B, int F, int D, int itself, int x_act,
-                                                      float* __restrict__ dfeat) {
+                                                      float* __restrict__ dfeat, int skip0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ldt = D + 1;
@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (i < F) {
+                    if (i < F && !(skip0 && i == 0)) {
                         float v = acc[r];
                         if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
                             v += gx[col];
@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd_r(const float* __restrict_
 template <int D4, bool STAGED>
 __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict__ feat, const float* __restrict__ dR,
                                                         int64_t ld_r, int64_t B, int F, int itself, int x_act,
-                                                        float* __restrict__ dfeat) {
+                                                        float* __restrict__ dfeat, int skip0) {
     constexpr int D = 4 * D4, PITCH = D + 4;
     constexpr int GMAX = D + 528;               // dense part + up to 32*33/2 pair gradients
     constexpr int NG = (GMAX / 4 + 63) / 64;
@@ -1026,9 +1026,10 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
                     for (int rr = 0; rr < 8; ++rr)      // accumulator register 8h + rr: row 16h + (rr&3) + 8 (rr>>2) + 4 lk
                         Os[((rr & 3) + 8 * (rr >> 2) + 4 * lk) * 32 + lr] = acc[8 * h + rr];
                     const int nvalid = min(F - 16 * h, 16) * 8;     // float4 words of valid rows (F > 16: >= 8)
+                    const int first = (h == 0 && skip0) ? 8 : 0;    // skip0: row 0 (the dense feature) is another launch's
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const int idx = min(64 * k + lane, nvalid - 1);     // clamped: spare lanes repeat the last word
+                        const int idx = first + min(64 * k + lane, nvalid - first - 1);     // clamped: spare lanes repeat the last word
                         const int row = idx >> 3, c4 = idx & 7;
                         *reinterpret_cast<v4f*>(out + (16 * h + row) * D + n0 + 4 * c4) =
                             *reinterpret_cast<const v4f*>(Os + row * 32 + 4 * c4);
@@ -1038,7 +1039,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (i < F) {
+                    if (i < F && !(skip0 && i == 0)) {
                         float v = acc[r];
                         if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
                             v += Gs[col];
@@ -1058,6 +1059,44 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
         b += nw;
     }
     for (; b < B; b += nw) one(b);
+}
+
+// The dense feature's gradient row alone: dX_0 = dR[:D] + sum_j S_0j T_j, times act'(T_0) -- 1/F of the interaction backward's
+// output and the ONLY part the bottom MLP's backward waits for.  As its own launch on the training queue it lets that chain
+// (MFMA-bound, the step's critical path) start beside the rest of the interaction backward (HBM-bound, embedding rows only,
+// on the side queue in front of the embedding backward that consumes it).  D4 lanes x float4 per sample, weighted sum of the
+// F rows in a fixed order (j ascending); the F coefficients S_0j = G[j][0] (+ G[0][0] twice with `itself`) come from the dR row.
+__global__ void __launch_bounds__(256) k_interact_bwd_dense(const float* __restrict__ feat, const float* __restrict__ dR,
+                                                            int64_t ld_r, int64_t B, int F, int D4, int itself, int x_act,
+                                                            float* __restrict__ dfeat) {
+    const int lps = D4;                                     // lanes per sample (D4 = D / 4 <= 64, a power of two here)
+    const int sub = threadIdx.x % lps, grp = threadIdx.x / lps, gpb = blockDim.x / lps;
+    const int D = 4 * D4;
+    const int off = itself ? 1 : 0;
+    for (int64_t b = (int64_t)blockIdx.x * gpb + grp; b < B; b += (int64_t)gridDim.x * gpb) {
+        const float* g = dR + b * ld_r;
+        const v4f* T = reinterpret_cast<const v4f*>(feat + b * F * D) + sub;
+        v4f acc = *reinterpret_cast<const v4f*>(g + 4 * sub);      // the direct path
+        const v4f t0 = T[0];
+        if (itself) {
+            const float s = 2.f * g[D];                             // pair (0, 0)
+            acc += s * t0;
+        }
+#pragma unroll 4
+        for (int j = 1; j < F; ++j) {
+            const float s = g[D + pair_base(j, itself)];            // pair (j, 0): first entry of row j of the triangle
+            acc += s * T[(int64_t)j * D4];
+        }
+        if (x_act == 1) {
+            acc.x = t0.x > 0.f ? acc.x : 0.f; acc.y = t0.y > 0.f ? acc.y : 0.f;
+            acc.z = t0.z > 0.f ? acc.z : 0.f; acc.w = t0.w > 0.f ? acc.w : 0.f;
+        } else if (x_act == 2) {
+            acc.x *= (1.0f - t0.x) * t0.x; acc.y *= (1.0f - t0.y) * t0.y;
+            acc.z *= (1.0f - t0.z) * t0.z; acc.w *= (1.0f - t0.w) * t0.w;
+        }
+        (void)off;
+        reinterpret_cast<v4f*>(dfeat + b * F * D)[sub] = acc;
+    }
 }
 
 template <typename K>
@@ -1139,12 +1178,26 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
     return 0;
 }
 
-extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
-                                  int32_t itself, int32_t x_act, float* dfeat, void* stream) {
+// rows: 0 all F gradient rows, 1 the dense feature's row (row 0) only, 2 all but row 0
+extern "C" int cdlrm_interact_bwd_rows(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
+                                       int32_t itself, int32_t x_act, float* dfeat, int32_t rows, void* stream) {
     CDLRM_REQUIRE(feat && dR && dfeat && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape");
     CDLRM_REQUIRE(aligned16(feat), "alignment");
+    CDLRM_REQUIRE(rows >= 0 && rows <= 2, "rows: 0 all, 1 dense row only, 2 all but the dense row");
     if (B == 0) return 0;
     const int npairs = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    if (rows == 1) {
+        const int D4 = D / 4;
+        CDLRM_REQUIRE((D4 & (D4 - 1)) == 0 && D4 <= 64 && aligned16(dR) && aligned16(dfeat) && ld_r % 4 == 0 &&
+                          ld_r >= D + npairs, "dense-row launch: D / 4 a power of two <= 64, 16-byte aligned dR rows");
+        int64_t gx = cdiv(B, 256 / D4);
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(k_interact_bwd_dense, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, feat, dR, ld_r, B,
+                           (int)F, D4, (int)itself, (int)x_act, dfeat);
+        CDLRM_LAUNCH_CHECK();
+        return 0;
+    }
+    const int skip0 = rows == 2;
     if ((D == 32 || D == 64 || D == 128) && ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3)) {
         const size_t ldsp = (size_t)4 * (32 * (D + 4) + D + 528) * sizeof(float);
         int64_t gp = cdiv(B, 4);
@@ -1158,10 +1211,10 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         if (rc) return rc;                                                                                     \
         if (staged)                                                                                            \
             hipLaunchKernelGGL((k_interact_bwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                                    \
+                               feat, dR, ld_r, B, F, itself, x_act, dfeat, skip0);                             \
         else                                                                                                   \
             hipLaunchKernelGGL((k_interact_bwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                                    \
+                               feat, dR, ld_r, B, F, itself, x_act, dfeat, skip0);                             \
     } while (0)
         if (D == 32) IBWD(8, b32);
         else if (D == 64) IBWD(16, b64);
@@ -1180,9 +1233,14 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     int64_t gx = cdiv(B, 4);
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(k_interact_bwd, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, feat, dR, ld_r, B, F, D,
-                       itself, x_act, dfeat);
+                       itself, x_act, dfeat, skip0);
     CDLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
+                                  int32_t itself, int32_t x_act, float* dfeat, void* stream) {
+    return cdlrm_interact_bwd_rows(feat, dR, ld_r, B, F, D, itself, x_act, dfeat, 0, stream);
 }
 
 // =================================================================================================

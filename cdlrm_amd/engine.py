@@ -437,6 +437,9 @@ class TrainEngine:
         self.native_tape = os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0"
         self.wgrad_late = os.environ.get("CDLRM_WGRAD_LATE", "0") == "1"
         self.fuse_sgd = os.environ.get("CDLRM_FUSE_SGD", "1") != "0"
+        # (interaction backward split by rows, see _fwd_bwd: measured SLOWER at c3, 0.718 vs 0.663 ms -- beside the GEMMs the
+        #  HBM-bound rest kernel takes 112 us instead of 52 and the embedding chain behind it becomes the long pole -- so off)
+        self.split_ibwd = os.environ.get("CDLRM_SPLIT_IBWD", "0") == "1"
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -482,6 +485,19 @@ class TrainEngine:
     def _side_gather(self, B: int) -> bool:
         """Short local batches run the gather on the side stream (see _fwd_bwd)."""
         return B < self.gather_alone_min and not (self.defer_top and self.cat)
+
+    def _alt_feat(self, B: int, lS_o) -> bool:
+        """Long batches on the Criteo layout with the dot interaction: the interaction backward runs split by rows and the
+        feature block alternates between two buffers (see _fwd_bwd)."""
+        D4 = self.D // 4
+        return (self.split_ibwd and not self.cat and lS_o is None and not self._side_gather(B) and self.D % 4 == 0
+                and (D4 & (D4 - 1)) == 0 and D4 <= 64 and self.r_width % 4 == 0)
+
+    def _feat_pair(self, B: int):
+        buf = self._buffers(B)
+        if "feat_pair" not in buf:
+            buf["feat_pair"] = (buf["feat"], torch.zeros(B + 1, self.F, self.D, dtype=torch.float32, device=self.dev)[:B])
+        return buf["feat_pair"]
 
     def _chain(self, B: int, next_idx, lS_o) -> bool:
         """Long batches on the window-resident probe: the next batch's take rides behind this step's embedding update on
@@ -738,6 +754,11 @@ class TrainEngine:
         chain = self._chain(B, next_idx, lS_o)
         if chain:
             two_phase = False
+        # Long batches: the interaction backward is split by rows (see below); the side stream then still reads THIS step's
+        # feature block while the main stream starts the next step, so the block alternates between two buffers
+        alt_feat = self._alt_feat(B, lS_o)
+        if alt_feat:
+            feat = self._feat_pair(B)[self.iter & 1]
         if self.defer_top and self.cat:
             # the previous step's top weight gradients read R = the feature block this step's first kernels overwrite
             rec(main.wait_event, ev["top_updated"])
@@ -888,18 +909,30 @@ class TrainEngine:
         if split is not None and not wgrad_late:
             rec(ev["top_dz"].record, main)
             top_wgrad(ev["top_dz"])
+        # Interaction backward by rows (long batches): the bottom MLP's backward -- MFMA-bound, the rest of the step's critical
+        # path -- needs ONE of the F gradient rows, the dense feature's.  That row is its own small launch on the main stream
+        # (cdlrm_interact_bwd_rows(rows = 1): 13.8 KB read per sample, vector ALU); the other F-1 rows, which only the
+        # embedding backward consumes, are computed on the side stream in front of it (rows = 2: the HBM-bound kernel), beside
+        # the bottom MLP's GEMMs.  The side stream starts from the `top_dz` event the weight gradients wait for anyway, so the
+        # main queue also loses the `interacted` record.
+        split_ibwd = alt_feat and not self.cat and split is not None and not wgrad_late
         if self.cat:
             # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
             # derivative (the dot path applies it in the interaction backward's epilogue)
             ops.act_bwd(dfeat[:, 0, :], feat[:, 0, :], self.bot[-1][1])
+        elif split_ibwd:
+            rec(side.wait_event, ev["top_dz"])
+            ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1], rows=2, stream=side)
+            ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1], rows=1)
         else:
             ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
-        rec(ev["interacted"].record, main)
-        if wgrad_late:
-            top_wgrad(ev["interacted"])
-        rec(side.wait_event, ev["interacted"])
+        if not split_ibwd:
+            rec(ev["interacted"].record, main)
+            if wgrad_late:
+                top_wgrad(ev["interacted"])
+            rec(side.wait_event, ev["interacted"])
         ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
                              cg.touched if self.world > 1 else None, stream=side)
         emb_done = ev["emb_done"]
@@ -1019,7 +1052,7 @@ class TrainEngine:
         nxt = next_idx is not None
         key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
                next_idx.stride(0) if nxt else 0,
-               (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
+               (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None) or self._alt_feat(B, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
                self._gslot is not None,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,

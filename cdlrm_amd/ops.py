@@ -375,12 +375,13 @@ def interact_fwd(feat: torch.Tensor, itself: bool, R: torch.Tensor, stream=None)
                                         stream_ptr(stream)))
 
 
-def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None, x_act: int = 0):
+def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None, x_act: int = 0,
+                 rows: int = 0):
     """x_act: activation that produced feature 0 (the bottom MLP's output); its gradient row then leaves as the
-    pre-activation gradient."""
+    pre-activation gradient.  rows: 0 all gradient rows, 1 the dense feature's row only, 2 all but that row."""
     B, F, D = feat.shape
-    check(_lib.lib().cdlrm_interact_bwd(feat.data_ptr(), dR.data_ptr(), dR.stride(0), B, F, D, int(bool(itself)),
-                                        int(x_act), dfeat.data_ptr(), stream_ptr(stream)))
+    check(_lib.lib().cdlrm_interact_bwd_rows(feat.data_ptr(), dR.data_ptr(), dR.stride(0), B, F, D, int(bool(itself)),
+                                             int(x_act), dfeat.data_ptr(), int(rows), stream_ptr(stream)))
 
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}

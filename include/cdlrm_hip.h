@@ -323,6 +323,12 @@ int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32
  * act'(feat[b,0,:]) here, so the bottom MLP's backward starts from the pre-activation gradient. */
 int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F,
                        int32_t D, int32_t itself, int32_t x_act, float* dfeat, void* stream);
+/* The same, by rows: 0 = all F gradient rows (cdlrm_interact_bwd), 1 = the dense feature's row only (row 0: all the bottom
+ * MLP's backward waits for -- a small launch on the training queue), 2 = every row but row 0 (the embedding rows, for the
+ * embedding backward: the training step runs it on the side queue beside the bottom MLP's backward).  1 and 2 together write
+ * what 0 writes (row 0 summed in j order by the vector ALU instead of the MFMA: equal within fp32 rounding). */
+int cdlrm_interact_bwd_rows(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
+                            int32_t itself, int32_t x_act, float* dfeat, int32_t rows, void* stream);
 
 /* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
  * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */

@@ -544,6 +544,18 @@ def test_interaction_kernels_vs_torch(ops, B, F, D, itself, pad):
     dfeat = torch.empty_like(fd)
     ops.interact_bwd(fd, G.to(DEV), bool(itself), dfeat)
     np.testing.assert_allclose(dfeat.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
+    # by rows: the dense feature's row (vector ALU, its own launch) + every other row = the whole, each touching only its part
+    if D % 4 == 0 and (D // 4) & (D // 4 - 1) == 0 and D // 4 <= 64 and width % 4 == 0:
+        for x_act in (0, 1):
+            whole = torch.empty_like(fd)
+            ops.interact_bwd(fd, G.to(DEV), bool(itself), whole, x_act=x_act)
+            parts = torch.full_like(fd, 3.0)
+            ops.interact_bwd(fd, G.to(DEV), bool(itself), parts, x_act=x_act, rows=2)
+            assert bool((parts[:, 0, :] == 3.0).all())                              # row 0 untouched
+            assert torch.equal(parts[:, 1:, :], whole[:, 1:, :])                    # the other rows: the same kernel
+            ops.interact_bwd(fd, G.to(DEV), bool(itself), parts, x_act=x_act, rows=1)
+            assert torch.equal(parts[:, 1:, :], whole[:, 1:, :])                    # rows 1.. untouched by the dense launch
+            np.testing.assert_allclose(parts[:, 0, :].cpu().numpy(), whole[:, 0, :].cpu().numpy(), rtol=2e-5, atol=2e-4)
 
 
 @pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 4096, 8192])
