@@ -102,9 +102,11 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, reso
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,defer", [("train_small", True), ("train_small", False), ("train_c1", True),
-                                        ("train_stream", True)])
-def test_chained_take_long_batch_path(golden, name, defer):
+@pytest.mark.parametrize("name,defer,split_rows", [("train_small", True, False), ("train_small", False, False),
+                                                   ("train_c1", True, False), ("train_stream", True, False),
+                                                   # + the interaction backward split by rows (CDLRM_SPLIT_IBWD=1 schedule)
+                                                   ("train_small", True, True), ("train_c1", True, True)])
+def test_chained_take_long_batch_path(golden, name, defer, split_rows):
     """The long-batch schedule (gather alone on the main stream, B >= gather_alone_min) on the window-resident probe: the
     next batch's take follows the embedding update on the side stream and the next gather waits for ONE event recorded
     behind it (and behind the deferred top-MLP update).  Forced here at the goldens' small batches; same trajectory,
@@ -115,6 +117,7 @@ def test_chained_take_long_batch_path(golden, name, defer):
     eng = TrainEngine(cg, dl, host, lr=eng0.lr, lr_embeds=eng0.lr_embeds, table_agg_freq=eng0.agg_freq,
                       table_agg_op=eng0.agg_op, defer_top_update=defer)
     eng.gather_alone_min = 1
+    eng.split_ibwd = split_rows
     assert eng.chain_take
     L = int(g["L"])
     batches = make_batches(g)
