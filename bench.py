@@ -368,7 +368,11 @@ def main():
             "config": {"workload": cfg["name"] + (" [windows streamed to the plan in chunks of %d batches]" % C if C else ""),
                        "config_id": a.config, "global_batch": B, "local_batch": lbs,
                        "lookahead": L, "zipf_alpha": a.alpha, "tables_rows_total": int(sum(ln_emb)),
-                       "parallelism": "dp%d" % world, "final_loss": loss, "setup_s": round(setup_s, 1),
+                       "parallelism": "dp%d" % world,
+                       # what torch.distributed itself reports for this run (a SCALE record can be checked for N ranks on RCCL)
+                       "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "dist_backend": dist.get_backend() if dist.is_initialized() else "none (one process, no collectives)",
+                       "final_loss": loss, "setup_s": round(setup_s, 1),
                        "host_issue_ms_per_step": t_issued / a.steps * 1e3,
                        # what of the look-ahead side fell INTO the timed steps (a 20-step run of a 3000-step window holds
                        # none; the default 3000-step run crosses one boundary and one background plan)

@@ -450,12 +450,15 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
 // ordered miss numbering per SEGMENT (= one batch of one rank: seg_len lookups): the i-th miss of a segment, in
 // position order, gets aux slot P*ways + i (phase 0; k_take adds the aux phase)
 __global__ void __launch_bounds__(1024) k_resolve_seg(const TableDesc* __restrict__ tab, int ways, int aux,
-                                                      int32_t* __restrict__ wslots, int64_t n, int64_t seg_len, int* err) {
+                                                      int32_t* __restrict__ wslots, int64_t n, int64_t batch_len,
+                                                      int64_t seg_len, int64_t segs_per_batch, int* err) {
     __shared__ int smem[32];
     const int t = blockIdx.y;
     const TableDesc d = tab[t];
-    const int64_t s0 = (int64_t)blockIdx.x * seg_len;
-    const int64_t cnt = min(seg_len, n - s0);
+    // segment = (batch b, rank r): starts at b * batch_len + r * seg_len and ends with the rank's slice or the batch
+    const int64_t b = (int64_t)blockIdx.x / segs_per_batch, r = (int64_t)blockIdx.x % segs_per_batch;
+    const int64_t s0 = b * batch_len + r * seg_len;
+    const int64_t cnt = min(min(seg_len, batch_len - r * seg_len), n - s0);
     int32_t* row = wslots + (int64_t)t * n + s0;
     int running = 0;
     for (int64_t base = 0; base < cnt; base += blockDim.x) {
@@ -497,12 +500,13 @@ __global__ void __launch_bounds__(256) k_victim_pos(const TableDesc* __restrict_
     }
 }
 
-extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, int64_t seg_len,
-                                    int32_t* wslots, int32_t* wsrc, void* stream) {
+extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, int64_t batch_len,
+                                    int64_t seg_len, int32_t* wslots, int32_t* wsrc, void* stream) {
     CDLRM_CLEAR_STALE();
     CDLRM_REQUIRE(ctx && idx && wslots && wsrc, "null argument");
     CDLRM_REQUIRE(ctx->tags && ctx->weight, "cdlrm_ctx_bind_cache first");
-    CDLRM_REQUIRE(n >= 1 && ld_idx >= n && n < ((int64_t)1 << 31) && seg_len >= 1, "bad n / ld_idx / seg_len");
+    CDLRM_REQUIRE(n >= 1 && ld_idx >= n && n < ((int64_t)1 << 31) && seg_len >= 1 && batch_len >= 0, "bad n / ld_idx / seg_len");
+    if (batch_len == 0) batch_len = cdiv(n, seg_len) * seg_len;     // one run of seg_len-long segments
     CDLRM_REQUIRE(ctx->vict_idx == nullptr || ctx->total_rows < ((int64_t)1 << 31), "victim positions must fit 31 bits");
     hipStream_t s = (hipStream_t)stream;
     int lpl = pow2ceil(ctx->ways);
@@ -519,11 +523,12 @@ extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t 
         default: PROBE_CALL(16); break;
     }
 #undef PROBE_CALL
-    const int64_t nseg = cdiv(n, seg_len);
+    const int64_t spb = cdiv(batch_len, seg_len);
+    const int64_t nseg = cdiv(n, batch_len) * spb;
     CDLRM_REQUIRE(nseg <= 65535 * 16, "too many segments");
     // grid.x is the segment index (up to 2^31 - 1 on HIP)
     hipLaunchKernelGGL(k_resolve_seg, dim3((unsigned)nseg, (unsigned)ctx->T), dim3(1024), 0, s, ctx->d_tab, ctx->ways, ctx->aux,
-                       wslots, n, seg_len, ctx->d_err);
+                       wslots, n, batch_len, seg_len, spb, ctx->d_err);
     int64_t gv = cdiv(n, 256);
     if (gv > 4096) gv = 4096;
     hipLaunchKernelGGL(k_victim_pos, dim3((unsigned)gv, (unsigned)ctx->T), dim3(256), 0, s, ctx->d_tab, ctx->T, ctx->ways, idx, n,

@@ -3,20 +3,23 @@
 // The engine (cdlrm_amd/engine.py, _step_taped) records the ~45 calls of a step once per control path -- kernel launches
 // through this library's entry points, event records and stream waits -- and re-issues them every step.  Replayed from
 // Python, each call costs 3-5 us of interpreter and ctypes marshalling: 0.22 ms per step, which at a per-rank batch of
-// 1024 (8192 over 8 GPUs) is MORE than the GPU needs for the step.  A tape holds the same calls as (function pointer,
+// 1024 (8192 over 8 GPUs) is MORE than the GPU needs for the step.  A tape holds the same calls as (entry point,
 // arguments) records; arguments that change from step to step (the batch's tensors) are "cells" the host patches before
 // a replay.
 //
-// The generic call: on the x86-64 System V ABI the k-th integer/pointer argument and the k-th floating-point argument of
-// a call travel in fixed places (rdi, rsi, rdx, rcx, r8, r9, then the stack in order; xmm0-7) whatever their positions
-// in the parameter list, the caller removes the stack arguments, and a callee ignores what it does not declare.  So
-// every entry point of this library (scalar arguments only, at most 8 floats) can be called through ONE function type
-// with its integer-class arguments and its float arguments given separately.  cdlrm_tape_selftest() checks exactly
-// that against a probe with interleaved float / int32 / pointer / stack arguments; the engine falls back to replaying
-// from Python when it fails.
+// Typed calls (round 3; the first version called every entry point through ONE mismatched function-pointer type, which
+// only the x86-64 System V register convention made work): every entry point a tape may hold is REGISTERED below with its
+// true type.  The host hands over a call's integer-class arguments (pointers, int32, int64: one int64 each, in parameter
+// order) and its float arguments separately; `invoke<R, A...>` walks the parameter types A... of the registered function,
+// takes the next integer or the next float for each, converts it to exactly that parameter type and calls the function
+// through a pointer of its own type.  An address that is not registered, or an argument count that does not match the
+// registered signature, is refused by cdlrm_tape_add (the engine then replays that step's tape from Python).
 #include <hip/hip_runtime.h>
 
 #include <new>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -24,12 +27,66 @@
 #define TAPE_MAX_INT 24
 #define TAPE_MAX_FLT 8
 
-typedef int (*tape_fn)(float, float, float, float, float, float, float, float, int64_t, int64_t, int64_t, int64_t,
-                       int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                       int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+typedef int (*tape_invoke_fn)(void* fn, const int64_t* ia, const float* fa);
+
+template <typename T>
+static inline T tape_take(const int64_t*& ia, const float*& fa) {
+    if constexpr (std::is_floating_point<T>::value) {
+        return (T)*fa++;
+    } else if constexpr (std::is_pointer<T>::value) {
+        return reinterpret_cast<T>((intptr_t)*ia++);
+    } else {
+        static_assert(std::is_integral<T>::value, "tape entry points take pointers, integers and floats only");
+        return static_cast<T>(*ia++);
+    }
+}
+
+template <typename R, typename... A>
+static int tape_invoke(void* fn, const int64_t* ia, const float* fa) {
+    // braced initialisation evaluates its elements left to right: arguments are taken in parameter order
+    std::tuple<A...> args{tape_take<A>(ia, fa)...};
+    return (int)std::apply(reinterpret_cast<R (*)(A...)>(fn), args);    // void* -> the function's OWN type: a round trip
+}
+
+struct TapeEntry {
+    void* fn;
+    tape_invoke_fn invoke;
+    int32_t n_int, n_flt;
+    const char* name;
+};
+
+template <typename R, typename... A>
+static TapeEntry tape_entry(R (*f)(A...), const char* name) {
+    static_assert(std::is_same<R, int>::value, "tape entry points return int");
+    constexpr int n_flt = (0 + ... + (std::is_floating_point<A>::value ? 1 : 0));
+    constexpr int n_int = (int)sizeof...(A) - n_flt;
+    static_assert(n_int <= TAPE_MAX_INT && n_flt <= TAPE_MAX_FLT, "too many arguments for a tape call");
+    return TapeEntry{reinterpret_cast<void*>(f), &tape_invoke<R, A...>, n_int, n_flt, name};
+}
+
+extern "C" int cdlrm_tape_probe(float f0, int64_t a0, float f1, int32_t a1, void* a2, int64_t a3, float f2, int32_t a4,
+                                int64_t a5, int64_t a6, void* a7, int32_t a8, float f3, int64_t a9);
+
+#define TAPE_FN(f) tape_entry(&f, #f)
+// every entry point a recorded training / evaluation step can issue (engine.py: _fwd_bwd, step, evaluate)
+static const std::vector<TapeEntry>& tape_registry() {
+    static const std::vector<TapeEntry> reg = {
+        TAPE_FN(cdlrm_embbag_probe), TAPE_FN(cdlrm_embbag_take), TAPE_FN(cdlrm_embbag_fwd), TAPE_FN(cdlrm_embbag_bwd_sgd),
+        TAPE_FN(cdlrm_embbag_bwd_prepare), TAPE_FN(cdlrm_embbag_bwd_apply), TAPE_FN(cdlrm_window_resolve),
+        TAPE_FN(cdlrm_mark_rows), TAPE_FN(cdlrm_interact_fwd), TAPE_FN(cdlrm_interact_bwd), TAPE_FN(cdlrm_linear_fwd),
+        TAPE_FN(cdlrm_linear_bwd), TAPE_FN(cdlrm_mlp_wgrad), TAPE_FN(cdlrm_mlp_wgrad_sgd), TAPE_FN(cdlrm_bce_fwd_bwd),
+        TAPE_FN(cdlrm_loss_fwd_bwd), TAPE_FN(cdlrm_head_fwd_bwd), TAPE_FN(cdlrm_head_finish), TAPE_FN(cdlrm_act_bwd),
+        TAPE_FN(cdlrm_sgd_step), TAPE_FN(cdlrm_sgd_step2), TAPE_FN(cdlrm_scale_div), TAPE_FN(cdlrm_ctx_time_next_gather),
+        TAPE_FN(cdlrm_event_record), TAPE_FN(cdlrm_stream_wait_event), TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather),
+        TAPE_FN(cdlrm_agg_scatter), TAPE_FN(cdlrm_tape_probe),
+    };
+    return reg;
+}
+#undef TAPE_FN
 
 struct TapeOp {
-    tape_fn fn;
+    void* fn;
+    tape_invoke_fn invoke;
     int32_t n_int, n_flt;
     int64_t iargs[TAPE_MAX_INT];
     int32_t cell[TAPE_MAX_INT];     // -1: literal, else index of the cell whose value is the argument
@@ -41,11 +98,7 @@ struct cdlrm_tape {
     std::vector<int64_t> cells;
 };
 
-static inline int tape_call(const TapeOp& o, const int64_t* a) {
-    const float* f = o.fargs;
-    return o.fn(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
-                a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20], a[21], a[22], a[23]);
-}
+static inline int tape_call(const TapeOp& o, const int64_t* a) { return o.invoke(o.fn, a, o.fargs); }
 
 extern "C" cdlrm_tape* cdlrm_tape_create(int32_t n_cells) {
     if (n_cells < 0 || n_cells > 64) { cdlrm_set_error("cdlrm_tape_create: 0..64 cells"); return nullptr; }
@@ -61,13 +114,23 @@ extern "C" int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int6
                               int32_t n_flt, const float* fargs) {
     CDLRM_REQUIRE(t && fn, "null argument");
     CDLRM_REQUIRE(n_int >= 0 && n_int <= TAPE_MAX_INT && n_flt >= 0 && n_flt <= TAPE_MAX_FLT, "too many arguments for a tape call");
+    const TapeEntry* e = nullptr;
+    for (const TapeEntry& r : tape_registry())
+        if (r.fn == fn) { e = &r; break; }
+    CDLRM_REQUIRE(e, "not a registered tape entry point (csrc/tape.hip: tape_registry)");
+    if (e->n_int != n_int || e->n_flt != n_flt) {
+        cdlrm_set_error("cdlrm_tape_add: %s takes %d integer-class + %d float arguments, got %d + %d", e->name, e->n_int,
+                        e->n_flt, n_int, n_flt);
+        return CDLRM_EINVAL;
+    }
     TapeOp o;
-    o.fn = (tape_fn)fn;
+    o.fn = fn;
+    o.invoke = e->invoke;
     o.n_int = n_int; o.n_flt = n_flt;
     for (int i = 0; i < TAPE_MAX_INT; ++i) {
         o.iargs[i] = i < n_int ? iargs[i] : 0;
         o.cell[i] = i < n_int ? cell[i] : -1;
-        CDLRM_REQUIRE(o.cell[i] < (int)t->cells.size(), "cell index outside the tape's cells");
+        CDLRM_REQUIRE(o.cell[i] >= -1 && o.cell[i] < (int)t->cells.size(), "cell index outside the tape's cells");
     }
     for (int i = 0; i < TAPE_MAX_FLT; ++i) o.fargs[i] = i < n_flt ? fargs[i] : 0.f;
     t->ops.push_back(o);
@@ -130,7 +193,7 @@ extern "C" int cdlrm_event_elapsed_us(void* start, void* stop, float* us) {
     return 0;
 }
 
-// ---- self-test of the generic call ----------------------------------------------------------------------------
+// ---- self-test of the typed call: interleaved float / int32 / pointer / int64 parameters, a cell in two places -------
 static int64_t g_probe_sum;
 static double g_probe_fsum;
 
@@ -158,7 +221,7 @@ extern "C" int cdlrm_tape_selftest(void) {
                              19 * 0x7e00cafe0000LL + 23 * ia[8] + 29 * ia[9];
         const double wantf = 1.5 + 2.0 * -2.25 + 4.0 * 1024.0 + 8.0 * 0.125;
         if (!rc && (g_probe_sum != want || g_probe_fsum != wantf)) {
-            cdlrm_set_error("cdlrm_tape_selftest: the generic call does not reach its arguments on this ABI");
+            cdlrm_set_error("cdlrm_tape_selftest: the typed call does not reach its arguments");
             rc = CDLRM_EINVAL;
         }
     }

@@ -77,7 +77,8 @@ class WindowPipeline:
                  *, parity_rng: bool = False, seed: int = 0, average_on_writeback: bool = False, rank: int = 0,
                  world_size: int = 1, cap_uniq: Optional[int] = None, cap_win: Optional[int] = None,
                  victim_rows: Optional[int] = None, host_gather: bool = False, gather_threads: int = 16,
-                 shard_fetch: Optional[bool] = None, process_group=None, write_back: bool = True):
+                 shard_fetch: Optional[bool] = None, process_group=None, write_back: bool = True,
+                 force_collectives: bool = False):
         """victim_rows: capacity (rows) of each of the two HBM buffers that hold the host rows of a window's
         non-cached indices (None: every unique index of a window, at most 8 GiB per buffer; 0: off -- every miss
         reads the host table over PCIe as the reference does).
@@ -92,7 +93,9 @@ class WindowPipeline:
         world x (winners + victims) to 1 x; the reference instead broadcasts whole cache tables from rank 0
         (main_no_ddp.py:318-319).
         write_back=False: evicted rows are dropped instead of written to the host tables (repeatability tests that must
-        leave the host tables as they found them; never in training)."""
+        leave the host tables as they found them; never in training).
+        force_collectives: take the multi-rank code paths (sharded fetch + in-place all-gather, barrier) at world_size 1
+        too -- a 1-rank communicator executes every collective the N-rank run issues (tests/test_rccl_one_rank.py)."""
         self.cg, self.host = cache_group, host_tables
         self.write_back = bool(write_back)
         self.ctx = cache_group.ctx
@@ -105,6 +108,7 @@ class WindowPipeline:
         self.side = S.new_stream(self.dev)
         self.parity_rng, self.seed, self.avg = parity_rng, int(seed), average_on_writeback
         self.rank, self.world = rank, world_size
+        self.multi = self.world > 1 or bool(force_collectives)
         self.host_ptrs = host_tables.device_pointers()
         self.ctx.bind_host_tables(self.host_ptrs)
         self.window_no = 0
@@ -115,7 +119,7 @@ class WindowPipeline:
         self.gather_threads = int(gather_threads)
         if shard_fetch is None:
             shard_fetch = os.environ.get("CDLRM_SHARD_FETCH", "1") != "0"
-        self.shard = bool(shard_fetch) and self.host_gather and self.world > 1
+        self.shard = bool(shard_fetch) and self.host_gather and self.multi
         self.pg = process_group
         self._exchange = []          # (buffer, chunk rows) all-gathers commit() owes for the plan in flight
         self._worker = None          # background thread of a host-gather plan
@@ -298,8 +302,8 @@ class WindowPipeline:
         """Host-side: the evicted rows are in the host tables (all ranks may read them afterwards)."""
         if self.written_back is not None:
             self.written_back.synchronize()
-        if self.world > 1:
-            dist.barrier()
+        if self.multi:
+            dist.barrier(group=self.pg)
 
     def eviction_data(self):
         """(idx, rows) per table, as the reference queues them (main_no_ddp.py:199); synchronises."""
@@ -317,7 +321,16 @@ class WindowResolver:
     ordered miss numbering per batch and the place of every miss in the window's victim rows (cdlrm_window_resolve), in
     chunks of `chunk` batches issued on the engine's prefetch stream ahead of the training position.  `batch(j)` hands the
     engine the views of batch j; what is left per iteration is cdlrm_embbag_take (copy the slot ids, copy the miss rows).
-    Create it right after the window's commit(); call ensure() after every step."""
+    Create it right after the window's commit(); call ensure() after every step.
+
+    Chunk results live in a fixed RING of three buffers owned by the engine (chunk c in slot c % 3), not in per-chunk
+    allocations: the resolve writes them on the prefetch stream while takes read them on the side stream, streams the
+    caching allocator knows nothing about -- a block freed on the host while queued takes still read it would be handed
+    straight to the next chunk's resolve.  A slot is recycled behind an event recorded on the side stream when the recycling
+    resolve is issued: every take of the chunk that held the slot (two chunks back) has been ISSUED by then, so the event
+    covers them all however far the host runs ahead of the GPU."""
+
+    RING = 3
 
     def __init__(self, engine: "TrainEngine", window_idx: torch.Tensor, global_batch: int, *, chunk: int = 16):
         self.eng, self.ctx = engine, engine.ctx
@@ -325,12 +338,21 @@ class WindowResolver:
         self.B = int(global_batch)
         self.lbs = -(-self.B // engine.world)
         self.rank = engine.rank
+        # this rank's slice of a global batch (main_no_ddp.py:388-391): the last rank's is shorter when world does not divide B
+        self.col0 = min(self.rank * self.lbs, self.B)
+        self.width = max(0, min(self.lbs, self.B - self.col0))
         n = int(window_idx.shape[1])
         assert n % self.B == 0, "a window is a whole number of batches"
         self.nb = n // self.B
         self.CH = max(1, int(chunk))
         self.chunks = {}            # chunk number -> (wslots, wsrc, ready event)
         self.done = 0               # chunks issued
+        key = ("wres", self.CH * self.B)
+        if key not in engine._bufs:
+            T = self.ctx.T
+            engine._bufs[key] = [tuple(torch.empty(T * self.CH * self.B, dtype=torch.int32, device=window_idx.device)
+                                       for _ in range(2)) for _ in range(self.RING)]
+        self._ring = engine._bufs[key]
         self.ensure(self.CH + 2)
 
     def ensure(self, upto_batch: int):
@@ -340,15 +362,20 @@ class WindowResolver:
         want = min(nchunks, -(-min(int(upto_batch), self.nb) // self.CH))
         while self.done < want:
             c = self.done
+            assert (c - self.RING) not in self.chunks, "ring slot still handed out: ensure() ran more than two chunks ahead"
             b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
             cols = self.idx[:, b0 * self.B:b1 * self.B]
-            ws = torch.empty(ctx.T, cols.shape[1], dtype=torch.int32, device=self.idx.device)
-            wsrc = torch.empty_like(ws)
+            w = int(cols.shape[1])
+            ring_ws, ring_src = self._ring[c % self.RING]
+            ws, wsrc = ring_ws[:ctx.T * w].view(ctx.T, w), ring_src[:ctx.T * w].view(ctx.T, w)
             pst = eng.pref
             if self.done == 0:
                 pst.wait_stream(S.current_stream(eng.dev))      # the commit (tags, victims) is on the main stream
+            # the slot's previous chunk (this window's c - 3, or a chunk of the previous window): its takes are all issued,
+            # on the side stream (chained / in-line takes) or on this very stream (two-phase takes: in order)
+            pst.wait_stream(eng.side)
             with S.on_stream(pst):
-                ops.window_resolve(ctx, cols, self.lbs, ws, wsrc, stream=pst)
+                ops.window_resolve(ctx, cols, self.lbs, ws, wsrc, stream=pst, batch_len=self.B)
                 ev = S.new_event(eng.dev)
                 ev.record(pst)
             self.chunks[c] = (ws, wsrc, ev)
@@ -359,28 +386,32 @@ class WindowResolver:
         c = j // self.CH
         self.ensure(j + 1)
         ws, wsrc, ev = self.chunks[c]
-        col = (j - c * self.CH) * self.B + self.rank * self.lbs
+        col = (j - c * self.CH) * self.B + self.col0
         if c >= 2 and (c - 2) in self.chunks:       # chunks far behind the training position are not needed any more
             del self.chunks[c - 2]
-        return ws[:, col:col + self.lbs], wsrc[:, col:col + self.lbs], ev
+        return ws[:, col:col + self.width], wsrc[:, col:col + self.width], ev
 
 
 class TrainEngine:
     def __init__(self, cache_group: Embedding_Table_Cache_Group, dlrm: DLRM_Net, host_tables: Embedding_Table_Group,
                  *, lr: float, lr_embeds: float, world_size: int = 1, rank: int = 0, table_agg_freq: int = 1,
                  table_agg_op: str = "mean", process_group=None, loss: str = "bce", loss_weights=(1.0, 1.0),
-                 defer_top_update: bool = False):
+                 defer_top_update: bool = False, force_collectives: bool = False):
         """loss / loss_weights: --loss-function / --loss-weights (main_no_ddp.py:364-372); the --loss-threshold clamp
         is read from `dlrm.loss_threshold`.
         defer_top_update: the top MLP's weight gradients, their all-reduce and their SGD update leave the critical
         path -- they run on a side stream beside the interaction backward, the bottom MLP's backward and the HEAD of the
         next step (gather, bottom MLP forward), which only waits for them in front of its interaction.  Same values,
-        different schedule; readers of the top MLP's weights outside step()/evaluate() call finish() first."""
+        different schedule; readers of the top MLP's weights outside step()/evaluate() call finish() first.
+        force_collectives: run the multi-rank control flow (gradient all-reduce, touched-row flags and merge, exchange
+        stream) at world_size 1 as well: over a 1-rank RCCL communicator every collective of the N-rank step executes and is
+        the identity, so the result must equal the one-rank fast path bit for bit (tests/test_rccl_one_rank.py)."""
         self.cg, self.dlrm, self.host = cache_group, dlrm, host_tables
         self.ctx = cache_group.ctx
         self.dev = cache_group.weight.device
         self.lr, self.lr_embeds = float(lr), float(lr_embeds)
         self.world, self.rank = int(world_size), int(rank)
+        self.multi = self.world > 1 or bool(force_collectives)      # the multi-rank control flow is on
         self.agg_freq, self.agg_op = int(table_agg_freq), table_agg_op
         self.pg = process_group
         self.T, self.D = self.ctx.T, self.ctx.D
@@ -399,7 +430,7 @@ class TrainEngine:
         self.ctx.bind_host_tables(host_tables.device_pointers())
         self._bufs = {}
         self.iter = 0
-        self.comm = S.new_stream(self.dev) if self.world > 1 else None
+        self.comm = S.new_stream(self.dev) if self.multi else None
         self.side = S.new_stream(self.dev)
         self.pref = S.new_stream(self.dev)          # next batch's tag probe + aux-row fill
         self.agg_rows = None
@@ -600,7 +631,7 @@ class TrainEngine:
         (main_no_ddp.py:318-319), which also overwrites whatever the other ranks changed since the last
         table-agg merge.  Same result without moving 10.9 GB: only the rows some rank touched since that merge can
         differ, so broadcast exactly those (union of the touched flags), leaving the flags set for the next merge."""
-        if self.world == 1:
+        if not self.multi:
             return
         ctx = self.ctx
         self._agg_alloc()
@@ -653,7 +684,7 @@ class TrainEngine:
         B, n = X.shape[0], lS_i.shape[1]
         self._res, self._next_res = res, (next_res if next_idx is not None else None)
         if lS_o is not None:
-            assert lS_o.shape[1] in (B, B + 1) and (self.world == 1 or lS_o.shape[1] == B)
+            assert lS_o.shape[1] in (B, B + 1) and (not self.multi or lS_o.shape[1] == B)
         if j is None:
             j = self.iter
         # (the row merge at the end of a table-agg step leaves aux rows alone -- the backward never flags them --, so the
@@ -680,7 +711,7 @@ class TrainEngine:
         else:
             sgd_done = self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
         # ---- dense gradient exchange + SGD ----
-        if self.world > 1 and self.defer_top:
+        if self.multi and self.defer_top:
             # two exchanges, issued in the same order on every rank: the top MLP's (its weight gradients were launched
             # on the side stream right after the top dgrad chain) runs beside the rest of this step's backward and the
             # head of the next step; the bottom MLP's is the only one on the critical path
@@ -704,7 +735,7 @@ class TrainEngine:
                 S.current_stream(self.dev).wait_event(self._events["emb_done"])
             ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
             sgd_done = True
-        elif self.world > 1:
+        elif self.multi:
             gw = self.grad_flat[:self.n_weight]
             if self._reduce_avg():
                 dist.all_reduce(gw, op=dist.ReduceOp.AVG, group=self.pg)
@@ -719,7 +750,7 @@ class TrainEngine:
         # ---- periodic cache-row merge (main_no_ddp.py:417-423) ----
         if j is None:
             j = self.iter
-        if self.world > 1 and j > 0 and j % self.agg_freq == 0:
+        if self.multi and j > 0 and j % self.agg_freq == 0:
             # (one rank averages with itself, W[u] = W[u] / 1: nothing to do, and no flags are kept at world == 1)
             if self._emb_done is not None:      # the merge reads (and the flag reset races with) this step's row updates
                 S.current_stream(self.dev).wait_event(self._emb_done)
@@ -893,11 +924,11 @@ class TrainEngine:
             # backward.  (Launching each layer's weight gradient as soon as ITS dZ exists -- beside the dgrad chain itself
             # -- measured slower: 0.810 vs 0.782 ms at B=8192; the chain is the critical path and loses CUs to them.)
             rec(wst.wait_event, after)
-            fused = self.defer_top and self.world == 1 and self.fuse_sgd
+            fused = self.defer_top and not self.multi and self.fuse_sgd
             ops.mlp_wgrad(split[1], stream=wst, lr=self.lr if fused else None)
             if not self.defer_top:
                 rec(ev["wgrad_done"].record, wst)
-            elif self.world == 1:
+            elif not self.multi:
                 if not fused:
                     ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
                 rec(ev["top_updated"].record, wst)
@@ -934,7 +965,7 @@ class TrainEngine:
                 top_wgrad(ev["interacted"])
             rec(side.wait_event, ev["interacted"])
         ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
-                             cg.touched if self.world > 1 else None, stream=side)
+                             cg.touched if self.multi else None, stream=side)
         emb_done = ev["emb_done"]
         rec(emb_done.record, side)
         self._emb_done = emb_done
@@ -950,7 +981,7 @@ class TrainEngine:
                 # ... and the sort of the next batch's slot ids for ITS backward: here it ends well before the step does; issued
                 # by the next step it ran late enough to share HBM with that step's gather (the roofline kernel)
                 ops.embbag_bwd_prepare(ctx, res[0], emb_work, stream=side)
-            chained_top = chain and self.defer_top and self.world == 1 and split is not None
+            chained_top = chain and self.defer_top and not self.multi and split is not None
             if chained_top:
                 rec(side.wait_event, ev["top_updated"])     # recorded above, behind this step's top-MLP SGD
             evp = ev["probed"][which]
@@ -967,11 +998,11 @@ class TrainEngine:
         sgd_included = False
         if split is not None:
             split[0].set_x(0, X)
-            fused = self.defer_top and self.world == 1 and self.fuse_sgd
+            fused = self.defer_top and not self.multi and self.fuse_sgd
             ops.mlp_wgrad(split[0], lr=self.lr if fused else None)
             if not self.defer_top:
                 rec(main.wait_event, ev["wgrad_done"])
-            elif self.world == 1:
+            elif not self.multi:
                 if not fused:
                     ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
                 sgd_included = True
@@ -979,7 +1010,7 @@ class TrainEngine:
             plan = buf["wgrad"]
             plan.set_x(0, X)
             ops.mlp_wgrad(plan)
-        if self.world > 1:
+        if self.multi:
             return False # step() joins AFTER it has issued the gradient all-reduce: the exchange overlaps the embedding update
         if next_idx is None:
             rec(main.wait_stream, side)      # full join
@@ -1002,6 +1033,13 @@ class TrainEngine:
         B, n = X.shape[0], lS_i.shape[1]
         assert n <= ctx.aux, "test batch larger than the aux table (test_mini_batch_size <= aux_table_size)"
         self.finish()
+        pend = self._pref
+        if pend is not None and pend["phase"] == self._phase:
+            # the next training batch's take already filled THIS aux region (single-region / chained take: the long-batch
+            # default): wait for it, let the test batch overwrite the region, and drop the prefetched result -- the next
+            # step() then takes (and sorts) its batch again in line
+            S.current_stream(self.dev).wait_event(pend["res"][3])
+            self._pref = None
         buf = self._buffers(B)
         feat, R = buf["feat"], buf["R"]
         F, D = self.F, self.D
@@ -1063,7 +1101,7 @@ class TrainEngine:
             _lib.start_recording(calls)
             try:
                 included = self._fwd_bwd(X, lS_i, T, None, None, next_idx)
-                if self.world == 1 and not included:   # no gradient exchange in between: the dense SGD rides on the tape too
+                if not self.multi and not included:   # no gradient exchange in between: the dense SGD rides on the tape too
                     ops.sgd_step(self.param_flat, self.grad_flat, self.lr)
             finally:
                 _lib.stop_recording()
@@ -1081,7 +1119,7 @@ class TrainEngine:
                 cells["g0"], cells["g1"] = C.c_void_p(self._gslot[0].handle), C.c_void_p(self._gslot[1].handle)
             by_value = {c.value: c for c in cells.values()}
             if len(by_value) != len(cells):
-                return self.world == 1      # aliased inputs: stay on the untaped path
+                return not self.multi      # aliased inputs: stay on the untaped path
             prog = []
             for fn, args in calls:
                 if getattr(fn, "argtypes", None) is not None:
@@ -1101,7 +1139,7 @@ class TrainEngine:
             self._tapes[key] = dict(prog=prog, cells=cells, phase=self._phase, native=native,
                                     pref=None if post is None else (post["phase"], post["res"], post.get("chained_top", False),
                                                                     post.get("prepared", False)))
-            return self.world == 1
+            return not self.multi
         cells = tape["cells"]
         cells["X"].value = X.data_ptr()
         cells["T"].value = T.data_ptr()
@@ -1134,7 +1172,7 @@ class TrainEngine:
         if tape["pref"] is not None:
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1],
                               chained_top=tape["pref"][2], prepared=tape["pref"][3])
-        return self.world == 1
+        return not self.multi
 
     def table_aggregate(self):
         """broadcast_and_aggregate (main_no_ddp.py:250-292): average the rows any rank touched since the last
@@ -1144,7 +1182,7 @@ class TrainEngine:
         i-1 scattered back on the main stream.  No allocation in steady state; the host waits only for the row count."""
         cg, ctx = self.cg, self.ctx
         touched = cg.touched
-        if self.world == 1:
+        if not self.multi:
             touched.zero_()
             return
         main = S.current_stream(self.dev)

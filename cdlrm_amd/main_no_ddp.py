@@ -488,7 +488,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 # during this step instead of at the head of the next one
                 nxt = rank_indices(window[0][2]) if window else None
                 carried_idx = nxt
-            rs = resolver if (resolver is not None and Xr.shape[0] == local_batch_size) else None
+            rs = resolver if (resolver is not None and Xr.shape[0] == resolver.width) else None
             lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j, next_idx=nxt,
                                res=rs.batch(wj) if rs is not None else None,
                                next_res=rs.batch(wj + 1) if (rs is not None and nxt is not None) else None)

@@ -109,15 +109,17 @@ def embbag_probe(ctx: CacheCtx, idx: torch.Tensor, stream=None, aux_phase: int =
     return slots, miss_pos, miss_count
 
 
-def window_resolve(ctx: CacheCtx, idx: torch.Tensor, seg_len: int, wslots: torch.Tensor, wsrc: torch.Tensor, stream=None):
-    """Resolve every lookup of idx [T, n] (n / seg_len consecutive batches) against the CURRENT tags and the bound victim
-    list, once: wslots / wsrc int32 [T, n] contiguous (see include/cdlrm_hip.h)."""
+def window_resolve(ctx: CacheCtx, idx: torch.Tensor, seg_len: int, wslots: torch.Tensor, wsrc: torch.Tensor, stream=None,
+                   batch_len: int = 0):
+    """Resolve every lookup of idx [T, n] (consecutive global batches of batch_len lookups, each cut into rank slices of
+    seg_len; batch_len 0 = one run of seg_len-long segments) against the CURRENT tags and the bound victim list, once:
+    wslots / wsrc int32 [T, n] contiguous (see include/cdlrm_hip.h)."""
     _require_cuda(idx, "idx")
     assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.shape[0] == ctx.T and idx.stride(1) == 1
     n = idx.shape[1]
     for w in (wslots, wsrc):
         assert w.dtype == torch.int32 and tuple(w.shape) == (ctx.T, n) and w.is_contiguous()
-    check(_lib.lib().cdlrm_window_resolve(ctx.handle, idx.data_ptr(), n, idx.stride(0), int(seg_len), wslots.data_ptr(),
+    check(_lib.lib().cdlrm_window_resolve(ctx.handle, idx.data_ptr(), n, idx.stride(0), int(batch_len), int(seg_len), wslots.data_ptr(),
                                           wsrc.data_ptr(), stream_ptr(stream)))
 
 

@@ -94,8 +94,11 @@ int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld
 /* Window-resident form of the same (round 2).  Tags only change at a refill (main_no_ddp.py:393-399), so the tag match
  * of model_no_ddp.py:163-174, the ordered miss numbering (:176-177) and the lookup of a miss in the window's victim list
  * need to run ONCE per look-ahead window, not once per iteration:
- *   cdlrm_window_resolve   idx [T, n] = the lookups of n/seg_len consecutive batches (seg_len = lookups of one batch of one
- *                          rank).  wslots int32 [T, n]: the slot of every lookup, misses numbered per segment in position
+ *   cdlrm_window_resolve   idx [T, n] = the lookups of n/batch_len consecutive GLOBAL batches of batch_len lookups each;
+ *                          every batch is cut into segments of seg_len lookups (= one rank's slice, ceil(B/world): the
+ *                          last segment of a batch is shorter when world does not divide B, main_no_ddp.py:344, 388-391) and
+ *                          the numbering restarts at every segment AND every batch boundary.  batch_len = 0: one run of
+ *                          seg_len-long segments.  wslots int32 [T, n]: the slot of every lookup, misses numbered per segment in position
  *                          order as P_k*ways + i (aux phase 0); wsrc int32 [T, n]: for a miss, the position of its row in
  *                          the bound victim rows (cdlrm_ctx_bind_victims), -1 = read the host table; undefined for hits.
  *                          Call after the window's cdlrm_plan_commit + cdlrm_ctx_bind_victims.
@@ -103,7 +106,7 @@ int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld
  *                          region aux_phase) and the misses' rows copied into their aux rows -- exactly what
  *                          cdlrm_embbag_probe leaves behind for that batch.  wslots / wsrc / idx point at the batch's
  *                          first column; ld_w / ld_idx are the row strides. */
-int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, int64_t seg_len,
+int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, int64_t batch_len, int64_t seg_len,
                          int32_t* wslots, int32_t* wsrc, void* stream);
 int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, const int32_t* wslots,
                       const int32_t* wsrc, int64_t ld_w, int32_t* slots_out, int32_t aux_phase, void* stream);

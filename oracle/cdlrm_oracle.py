@@ -570,7 +570,11 @@ class OracleTrainer:
                 Or = [lS_o[k] for k in range(len(self.ln_emb))]
             else:               # the rank slice of the Criteo layout (one lookup per sample)
                 Ir = [lS_i[k][r * lbs:(r + 1) * lbs] for k in range(len(self.ln_emb))]
-                Or = [lS_o[k][:lbs] for k in range(len(self.ln_emb))]
+                # lS_o[:, :local_batch_size] (:390).  When world does not divide the batch the reference's last rank gets
+                # lbs offsets for fewer lookups -- an empty trailing bag, [lbs, D] pooled rows beside a shorter X -- and
+                # raises in interact_features' cat (model_no_ddp.py:276).  Defined here (and in the engine) as the natural
+                # extension: the last rank trains on its short slice, one bag per lookup it has.
+                Or = [lS_o[k][:Ir[k].numel()] for k in range(len(self.ln_emb))]
             Tr = T[r * lbs:(r + 1) * lbs]
             ly, cg = cache_forward(self.occ, self.weights[r], self.cache_sizes, Or, Ir, self.host)
             ly = [v.detach().requires_grad_(True) for v in ly]

@@ -1,9 +1,11 @@
 """BASELINE.json's GPU configurations at the SHAPE the bench runs them, against the REFERENCE's own run of the same
-workload (tests/golden/train_c{2,3,5}shape.npz, captured by tools/make_golden.py:g_train_shapes from the imported
+workload (tests/golden/train_c{2,3,4,5}shape.npz, captured by tools/make_golden.py:g_train_shapes from the imported
 reference: main_no_ddp.py:148-209 CacheEmbeddings, model_no_ddp.py:149-212 cache forward, DLRM_Net, BCELoss, both SGDs).
 
   c3-shape: 26 Terabyte-cardinality tables (capped at 50 k rows), D=128, 16-WAY, bot 13-512-256-128, top 512-512-256-1
   c2-shape: 26 Kaggle-cardinality tables, D=32, 8-way, B=2048, L=4
+  c4-shape: embed-dim 256 (BASELINE configs[3]): bot 13-512-256-256, the 607-wide top input on its 608-float pitch, 26
+            tables x 16-way with 1024-byte cache rows -- pipelined and window-resolved
   c5-shape: 12288 lookups per table and step (the backward's slot sort takes its merge passes), the look-ahead window
             STREAMED into the plan in 3 chunks (cdlrm_window_unique_add / _finish) in front of a real insert
 
@@ -33,7 +35,8 @@ def t(a):
 
 @pytest.mark.parametrize("name,chunks,pipelined,resolved", [("train_c3shape", 0, True, False), ("train_c2shape", 0, True, True),
                                                             ("train_c5shape", 3, True, False), ("train_c3shape", 2, False, False),
-                                                            ("train_c3shape", 0, True, True), ("train_c5shape", 0, True, True)])
+                                                            ("train_c3shape", 0, True, True), ("train_c5shape", 0, True, True),
+                                                            ("train_c4shape", 0, True, False), ("train_c4shape", 0, True, True)])
 def test_config_shaped_training_vs_reference(golden, name, chunks, pipelined, resolved):
     from test_engine_parity import build, make_batches
     g = golden(name)
@@ -113,9 +116,10 @@ def _check_cache_invariants(cg):
         assert int(v.min()) >= 0 and int(v.max()) < int(cg.ln_emb[k]) if v.numel() else True
 
 
-def _run_full_size(config, host, L, n_windows, steps_per_window):
+def _run_full_size(config, host, L, n_windows, steps_per_window, max_ind_range=-1):
     import bench
-    w = bench.build_workload(config, lookahead=L, host=host, seed=123, cache_init="zeros", write_back=False)
+    w = bench.build_workload(config, lookahead=L, host=host, seed=123, cache_init="zeros", write_back=False,
+                             max_ind_range=max_ind_range)
     cg, eng, pipe, syn, B = w["cg"], w["eng"], w["pipe"], w["syn"], w["B"]
     T = len(cg.cache_sizes)
     losses, feats = [], None
@@ -175,6 +179,28 @@ def test_full_size_invariants_and_bitwise_repeat(terabyte_host, config, L, steps
     second run sees the host tables of the first.)"""
     a = _run_full_size(config, terabyte_host, L, 2, steps)
     b = _run_full_size(config, terabyte_host, L, 2, steps)
+    assert torch.isfinite(a["losses"]).all() and 0.3 < float(a["losses"][-1]) < 2.0
+    assert torch.equal(a["losses"], b["losses"]), "loss trajectory differs between two identical runs"
+    assert torch.equal(a["tags"], b["tags"])
+    assert torch.equal(a["params"], b["params"])
+    assert a["wsum"] == b["wsum"] and a["feats"] == b["feats"]
+    assert int((a["tags"] != -1).sum()) > 1_000_000
+
+
+def test_c4_capped_invariants_and_bitwise_repeat():
+    """BASELINE configs[3] (embed-dim 256, 26 tables x 150 k x 16-way, B = 8192) exactly as `bench.py --config c4
+    --max-ind-range 2000000` builds it: tables capped at 2 M rows (the uncapped host tables are 192 GB of pinned memory;
+    capped: 20 GB), everything else at the configuration's size -- the 1024-byte-row gather / backward, the 13-512-256-256
+    bottom MLP, the 607 -> 608-pitch top input at M = 8192.  Same invariants as the c3 / c5 cases, two windows of 8.2 M
+    indices per table: the eight 2 M-row tables overflow their 2.4 M slots' sets, so evictions and victims occur."""
+    import bench
+    cap = 2_000_000
+    host = bench.build_host_tables("c4", seed=123, dev=torch.device(DEV), max_ind_range=cap)
+    try:
+        a = _run_full_size("c4", host, 1000, 2, 4, max_ind_range=cap)
+        b = _run_full_size("c4", host, 1000, 2, 4, max_ind_range=cap)
+    finally:
+        del host
     assert torch.isfinite(a["losses"]).all() and 0.3 < float(a["losses"][-1]) < 2.0
     assert torch.equal(a["losses"], b["losses"]), "loss trajectory differs between two identical runs"
     assert torch.equal(a["tags"], b["tags"])

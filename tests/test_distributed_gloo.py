@@ -71,7 +71,7 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False):
     eng = engine.TrainEngine(cg, dl, eg, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]), world_size=world, rank=rank,
                              table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]), defer_top_update=defer)
     pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
-    lbs = B // world
+    lbs = -(-B // world)            # ceil (main_no_ddp.py:344); the last rank's slice is shorter when world does not divide B
     losses = []
     batches = _batches(g)
     for j, (X, lS_i, Tt) in enumerate(batches):
@@ -126,3 +126,79 @@ def test_two_rank_training_matches_reference(golden, name, port, defer):
     assert not np.array_equal(got[0]["top_b"][0], got[1]["top_b"][0])
     for k in range(len(g["ln_emb"])):
         np.testing.assert_allclose(float(host[k].double().sum()), float(g[f"host_sum_{k}"]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("world,port,defer,name", [(3, 29816, True, "train_w2_mean"), (8, 29817, False, "train_w2_freq1"),
+                                                   (8, 29818, True, "train_w2_max")])
+def test_three_and_eight_rank_training_matches_oracle(golden, world, port, defer, name):
+    """World sizes the reference's goldens do not cover (they are 2-process runs): 8 ranks -- the node the bench targets --
+    and 3, where `lbs = ceil(B / world)` leaves the last rank a SHORT slice (32 = 11 + 11 + 10).  Checked against the
+    oracle's W-rank emulation (pinned on the reference's 1- and 2-process goldens; same code at any W): per-rank losses,
+    shared tag state, identical weight replicas, per-rank biases, host tables after rank 0's write-backs."""
+    from oracle import cdlrm_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import make_batches as oracle_batches
+    g = golden(name)
+    ln_emb = [int(x) for x in g["ln_emb"]]
+    L, m_spa = int(g["L"]), int(g["m_spa"])
+    ln_top = np.array([m_spa + (len(ln_emb) + 1) * len(ln_emb) // 2] + list(g["top"]))
+    tr = O.OracleTrainer(ln_emb, m_spa, g["ln_bot"], ln_top, cache_size=int(g["cache_size"]), num_ways=int(g["ways"]),
+                         mini_batch_size=int(g["B"]), world_size=world, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]),
+                         lookahead=L, table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]), seed=int(g["seed"]))
+    ob = oracle_batches(g)
+    for j, (X, lS_o, lS_i, Tt) in enumerate(ob):
+        if j % L == 0:
+            torch.manual_seed(5000 + j)
+            tr.refill(torch.cat([b[2] for b in ob[j:j + L]], dim=1))
+        tr.step(j, X, lS_o, lS_i, Tt)
+    np.random.seed(int(g["seed"]))
+    host = [h.share_memory_() for h in O.init_host_tables(ln_emb, m_spa)]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, host, ret, defer)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, payload = ret.get(timeout=400)
+        assert "error" not in payload, payload["error"]
+        got[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], np.array([l[r] for l in tr.losses]), rtol=1e-5)
+        for k in range(len(ln_emb)):
+            assert np.array_equal(got[r]["occ"][k], tr.occ[k].numpy()), (r, k)
+        for i in range(len(got[r]["top_w"])):
+            np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(got[r]["top_b"][i], tr.top[r][1][i].numpy(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(got[r]["top_w"][i], got[0]["top_w"][i], rtol=0, atol=0)     # replicas agree bit for bit
+    for k in range(len(ln_emb)):
+        np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("n", [0, 1, 5, 7, 8, 9, 1000, 1001, 4099])
+def test_shard_ranges_tile_a_plan_list(world, n):
+    """WindowPipeline._shard_range, the slice of a plan list rank r fetches: the ranges tile [0, n) without overlap, rank r's
+    starts at r * chunk -- where the in-place all_gather_into_tensor of commit() expects it -- and a list whose padded length
+    world * chunk does not fit the buffer is fetched whole (None).  Remainder cases: n not a multiple of world, ranks whose
+    range is empty."""
+    import cdlrm_amd.engine as engine
+    cap = 4100
+    got = np.full(cap, -1)
+    for r in range(world):
+        p = engine.WindowPipeline.__new__(engine.WindowPipeline)
+        p.shard, p.world, p.rank = True, world, r
+        sh = p._shard_range(n, cap)
+        chunk = -(-n // world) if n else 0
+        if n == 0 or chunk * world > cap:
+            assert sh is None
+            continue
+        c, lo, hi = sh
+        assert c == chunk and lo == min(r * chunk, n) and hi == min(lo + chunk, n) and lo <= hi
+        assert (got[lo:hi] == -1).all()
+        got[lo:hi] = r
+        assert hi - lo <= chunk and r * chunk + (hi - lo) <= cap
+    if n and -(-n // world) * world <= cap:
+        assert (got[:n] >= 0).all() and (got[n:] == -1).all()

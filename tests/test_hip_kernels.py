@@ -651,6 +651,48 @@ def test_qr_embedding_bag_golden(ops, golden):
     assert int(g["big_q"][4]) == 10_000_000
 
 
+def test_qr_embedding_bag_c4_table_size(ops, golden):
+    """The QR operator at BASELINE configs[3]'s table size: 39 884 406 categories, 4 collisions (a 9 971 102-row, 10 GB
+    quotient table), embed-dim 256, lookups above 2**24 -- against the reference's module run at that size
+    (tools/make_golden.py:g_qr_c4; the table contents are the generator's formula, restated here on the device)."""
+    from cdlrm_amd.tricks.qr_embedding_bag import QREmbeddingBag
+    g = golden("qr_c4")
+    n, c, D = int(g["n"]), int(g["c"]), int(g["D"])
+    rows_q = -(-n // c)
+
+    def table(rows, salt):
+        out = torch.empty(rows, D, dtype=torch.float32, device=DEV)
+        d = torch.arange(D, dtype=torch.int64, device=DEV).view(1, -1)
+        for r0 in range(0, rows, 1 << 20):
+            i = torch.arange(r0, min(rows, r0 + (1 << 20)), dtype=torch.int64, device=DEV).view(-1, 1)
+            out[r0:r0 + i.shape[0]] = ((i * 37 + d * 11 + salt) & 1023).to(torch.float32) / 1024.0 - 0.5
+        return out
+
+    wq, wr = table(rows_q, 5), table(c, 901)
+    idx, offs, G = t(g["idx"]).to(DEV), t(g["offs"]).to(DEV), t(g["G"]).to(DEV)
+    rows = t(g["mult_gq_rows"]).to(DEV)
+    assert torch.equal(torch.unique(t(g["q"])).to(DEV), rows)
+    for op in ("mult", "add"):
+        E = QREmbeddingBag(n, D, c, operation=op, mode="sum", sparse=True, _weight=[wq, wr])
+        V = E(idx, offs)
+        np.testing.assert_allclose(V.detach().cpu().numpy(), g[f"{op}_V"], rtol=1e-6, atol=1e-6)
+        V.backward(G)
+        gq = E.weight_q.grad
+        # the rows the float32 quotients address (39884403 / 4 -> 9971101, not 9971100), and nothing else
+        touched = torch.zeros(rows_q, dtype=torch.bool, device=DEV)
+        touched[rows] = True
+        assert float(gq[~touched].abs().max()) == 0.0
+        if op == "mult":
+            np.testing.assert_allclose(gq[rows].cpu().numpy(), g["mult_gq_vals"], rtol=1e-5, atol=1e-6)
+        else:
+            np.testing.assert_allclose(gq[rows].double().sum(dim=1).cpu().numpy(), g["add_gq_rowsum"], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(E.weight_r.grad.cpu().numpy(), g[f"{op}_gr"], rtol=1e-5, atol=1e-4)
+        E.weight_q.grad = E.weight_r.grad = None
+        del E, gq, V
+    del wq, wr
+    torch.cuda.empty_cache()
+
+
 def test_md_embedding_bag_golden(ops, golden):
     """PrEmbeddingBag (mixed-dimension trick) forward + gradients vs the reference's module: widths 1, 2, 4, 8, with and
     without the projection, empty bags; md_solver's widths vs the reference's."""

@@ -247,7 +247,7 @@ def test_loss_trajectory_w1(golden, name):
         np.testing.assert_allclose(tr.top[0][0][i].numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["train_c3shape", "train_c2shape", "train_c5shape"])
+@pytest.mark.parametrize("name", ["train_c3shape", "train_c2shape", "train_c5shape", "train_c4shape"])
 def test_loss_trajectory_config_shapes(golden, name):
     """The oracle at the bench configurations' SHAPES (26 Criteo-cardinality tables, D = 128 / 32, 16- / 8-way, the
     configs' MLP widths; tools/make_golden.py:g_train_shapes) against the imported reference's run."""
@@ -297,6 +297,38 @@ def test_qr_operator(golden):
         V.backward(t(g[f"{op}_G"]))
         np.testing.assert_allclose(wq.grad.numpy(), g[f"{op}_gq"], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(wr.grad.numpy(), g[f"{op}_gr"], rtol=1e-6, atol=1e-7)
+
+
+def qr_c4_rows(rows, D, salt):
+    """tools/make_golden.py:qr_c4_weights for a list of rows (the 10 GB table itself is not stored)."""
+    i = torch.as_tensor(rows, dtype=torch.int64).view(-1, 1)
+    d = torch.arange(D, dtype=torch.int64).view(1, -1)
+    return ((i * 37 + d * 11 + salt) & 1023).to(torch.float32) / 1024.0 - 0.5
+
+
+def test_qr_operator_c4_table_size(golden):
+    """BASELINE configs[3]'s table size (39.9 M categories, D = 256): the oracle's quotient arithmetic on ids above 2**24
+    against the reference's, and its outputs / gradients on the rows those quotients address (compact copy of the touched
+    rows: idx' = compact_row * c + r keeps both the quotient and the remainder of every lookup)."""
+    g = golden("qr_c4")
+    c, D = int(g["c"]), int(g["D"])
+    idx, offs = t(g["idx"]), t(g["offs"])
+    q = (idx / c).long()
+    assert torch.equal(q, t(g["q"])) and int((q != t(g["q_exact"])).sum()) > 30
+    rows, inv = torch.unique(q, return_inverse=True)
+    idx_c = inv * c + torch.remainder(idx, c)
+    for op in ("mult", "add"):
+        wq = qr_c4_rows(rows, D, 5).requires_grad_(True)
+        wr = qr_c4_rows(torch.arange(c), D, 901).requires_grad_(True)
+        V = O.qr_embedding_bag(idx_c, offs, wq, wr, c, op)
+        np.testing.assert_allclose(V.detach().numpy(), g[f"{op}_V"], rtol=1e-6, atol=1e-6)
+        V.backward(t(g["G"]))
+        assert torch.equal(rows, t(g[f"{op}_gq_rows"]))
+        if op == "mult":
+            np.testing.assert_allclose(wq.grad.numpy(), g[f"{op}_gq_vals"], rtol=1e-5, atol=1e-6)
+        else:
+            np.testing.assert_allclose(wq.grad.double().sum(dim=1).numpy(), g[f"{op}_gq_rowsum"], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(wr.grad.numpy(), g[f"{op}_gr"], rtol=1e-5, atol=1e-4)
 
 
 def test_md_operator(golden):

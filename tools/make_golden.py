@@ -565,6 +565,10 @@ def g_train_shapes(M, MD, CM, QR):
         # c5: more than 8192 lookups per table and step (the slot sort takes its merge passes), 16-way
         "train_c5shape": dict(ln_emb=cap(TERABYTE, 40000), m_spa=128, ln_bot=[13, 512, 256, 128], top=[512, 512, 256, 1],
                               cache_size=4000, ways=16, B=12288, L=2, nbatch=6, seed=33, lr=0.8, lr_emb=0.8, alpha=1.05),
+        # c4 (BASELINE configs[3]): embed-dim 256 -- bot 13-512-256-256, a 256 + 351 = 607-wide top input (608-pitch), 26 tables
+        # x 16-way, 1024-byte cache rows; the QR operator itself is stand-alone in the reference (g_qr / g_qr_c4)
+        "train_c4shape": dict(ln_emb=cap(TERABYTE, 40000), m_spa=256, ln_bot=[13, 512, 256, 256], top=[512, 512, 256, 1],
+                              cache_size=1500, ways=16, B=1024, L=3, nbatch=9, seed=34, lr=0.8, lr_emb=0.8, alpha=1.05),
     }
     torch.set_num_threads(1)
     for name, c in cfgs.items():
@@ -737,6 +741,54 @@ def g_qr(M, MD, CM, QR):
     save("qr", **out)
 
 
+def qr_c4_weights(rows, D, salt):
+    """Deterministic table contents for fixtures whose tables are too large to store: w[i, d] = ((37 i + 11 d + salt) mod
+    1024) / 1024 - 0.5 -- exact in float32 on any device (tests/test_hip_kernels.py restates the formula)."""
+    out = torch.empty(rows, D, dtype=torch.float32)
+    d = torch.arange(D, dtype=torch.int64).view(1, -1)
+    for r0 in range(0, rows, 1 << 20):
+        i = torch.arange(r0, min(rows, r0 + (1 << 20)), dtype=torch.int64).view(-1, 1)
+        out[r0:r0 + i.shape[0]] = ((i * 37 + d * 11 + salt) & 1023).to(torch.float32) / 1024.0 - 0.5
+    return out
+
+
+def g_qr_c4(M, MD, CM, QR):
+    """The QR operator at BASELINE configs[3]'s table size: the largest Terabyte table (39 884 406 categories, 4 collisions
+    -> a 9 971 102-row quotient table), embed-dim 256, lookups mostly above 2**24 where `(input / c).long()` is a float32
+    division (tricks/qr_embedding_bag.py:157).  Table contents come from qr_c4_weights (10 GB: not stored); the fixture
+    holds indices, outputs and the SPARSE weight gradients."""
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(8)
+    n, D, c = 39884406, 256, 4
+    rows_q = math.ceil(n / c)
+    wq = qr_c4_weights(rows_q, D, 5)
+    wr = qr_c4_weights(c, D, 901)
+    torch.set_num_threads(1)
+    rng = np.random.RandomState(44)
+    idx = rng.randint(0, n, size=1024).astype(np.int64)
+    idx[:8] = [0, 16777217, 33554433, 39884403, 39884405, 25000003, 16777216, 3]
+    idx[8:64] = idx[:56]                                   # repeats: gradient rows accumulate
+    idx = torch.from_numpy(idx)
+    offs = torch.arange(0, 1024, 4, dtype=torch.int64)
+    out = dict(n=n, c=c, D=D, idx=idx, offs=offs, q=(idx / c).long(), q_exact=idx // c)
+    G = torch.from_numpy(rng.randn(offs.numel(), D).astype(np.float32))
+    out["G"] = G
+    for op in ("mult", "add"):
+        E = QR.QREmbeddingBag(n, D, c, operation=op, mode="sum", sparse=True, _weight=[wq, wr])
+        V = E(idx, offs)
+        V.backward(G)
+        gq = E.weight_q.grad.coalesce()
+        out.update({f"{op}_V": V.detach(), f"{op}_gq_rows": gq.indices()[0], f"{op}_gr": E.weight_r.grad.to_dense()})
+        if op == "mult":
+            out[f"{op}_gq_vals"] = gq.values()
+        else:       # (for "add" a quotient row's gradient is a plain sum of G rows: a per-row checksum pins it)
+            out[f"{op}_gq_rowsum"] = gq.values().double().sum(dim=1)
+        E.weight_q.grad = E.weight_r.grad = None
+    assert int((out["q"] != out["q_exact"]).sum()) > 30     # the float32-division quirk is exercised
+    save("qr_c4", **out)
+    torch.set_num_threads(nthreads)
+
+
 def g_md(M, MD, CM, QR):
     """Mixed-dimension trick: md_solver on a few size lists, PrEmbeddingBag forward/backward with and without the
     projection, including widths 1 and 2."""
@@ -843,7 +895,7 @@ def g_criteo_loader(M, MD, CM, QR):
 
 GENS = dict(criteo_loader=g_criteo_loader, isprime=g_isprime, appendix_a=g_appendix_a, writeback=g_writeback, init=g_init, dense=g_dense,
             dense_variants=g_dense_variants, random_data=g_random_data, synthetic_data=g_synthetic_data,
-            embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_shapes=g_train_shapes, train_w2=g_train_w2, qr=g_qr, md=g_md,
+            embbag_sgd=g_embbag_sgd, train_w1=g_train_w1, train_shapes=g_train_shapes, train_w2=g_train_w2, qr=g_qr, qr_c4=g_qr_c4, md=g_md,
             window_groups=g_window_groups)
 
 
