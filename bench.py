@@ -157,13 +157,13 @@ def build_workload(config, *, lookahead=-1, batch=-1, host=None, seed=123, dev=N
     if defer_top is None:
         # one GPU: the step no longer ends on a wait for the top MLP's weight gradients (0.724 -> 0.716 ms at c3, round 2);
         # with more ranks it takes the top MLP's all-reduce off the critical path
-        defer_top = os.environ.get("CDLRM_DEFER_TOP", "1") != "0"
+        defer_top = True
     eng = TrainEngine(cg, dl, host, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], world_size=world, rank=rank,
                       table_agg_freq=cfg["agg"], table_agg_op="mean", defer_top_update=defer_top)
     # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
     # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
     pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=seed, rank=rank, world_size=world,
-                          host_gather=os.environ.get("CDLRM_HOST_GATHER", "1") != "0",
+                          host_gather=True,
                           gather_threads=max(4, min(32, (os.cpu_count() or 8) // max(1, world))), write_back=write_back)
     syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=seed, alpha=alpha, device=dev)
     return dict(cfg=cfg, ln_emb=ln_emb, host=host, cg=cg, dl=dl, eng=eng, pipe=pipe, syn=syn, B=B, L=L, D=D)
@@ -206,11 +206,9 @@ def main():
     lbs = math.ceil(B / world)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
-    prio = int(os.environ.get("CDLRM_MAIN_PRIORITY", "-1"))
-    if prio != 0:
-        # the step's critical-path queue outranks the side queues (weight gradients, embedding backward, take): where they
-        # compete for CUs the critical path goes first (c3: 0.685 -> 0.673 ms); the side work has slack until the next step
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=prio))
+    # the step's critical-path queue outranks the side queues (weight gradients, embedding backward, take): where they
+    # compete for CUs the critical path goes first (c3: 0.685 -> 0.673 ms); the side work has slack until the next step
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 
     total_steps = a.warmup + a.steps
     # The synthetic index stream is the input: generate it BEFORE the timed region (windows of L batches, int64
@@ -237,7 +235,7 @@ def main():
         return pregen[w] if w in pregen else syn.window(w, L)
 
     from cdlrm_amd.engine import WindowResolver
-    use_resolver = os.environ.get("CDLRM_WINDOW_RESOLVE", "1") != "0"
+    use_resolver = True
     state = {"win": None, "next": None, "w": -1}
     plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
     ev_pairs = []

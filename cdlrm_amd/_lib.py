@@ -86,7 +86,6 @@ PROTOTYPES = {
     "cdlrm_agg_scatter": (C.c_int, [vp, vp, vp, vp, c_i64, c_i64, vp]),
     "cdlrm_interact_fwd": (C.c_int, [vp, c_i64, c_i32, c_i32, c_i32, vp, c_i64, vp]),
     "cdlrm_interact_bwd": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp]),
-    "cdlrm_interact_bwd_rows": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp]),
     "cdlrm_linear_fwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp]),
     "cdlrm_linear_bwd_work_bytes": (c_u64, [c_i64, c_i32, c_i32]),
     "cdlrm_linear_bwd": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i32, c_i32,
@@ -107,10 +106,6 @@ PROTOTYPES = {
     "cdlrm_scatter_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, C.c_int, vp]),
     "cdlrm_blend_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_mark_rows": (C.c_int, [vp, vp, c_i64, vp, vp]),
-    "cdlrm_chain_sync_ints": (c_i64, []),
-    "cdlrm_chain_err_index": (c_i64, []),
-    "cdlrm_mlp_fwd_chain": (C.c_int, [c_i32, vp, c_i64, vp, vp, vp, vp, c_i64, vp, vp, vp, vp, vp]),
-    "cdlrm_mlp_dgrad_chain": (C.c_int, [c_i32, vp, c_i64, vp, vp, vp, vp, vp, vp, c_i64, vp, vp, vp, vp]),
     "cdlrm_tape_create": (vp, [c_i32]),
     "cdlrm_tape_destroy": (None, [vp]),
     "cdlrm_tape_add": (C.c_int, [vp, vp, c_i32, vp, vp, c_i32, vp]),
@@ -145,10 +140,13 @@ class _Recording:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)          # AttributeError for an unknown symbol
+        # size / geometry queries (cdlrm_*_work_bytes, ...: anything that does not return a status code) issue nothing: a
+        # recorded step that happens to allocate its scratch does not put them on its tape
+        is_call = fn.restype is C.c_int
 
         def call(*args):
             tape = getattr(_rec, "tape", None)
-            if tape is not None:
+            if tape is not None and is_call:
                 tape.append((fn, args))
             return fn(*args)
 
@@ -211,10 +209,10 @@ _native_ok: Optional[bool] = None
 
 
 def native_tape_ok() -> bool:
-    """csrc/tape.hip's generic call works on this machine (x86-64 System V) and is not switched off."""
+    """csrc/tape.hip's typed call passes its self-test."""
     global _native_ok
     if _native_ok is None:
-        _native_ok = os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0" and raw().cdlrm_tape_selftest() == 0
+        _native_ok = raw().cdlrm_tape_selftest() == 0
     return _native_ok
 
 
@@ -243,7 +241,8 @@ class NativeTape:
             L.cdlrm_tape_destroy(h)
             self._h = None
             raise
-        self._cells = (C.c_int64 * max(1, len(order))).from_address(L.cdlrm_tape_cells(h))
+        addr = L.cdlrm_tape_cells(h) if order else None     # (a tape without cells has no cell array)
+        self._cells = (C.c_int64 * len(order)).from_address(addr) if addr else None
         self._replay = L.cdlrm_tape_replay
 
     def _translate(self, fn, args, torch):
@@ -302,7 +301,7 @@ class NativeTape:
         FA = (C.c_float * max(1, len(fa)))(*fa)
         rc = L.cdlrm_tape_add(self._h, C.cast(fn, C.c_void_p), n, IA, CI, len(fa), FA)
         if rc:
-            raise TapeUnsupported(L.cdlrm_last_error().decode("utf-8", "replace"))
+            raise TapeUnsupported("%s: %s" % (getattr(fn, "__name__", fn), L.cdlrm_last_error().decode("utf-8", "replace")))
 
     def replay(self) -> int:
         """Patch the cells from the shared ctypes cells the Python tape uses, re-issue the step."""

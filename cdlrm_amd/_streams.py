@@ -31,12 +31,9 @@ def is_hip(device) -> bool:
 
 
 def new_stream(device, priority=None):
-    """A side stream; CDLRM_SIDE_PRIORITY (an integer, lower = more urgent) sets the priority of all of them."""
+    """A side stream (default priority: the trainer's own queue is created at high priority, see main_no_ddp.Run)."""
     if not is_hip(device):
         return _NullStream()
-    import os
-    if priority is None and os.environ.get("CDLRM_SIDE_PRIORITY"):
-        priority = int(os.environ["CDLRM_SIDE_PRIORITY"])
     return torch.cuda.Stream(device=device) if priority is None else torch.cuda.Stream(device=device, priority=priority)
 
 

@@ -5,7 +5,6 @@
 // fp32 everywhere (1e-5 loss-trajectory parity): v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32
 // fma chain at the fp32 vector peak (MI355X_MICROARCH.md "Matrix cores").
 #include "gemm_glds.h"
-#include "chain.h"
 
 
 // Linear forward with a short contraction (K <= 32: the first bottom layer reads the 13 dense features).  An MFMA
@@ -80,127 +79,6 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
     g.vecA = aligned16(X) && ld_x % 4 == 0 && K % 4 == 0;
     g.vecB = aligned16(W) && K % 4 == 0;
     return launch_gemm<true, true>(g, 1, (hipStream_t)stream);
-}
-
-// ---- layer chains (local batches <= 2048) ----------------------------------------------------------------------
-extern "C" int64_t cdlrm_chain_sync_ints(void) { return CHAIN_SYNC_INTS; }
-extern "C" int64_t cdlrm_chain_err_index(void) { return CHAIN_ERR; }
-
-static bool chain_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("CDLRM_MLP_CHAIN");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return on != 0;
-}
-
-// Y[i] = act_i(Y[i-1] W[i]^T + b[i]), Y[-1] = X: n consecutive Linear layers (main_no_ddp.py / model_no_ddp.py:264-283, one
-// nn.Sequential) -- one launch when the chain applies (sync != NULL, M <= 2048, every layer on the staged kernel's shape
-// conditions), layer by layer through cdlrm_linear_fwd otherwise.  Same arithmetic per element either way.
-extern "C" int cdlrm_mlp_fwd_chain(int32_t n, const float* X, int64_t ld_x, const float* const* W, const float* const* bias,
-                                   float* const* Y, const int64_t* ld_y, int64_t M, const int32_t* N, const int32_t* K,
-                                   const int32_t* act, int32_t* sync, void* stream) {
-    CDLRM_REQUIRE(n >= 0 && (n == 0 || (X && W && bias && Y && ld_y && N && K && act)) && M >= 0, "bad argument");
-    if (n == 0 || M == 0) return 0;
-    ChainArgs c;
-    memset(&c, 0, sizeof(c));
-    bool ok = sync != nullptr && chain_enabled() && n <= CHAIN_MAX_OPS && n >= 2;
-    const float* in = X;
-    int64_t ld_in = ld_x;
-    for (int i = 0; i < n; ++i) {
-        CDLRM_REQUIRE(W[i] && Y[i] && N[i] >= 1 && K[i] >= 1 && ld_in >= K[i] && ld_y[i] >= N[i], "bad layer argument");
-        CDLRM_REQUIRE(i == 0 || K[i] == N[i - 1], "layer i reads layer i-1's output");
-        if (ok) {
-            GemmArgs g = gemm_args();
-            g.A = in; g.lda = ld_in; g.B = W[i]; g.ldb = K[i]; g.C = Y[i]; g.ldc = ld_y[i]; g.slab = 0;
-            g.M = M; g.N = N[i]; g.K = K[i]; g.kchunk = K[i]; g.bias = bias[i]; g.act = act[i];
-            g.vecA = aligned16(in) && ld_in % 4 == 0 && K[i] % 4 == 0;
-            g.vecB = aligned16(W[i]) && K[i] % 4 == 0;
-            g.vecC = aligned16(Y[i]) && ld_y[i] % 4 == 0;
-            ok = chain_layer_ok<true, true>(g);
-            c.g[i] = g;
-            c.ntn[i] = (int)cdiv(N[i], 32);
-            c.mode[i] = direct_mode(K[i], true);
-        }
-        in = Y[i];
-        ld_in = ld_y[i];
-    }
-    if (ok) {
-        c.n_ops = n;
-        c.rbs = (int)cdiv(M, 32);
-        c.sync = sync;
-        return launch_chain<true, true>(c, (hipStream_t)stream);
-    }
-    in = X;
-    ld_in = ld_x;
-    for (int i = 0; i < n; ++i) {
-        int rc = cdlrm_linear_fwd(in, ld_in, W[i], bias[i], Y[i], ld_y[i], M, N[i], K[i], act[i], stream);
-        if (rc) return rc;
-        in = Y[i];
-        ld_in = ld_y[i];
-    }
-    return 0;
-}
-
-// The input-gradient chain of n consecutive layers, top-most first: dX[i][M, K[i]] = dZ[i] W[i] (W[i] is [N[i], K[i]]),
-// times the derivative of the activation that produced the layer's input Xin[i] (x_act[i]; 0: none), and dZ[i+1] = dX[i]
-// (so N[i+1] == K[i]); dZ[0] = dY.  What cdlrm_linear_bwd(dW = NULL) does layer after layer, in one launch when the chain
-// applies.
-extern "C" int cdlrm_mlp_dgrad_chain(int32_t n, const float* dY, int64_t ld_dy, const float* const* W,
-                                     const float* const* Xin, const int64_t* ld_xin, const int32_t* x_act,
-                                     float* const* dX, const int64_t* ld_dx, int64_t M, const int32_t* N, const int32_t* K,
-                                     int32_t* sync, void* stream) {
-    CDLRM_REQUIRE(n >= 0 && (n == 0 || (dY && W && Xin && ld_xin && x_act && dX && ld_dx && N && K)) && M >= 0, "bad argument");
-    if (n == 0 || M == 0) return 0;
-    ChainArgs c;
-    memset(&c, 0, sizeof(c));
-    bool ok = sync != nullptr && chain_enabled() && n <= CHAIN_MAX_OPS && n >= 2;
-    const float* in = dY;
-    int64_t ld_in = ld_dy;
-    for (int i = 0; i < n; ++i) {
-        CDLRM_REQUIRE(W[i] && dX[i] && N[i] >= 1 && K[i] >= 1 && ld_in >= N[i] && ld_dx[i] >= K[i], "bad layer argument");
-        CDLRM_REQUIRE(x_act[i] >= 0 && x_act[i] <= 2 && (x_act[i] == 0 || (Xin[i] && ld_xin[i] >= K[i])), "bad activation / input");
-        CDLRM_REQUIRE(i == 0 || N[i] == K[i - 1], "layer i reads layer i-1's input gradient");
-        if (i < CHAIN_MAX_OPS) {
-            GemmArgs g = gemm_args();
-            g.A = in; g.lda = ld_in; g.B = W[i]; g.ldb = K[i]; g.C = dX[i]; g.ldc = ld_dx[i]; g.slab = 0;
-            g.M = M; g.N = K[i]; g.K = N[i]; g.kchunk = N[i]; g.bias = nullptr; g.act = 0;
-            g.vecA = aligned16(in) && ld_in % 4 == 0 && N[i] % 4 == 0;
-            g.vecB = aligned16(W[i]) && K[i] % 4 == 0;
-            g.vecC = aligned16(dX[i]) && ld_dx[i] % 4 == 0;
-            g.mask = x_act[i] ? Xin[i] : nullptr; g.ldmask = ld_xin[i]; g.mask_act = x_act[i];
-            if (ok) {
-                ok = chain_layer_ok<true, false>(g);
-                c.g[i] = g;
-                c.ntn[i] = (int)cdiv(K[i], 32);
-                c.mode[i] = direct_mode(N[i], true);
-            }
-        }
-        in = dX[i];
-        ld_in = ld_dx[i];
-    }
-    if (ok) {
-        c.n_ops = n;
-        c.rbs = (int)cdiv(M, 32);
-        c.sync = sync;
-        return launch_chain<true, false>(c, (hipStream_t)stream);
-    }
-    in = dY;
-    ld_in = ld_dy;
-    for (int i = 0; i < n; ++i) {
-        GemmArgs g = gemm_args();
-        g.A = in; g.lda = ld_in; g.B = W[i]; g.ldb = K[i]; g.C = dX[i]; g.ldc = ld_dx[i]; g.slab = 0;
-        g.M = M; g.N = K[i]; g.K = N[i]; g.kchunk = N[i]; g.bias = nullptr; g.act = 0;
-        g.vecA = aligned16(in) && ld_in % 4 == 0 && N[i] % 4 == 0;
-        g.vecB = aligned16(W[i]) && K[i] % 4 == 0;
-        g.mask = x_act[i] ? Xin[i] : nullptr; g.ldmask = ld_xin[i]; g.mask_act = x_act[i];
-        int rc = launch_gemm<true, false>(g, 1, (hipStream_t)stream);
-        if (rc) return rc;
-        in = dX[i];
-        ld_in = ld_dx[i];
-    }
-    return 0;
 }
 
 // ---- backward helpers -----------------------------------------------------------------------------
@@ -298,11 +176,7 @@ __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup grp) {
 static int wgrad_splits(int64_t M, int N, int K) {
     if (M <= WGRAD_DIRECT_MAX_M) return 1;
     const int64_t tiles = cdiv(N, 64) * cdiv(K, 64);    // the 64x64 tile launch_gemm picks for these shapes
-    static int64_t target = 0;
-    if (target == 0) {
-        const char* e = getenv("CDLRM_WGRAD_TARGET");
-        target = e && atol(e) > 0 ? atol(e) : 1024;
-    }
+    const int64_t target = 1024;        // measured at c3: 512 -> 0.687 ms/step, 1024 -> 0.668, 2048 the same
     int64_t s = cdiv(target, tiles);                  // aim at ~4 workgroups of 64x64 per CU (2 of 128x64)
     const int64_t smax = cdiv(M, 8 * GBK);
     if (s > smax) s = smax;
@@ -418,12 +292,8 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
         // Small batches, all layers at once.  Layers whose operands are 16-byte loadable go through the LDS-tiled
         // kernel as ONE grouped launch, the contraction (the batch) cut into slabs so that the group has ~1000
         // workgroups; the rest (13-wide input, 1-wide output) through the grouped LDS-free kernel with the same slabs;
-        // then ONE grouped reduction of all layers (fixed slab order).  CDLRM_WGRAD_TILED=0: everything LDS-free.
-        static int use_tiled = -1;
-        if (use_tiled < 0) {
-            const char* e = getenv("CDLRM_WGRAD_TILED");
-            use_tiled = e ? atoi(e) : 1;
-        }
+        // then ONE grouped reduction of all layers (fixed slab order).  
+        const int use_tiled = 1;
         std::vector<GemmArgs> direct, tiled;
         std::vector<int> direct_layer, tiled_layer;
         int64_t tiles = 0;
@@ -448,11 +318,7 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
         int64_t kchunk = M;
         int zs = 1;
         if (!tiled.empty()) {
-            static int64_t target_wgs = 0;      // workgroups the grouped launch aims at (slabs = target / tiles)
-            if (target_wgs == 0) {
-                const char* e = getenv("CDLRM_WGRAD_WGS");
-                target_wgs = e && atol(e) > 0 ? atol(e) : 1024;
-            }
+            const int64_t target_wgs = 1024;    // workgroups the grouped launch aims at (slabs = target / tiles)
             int64_t splits = cdiv(target_wgs, tiles);
             const int64_t smax = cdiv(M, 4 * GBK);
             if (splits > smax) splits = smax;
@@ -645,7 +511,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd(const float* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ feat, const float* __restrict__ dR,
                                                       int64_t ld_r, int64_t B, int F, int D, int itself, int x_act,
-                                                      float* __restrict__ dfeat, int skip0) {
+                                                      float* __restrict__ dfeat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ldt = D + 1;
@@ -703,7 +569,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd(const float* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (i < F && !(skip0 && i == 0)) {
+                    if (i < F) {
                         float v = acc[r];
                         if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
                             v += gx[col];
@@ -863,93 +729,6 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
     for (b += nw; b < B; b += nw) one(b);
 }
 
-// ---- register-direct forward (D = 32 / 64 / 128) -------------------------------------------------------------
-// The 16x16x4 MFMA wants, of lane l, row l % 16 of a row block and contraction indices 4 (l / 16) .. +3 of every
-// 16-wide group -- exactly one float4 of the feature matrix.  So a lane loads its fragments straight from global memory
-// (per instruction 16 rows x 64 contiguous bytes, the other half of each 128-byte line by the next instruction) and
-// no LDS is involved at all: occupancy is bounded by registers, not by a 17 KB staging slice per wave, and a CU keeps
-// 12-20 samples in flight instead of 8.  Rows >= F are loaded from row F-1 (their products never reach an output).
-template <int D4, bool PREF>
-__global__ void __launch_bounds__(256) k_interact_fwd_r(const float* __restrict__ feat, int64_t B, int F, int itself,
-                                                        float* __restrict__ R, int64_t ld_r, int vec_out) {
-    constexpr int D = 4 * D4, NG = D / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l16 = lane & 15, g4 = lane >> 4;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    int64_t b = (int64_t)blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    const int r0 = min(l16, F - 1), r1 = min(16 + l16, F - 1);
-    const int64_t o0 = (int64_t)r0 * D + 4 * g4, o1 = (int64_t)r1 * D + 4 * g4;
-    const int64_t FD = (int64_t)F * D;
-    v4f c0[NG], c1[NG];
-    {
-        const float* base = feat + b * FD;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            c0[g] = *reinterpret_cast<const v4f*>(base + o0 + 16 * g);
-            c1[g] = *reinterpret_cast<const v4f*>(base + o1 + 16 * g);
-        }
-    }
-    const int off = itself ? 1 : 0;
-    for (; b < B; b += nw) {
-        v4f n0[NG], n1[NG];
-        if (PREF) {
-            const float* base = feat + min(b + nw, B - 1) * FD;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                n0[g] = *reinterpret_cast<const v4f*>(base + o0 + 16 * g);
-                n1[g] = *reinterpret_cast<const v4f*>(base + o1 + 16 * g);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const v4f a0 = c0[g], a1 = c1[g];
-            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a0.x, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a1.x, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, a0.y, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a0.y, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a1.y, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, a0.z, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a0.z, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a1.z, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, a0.w, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a0.w, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, acc11, 0, 0, 0);
-        }
-        float* out = R + b * ld_r;
-        if (l16 == 0) {                             // row 0 = the dense feature, copied through
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float* o = out + 16 * g + 4 * g4;
-                if (vec_out) *reinterpret_cast<v4f*>(o) = c0[g];
-                else { o[0] = c0[g].x; o[1] = c0[g].y; o[2] = c0[g].z; o[3] = c0[g].w; }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // accumulator register r of lane l: tile row 4 (l / 16) + r, tile column l % 16
-            const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
-            if (i0 < F && l16 < i0 + off) out[D + pair_base(i0, itself) + l16] = acc00[r];
-            if (i1 < F) out[D + pair_base(i1, itself) + l16] = acc10[r];
-            if (i1 < F && 16 + l16 < i1 + off) out[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
-        }
-        if (PREF) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) { c0[g] = n0[g]; c1[g] = n1[g]; }
-        } else if (b + nw < B) {
-            const float* base = feat + (b + nw) * FD;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                c0[g] = *reinterpret_cast<const v4f*>(base + o0 + 16 * g);
-                c1[g] = *reinterpret_cast<const v4f*>(base + o1 + 16 * g);
-            }
-        }
-    }
-}
-
 // backward: dR row staged as float4 (needs ld_r % 4 == 0 and a 16-byte aligned dR)
 // STAGED (F > 16): the 32x32 accumulator tile leaves through LDS -- 16 rows at a time into the part of the dR staging
 // row that is dead once the S fragments are built -- as whole float4 words of valid rows only: 4 unconditional, fully
@@ -958,7 +737,7 @@ __global__ void __launch_bounds__(256) k_interact_fwd_r(const float* __restrict_
 template <int D4, bool STAGED>
 __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict__ feat, const float* __restrict__ dR,
                                                         int64_t ld_r, int64_t B, int F, int itself, int x_act,
-                                                        float* __restrict__ dfeat, int skip0) {
+                                                        float* __restrict__ dfeat) {
     constexpr int D = 4 * D4, PITCH = D + 4;
     constexpr int GMAX = D + 528;               // dense part + up to 32*33/2 pair gradients
     constexpr int NG = (GMAX / 4 + 63) / 64;
@@ -1026,7 +805,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
                     for (int rr = 0; rr < 8; ++rr)      // accumulator register 8h + rr: row 16h + (rr&3) + 8 (rr>>2) + 4 lk
                         Os[((rr & 3) + 8 * (rr >> 2) + 4 * lk) * 32 + lr] = acc[8 * h + rr];
                     const int nvalid = min(F - 16 * h, 16) * 8;     // float4 words of valid rows (F > 16: >= 8)
-                    const int first = (h == 0 && skip0) ? 8 : 0;    // skip0: row 0 (the dense feature) is another launch's
+                    const int first = 0;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int idx = first + min(64 * k + lane, nvalid - first - 1);     // clamped: spare lanes repeat the last word
@@ -1039,7 +818,7 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (i < F && !(skip0 && i == 0)) {
+                    if (i < F) {
                         float v = acc[r];
                         if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
                             v += Gs[col];
@@ -1061,44 +840,6 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
     for (; b < B; b += nw) one(b);
 }
 
-// The dense feature's gradient row alone: dX_0 = dR[:D] + sum_j S_0j T_j, times act'(T_0) -- 1/F of the interaction backward's
-// output and the ONLY part the bottom MLP's backward waits for.  As its own launch on the training queue it lets that chain
-// (MFMA-bound, the step's critical path) start beside the rest of the interaction backward (HBM-bound, embedding rows only,
-// on the side queue in front of the embedding backward that consumes it).  D4 lanes x float4 per sample, weighted sum of the
-// F rows in a fixed order (j ascending); the F coefficients S_0j = G[j][0] (+ G[0][0] twice with `itself`) come from the dR row.
-__global__ void __launch_bounds__(256) k_interact_bwd_dense(const float* __restrict__ feat, const float* __restrict__ dR,
-                                                            int64_t ld_r, int64_t B, int F, int D4, int itself, int x_act,
-                                                            float* __restrict__ dfeat) {
-    const int lps = D4;                                     // lanes per sample (D4 = D / 4 <= 64, a power of two here)
-    const int sub = threadIdx.x % lps, grp = threadIdx.x / lps, gpb = blockDim.x / lps;
-    const int D = 4 * D4;
-    const int off = itself ? 1 : 0;
-    for (int64_t b = (int64_t)blockIdx.x * gpb + grp; b < B; b += (int64_t)gridDim.x * gpb) {
-        const float* g = dR + b * ld_r;
-        const v4f* T = reinterpret_cast<const v4f*>(feat + b * F * D) + sub;
-        v4f acc = *reinterpret_cast<const v4f*>(g + 4 * sub);      // the direct path
-        const v4f t0 = T[0];
-        if (itself) {
-            const float s = 2.f * g[D];                             // pair (0, 0)
-            acc += s * t0;
-        }
-#pragma unroll 4
-        for (int j = 1; j < F; ++j) {
-            const float s = g[D + pair_base(j, itself)];            // pair (j, 0): first entry of row j of the triangle
-            acc += s * T[(int64_t)j * D4];
-        }
-        if (x_act == 1) {
-            acc.x = t0.x > 0.f ? acc.x : 0.f; acc.y = t0.y > 0.f ? acc.y : 0.f;
-            acc.z = t0.z > 0.f ? acc.z : 0.f; acc.w = t0.w > 0.f ? acc.w : 0.f;
-        } else if (x_act == 2) {
-            acc.x *= (1.0f - t0.x) * t0.x; acc.y *= (1.0f - t0.y) * t0.y;
-            acc.z *= (1.0f - t0.z) * t0.z; acc.w *= (1.0f - t0.w) * t0.w;
-        }
-        (void)off;
-        reinterpret_cast<v4f*>(dfeat + b * F * D)[sub] = acc;
-    }
-}
-
 template <typename K>
 static int interact_set_lds(K kernel, size_t lds, size_t* cached) {
     if (lds > *cached) {
@@ -1113,35 +854,11 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
     CDLRM_REQUIRE(feat && R && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape (F<=32, D%4==0)");
     CDLRM_REQUIRE(aligned16(feat) && ld_r >= D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2), "alignment / ld_r");
     if (B == 0) return 0;
-    static const int fwd_mode = getenv("CDLRM_INTERACT_FWD") ? atoi(getenv("CDLRM_INTERACT_FWD")) : 0;
-    if (fwd_mode && (D == 32 || D == 64 || D == 128)) {
-        // mode 1: one pass of waves, as many as fit; 2: register prefetch, 3 workgroups per CU
-        const int vec_out = ld_r % 4 == 0 && aligned16(R);
-        int64_t gp = cdiv(B, 4);
-        const int64_t cap = fwd_mode == 2 ? 512 : (fwd_mode == 1 ? 4096 : fwd_mode);
-        if (gp > cap) gp = cap;
-#define IFWDR(D4_)                                                                                             \
-    do {                                                                                                       \
-        if (fwd_mode == 2)                                                                                     \
-            hipLaunchKernelGGL((k_interact_fwd_r<D4_, true>), dim3((unsigned)gp), dim3(256), 0, (hipStream_t)stream, \
-                               feat, B, F, itself, R, ld_r, vec_out);                                          \
-        else                                                                                                   \
-            hipLaunchKernelGGL((k_interact_fwd_r<D4_, false>), dim3((unsigned)gp), dim3(256), 0, (hipStream_t)stream, \
-                               feat, B, F, itself, R, ld_r, vec_out);                                          \
-    } while (0)
-        if (D == 32) IFWDR(8);
-        else if (D == 64) IFWDR(16);
-        else IFWDR(32);
-#undef IFWDR
-        CDLRM_LAUNCH_CHECK();
-        return 0;
-    }
     if (D == 32 || D == 64 || D == 128 || D == 256) {
         const size_t ldsp = (size_t)4 * 32 * (D + 4) * sizeof(float);
         const int width_p = D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2);
         // whole-float4 output rows: the 32-row staging slice must hold one (F >= 4 does), the row pitch its last word
-        const int vec_out_p = ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width_p + 3) & ~3) && width_p + 4 <= 32 * (D + 4) &&
-                              !getenv("CDLRM_INTERACT_SCALAR_OUT");
+        const int vec_out_p = ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width_p + 3) & ~3) && width_p + 4 <= 32 * (D + 4);
         int64_t gp = cdiv(B, 4);
         if (gp > 512) gp = 512;             // 2 workgroups per CU (LDS), each wave streams ~4 samples
         static size_t a32 = 0, a64 = 0, a128 = 0, a256 = 0, a32v = 0, a64v = 0, a128v = 0, a256v = 0;
@@ -1178,32 +895,18 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
     return 0;
 }
 
-// rows: 0 all F gradient rows, 1 the dense feature's row (row 0) only, 2 all but row 0
-extern "C" int cdlrm_interact_bwd_rows(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
-                                       int32_t itself, int32_t x_act, float* dfeat, int32_t rows, void* stream) {
+extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
+                                  int32_t itself, int32_t x_act, float* dfeat, void* stream) {
     CDLRM_REQUIRE(feat && dR && dfeat && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape");
     CDLRM_REQUIRE(aligned16(feat), "alignment");
-    CDLRM_REQUIRE(rows >= 0 && rows <= 2, "rows: 0 all, 1 dense row only, 2 all but the dense row");
     if (B == 0) return 0;
     const int npairs = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    if (rows == 1) {
-        const int D4 = D / 4;
-        CDLRM_REQUIRE((D4 & (D4 - 1)) == 0 && D4 <= 64 && aligned16(dR) && aligned16(dfeat) && ld_r % 4 == 0 &&
-                          ld_r >= D + npairs, "dense-row launch: D / 4 a power of two <= 64, 16-byte aligned dR rows");
-        int64_t gx = cdiv(B, 256 / D4);
-        if (gx > 4096) gx = 4096;
-        hipLaunchKernelGGL(k_interact_bwd_dense, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, feat, dR, ld_r, B,
-                           (int)F, D4, (int)itself, (int)x_act, dfeat);
-        CDLRM_LAUNCH_CHECK();
-        return 0;
-    }
-    const int skip0 = rows == 2;
     if ((D == 32 || D == 64 || D == 128) && ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3)) {
         const size_t ldsp = (size_t)4 * (32 * (D + 4) + D + 528) * sizeof(float);
         int64_t gp = cdiv(B, 4);
         if (gp > 512) gp = 512;
         static size_t b32 = 0, b64 = 0, b128 = 0, b32s = 0, b64s = 0, b128s = 0;
-        const bool staged = F > 16 && aligned16(dfeat) && !getenv("CDLRM_INTERACT_SCALAR_OUT");
+        const bool staged = F > 16 && aligned16(dfeat);
 #define IBWD(D4_, A_)                                                                                          \
     do {                                                                                                       \
         int rc = interact_set_lds(k_interact_bwd_p<D4_, false>, ldsp, &A_);                                    \
@@ -1211,10 +914,10 @@ extern "C" int cdlrm_interact_bwd_rows(const float* feat, const float* dR, int64
         if (rc) return rc;                                                                                     \
         if (staged)                                                                                            \
             hipLaunchKernelGGL((k_interact_bwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, dR, ld_r, B, F, itself, x_act, dfeat, skip0);                             \
+                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                             \
         else                                                                                                   \
             hipLaunchKernelGGL((k_interact_bwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, dR, ld_r, B, F, itself, x_act, dfeat, skip0);                             \
+                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                             \
     } while (0)
         if (D == 32) IBWD(8, b32);
         else if (D == 64) IBWD(16, b64);
@@ -1233,14 +936,9 @@ extern "C" int cdlrm_interact_bwd_rows(const float* feat, const float* dR, int64
     int64_t gx = cdiv(B, 4);
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(k_interact_bwd, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, feat, dR, ld_r, B, F, D,
-                       itself, x_act, dfeat, skip0);
+                       itself, x_act, dfeat);
     CDLRM_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
-                                  int32_t itself, int32_t x_act, float* dfeat, void* stream) {
-    return cdlrm_interact_bwd_rows(feat, dR, ld_r, B, F, D, itself, x_act, dfeat, 0, stream);
 }
 
 // =================================================================================================

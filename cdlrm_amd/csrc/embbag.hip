@@ -239,37 +239,7 @@ __global__ void __launch_bounds__(256) k_fill_aux(const TableDesc* __restrict__ 
 // holds 64/LPR bags per step and UNROLL steps in flight (independent slot -> row -> store chains).
 // Algorithmic bytes per lookup (Criteo layout): 4D row read + 4D output write + 8 index + 8 offset.
 // ---------------------------------------------------------------------------------------------
-#define FWD_UNROLL 4
-template <int LPR>
-__global__ void __launch_bounds__(256) k_embbag_fwd_arange(const TableDesc* __restrict__ tab, int D4,
-                                                           const float4* __restrict__ weight,
-                                                           const int32_t* __restrict__ slots, int64_t n,
-                                                           float* __restrict__ out, int64_t ld_bag, int64_t ld_table) {
-    const int t = blockIdx.y;
-    const int64_t row_base = tab[t].row_base;
-    const int c = threadIdx.x % LPR;
-    const int gpb = blockDim.x / LPR;
-    const int gid = threadIdx.x / LPR;
-    const int32_t* sl = slots + (int64_t)t * n;
-    float* o = out + (int64_t)t * ld_table;
-    for (int64_t b0 = ((int64_t)blockIdx.x * gpb + gid) * FWD_UNROLL; b0 < n;
-         b0 += (int64_t)gridDim.x * gpb * FWD_UNROLL) {
-        int32_t s[FWD_UNROLL];
-#pragma unroll
-        for (int u = 0; u < FWD_UNROLL; ++u) s[u] = (b0 + u < n) ? sl[b0 + u] : -1;
-        for (int cc = c; cc < D4; cc += LPR) {
-            float4 v[FWD_UNROLL];
-#pragma unroll
-            for (int u = 0; u < FWD_UNROLL; ++u)
-                if (s[u] >= 0) v[u] = weight[(row_base + s[u]) * D4 + cc];
-#pragma unroll
-            for (int u = 0; u < FWD_UNROLL; ++u)
-                if (s[u] >= 0) *reinterpret_cast<float4*>(o + (b0 + u) * ld_bag + cc * 4) = v[u];
-        }
-    }
-}
-
-// Persistent variant: a fixed grid walks (table, bag-chunk) work items; the slot ids of the NEXT item are loaded
+// Persistent grid: a fixed number of workgroups walks (table, bag-chunk) work items; the slot ids of the NEXT item are loaded
 // before the current item's rows, so the slot -> row dependency costs one memory latency per item instead of two,
 // and there is no per-block launch ramp.  Loads are unpredicated (tail bags clamp to the last bag), only the
 // stores are masked.
@@ -412,13 +382,7 @@ extern "C" int cdlrm_embbag_probe(cdlrm_ctx* ctx, const int64_t* idx, int64_t n,
         // grid x reads-per-lane x 4 KB per workgroup-read = bytes in flight.  Measured on the MI355X box (random 512-B
         // rows of a 96 GB pinned table): a host read takes ~17 us round trip, so the ~50 GB/s link needs ~0.5-1 MB in
         // flight; 32 workgroups x 4 reads is the knee (16x8: 1.04 ms/step, 32x4: 0.96, 64x4: 0.98)
-        static int fill_grid = -1, fill_u = -1;
-        if (fill_grid < 0) {
-            const char* e = getenv("CDLRM_FILL_GRID");       // development switches
-            fill_grid = e ? atoi(e) : 32;
-            e = getenv("CDLRM_FILL_U");
-            fill_u = e ? atoi(e) : 4;
-        }
+        const int fill_grid = 32, fill_u = 4;
         int64_t fx = cdiv((int64_t)(n < ctx->aux ? n : ctx->aux) * D4 * ctx->T, 256);
         const bool vict = ctx->vict_idx != nullptr;
         // with the window's victim rows resident in HBM the fill is a latency-bound search + HBM copy: wide grid
@@ -641,40 +605,20 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
     const float4* w = reinterpret_cast<const float4*>(ctx->weight);
     hipEvent_t ev0 = (hipEvent_t)ctx->ev_start, ev1 = (hipEvent_t)ctx->ev_stop;
     ctx->ev_start = ctx->ev_stop = nullptr;
-    static int variant = -1;
-    static int pgrid = 4096;     // measured on MI355X (c3 shape): persistent U=4, 4096 workgroups 33 us vs 45 us one-shot
-    if (variant < 0) {
-        const char* e = getenv("CDLRM_GATHER_VARIANT");     // development switch: 0 one-shot grid, 4/8 persistent
-        variant = e ? atoi(e) : 4;
-        const char* gsz = getenv("CDLRM_GATHER_GRID");
-        if (gsz) pgrid = atoi(gsz);
-    }
-    static int nt = -1;
-    if (nt < 0) {
-        const char* e = getenv("CDLRM_GATHER_NT");          // development switch: non-temporal output stores
-        nt = e ? atoi(e) : 0;
-    }
-    if (!offsets && (variant == 4 || variant == 8)) {
-        const int U = variant;
+    // persistent grid of 4096 workgroups, 4 rows in flight per lane group: measured on MI355X (c3 shape) 33 us against 45 us
+    // for a one-shot grid (8 in flight and non-temporal output stores: no better)
+    const int pgrid = 4096, nt = 0;
+    if (!offsets) {
+        constexpr int U = 4;
         int64_t total = cdiv(n, (int64_t)gpb * U) * ctx->T;
         int64_t gx = total < pgrid ? total : pgrid;
         // the launch's own start / stop timestamps land in the caller's events (cdlrm_ctx_time_next_gather): no marker
         // packets on the queue, so timing a launch does not move it or its neighbours
 #define PFWD_CALL(L)                                                                                                  \
-    if (U == 4) hipExtLaunchKernelGGL((k_embbag_fwd_arange_p<L, 4>), dim3((unsigned)gx), dim3(256), 0, s, ev0, ev1, 0, \
-                                      ctx->d_tab, ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt);               \
-    else hipExtLaunchKernelGGL((k_embbag_fwd_arange_p<L, 8>), dim3((unsigned)gx), dim3(256), 0, s, ev0, ev1, 0,     \
-                               ctx->d_tab, ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt)
+    hipExtLaunchKernelGGL((k_embbag_fwd_arange_p<L, U>), dim3((unsigned)gx), dim3(256), 0, s, ev0, ev1, 0, ctx->d_tab, \
+                          ctx->T, D4, w, slots, n, out, ld_bag, ld_table, nt)
         DISPATCH_LPR(lpr, PFWD_CALL)
 #undef PFWD_CALL
-    } else if (!offsets) {
-        if (ev0) CDLRM_HIP_CHECK(hipEventRecord(ev0, s));
-        int64_t gx = cdiv(n, (int64_t)gpb * FWD_UNROLL);
-        if (gx > 65535) gx = 65535;
-        dim3 grid((unsigned)gx, (unsigned)ctx->T);
-#define FWD_CALL(L) hipLaunchKernelGGL(k_embbag_fwd_arange<L>, grid, dim3(256), 0, s, ctx->d_tab, D4, w, slots, n, out, ld_bag, ld_table)
-        DISPATCH_LPR(lpr, FWD_CALL)
-#undef FWD_CALL
     } else {
         if (ev0) CDLRM_HIP_CHECK(hipEventRecord(ev0, s));
         int64_t gx = cdiv(n_bags, gpb);
@@ -684,7 +628,7 @@ extern "C" int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int6
         DISPATCH_LPR(lpr, FWD_CALL)
 #undef FWD_CALL
     }
-    if (ev1 && (offsets || !(variant == 4 || variant == 8))) CDLRM_HIP_CHECK(hipEventRecord(ev1, s));
+    if (ev1 && offsets) CDLRM_HIP_CHECK(hipEventRecord(ev1, s));
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

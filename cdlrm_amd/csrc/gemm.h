@@ -714,12 +714,6 @@ static void launch_gemm_v(const GemmArgs& g, dim3 grid, hipStream_t s) {
 // the tiled kernel needs this many 64x64 workgroups to be the better choice (2 per CU); below it the
 // LDS-free kernel's 4x finer cut wins.  CDLRM_GEMM_DIRECT=0 / 1 forces one or the other (experiments).
 static inline bool gemm_use_direct(int64_t M, int64_t N, int64_t splits) {
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = getenv("CDLRM_GEMM_DIRECT");
-        forced = e ? atoi(e) : -1;
-    }
-    if (forced >= 0) return forced != 0;
     return cdiv(M, 64) * cdiv(N, 64) * splits < 512;
 }
 
@@ -734,12 +728,6 @@ static inline int direct_mode(int64_t klen, bool al) {
 // contraction-contiguous operands, lane offsets within 32 bits
 template <bool A_KC, bool B_KC>
 static inline bool direct_aligned(const GemmArgs& g, int64_t klen) {
-    static int off = -1;
-    if (off < 0) {
-        const char* e = getenv("CDLRM_GEMM_ALIGNED");
-        off = (e && atoi(e) == 0) ? 1 : 0;
-    }
-    if (off) return false;
     if (g.K < 32 || g.K % 32 != 0 || (klen < g.K && klen % 32 != 0)) return false;
     if ((A_KC && !g.vecA) || (B_KC && !g.vecB)) return false;
     const int64_t lim = (int64_t)1 << 30;      // elements: byte offsets stay below 2^32
@@ -751,12 +739,7 @@ static inline bool direct_aligned(const GemmArgs& g, int64_t klen) {
 // contraction-strided operands (extent and pitch multiples of 4)
 template <bool A_KC, bool B_KC>
 static inline bool direct_staged(const GemmArgs& g, int64_t klen) {
-    static int off = -1;
-    if (off < 0) {
-        const char* e = getenv("CDLRM_GEMM_STAGED");
-        off = (e && atoi(e) == 0) ? 1 : 0;
-    }
-    if (off || !direct_aligned<A_KC, B_KC>(g, klen) || g.K < 64) return false;
+    if (!direct_aligned<A_KC, B_KC>(g, klen) || g.K < 64) return false;
     if (!A_KC && (g.M % 4 != 0 || g.lda % 4 != 0 || !aligned16(g.A))) return false;
     if (!B_KC && (g.N % 4 != 0 || g.ldb % 4 != 0 || !aligned16(g.B))) return false;
     const int64_t lim = (int64_t)1 << 30;

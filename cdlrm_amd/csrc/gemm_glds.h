@@ -338,12 +338,7 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
 // the vectorised non-contraction directions
 template <bool A_KC, bool B_KC>
 static inline bool gemm2_applies(const GemmArgs& g) {
-    static int off = -1;
-    if (off < 0) {
-        const char* e = getenv("CDLRM_GEMM_GLDS");
-        off = (e && atoi(e) == 0) ? 1 : 0;
-    }
-    if (off || !g.vecA || !g.vecB) return false;
+    if (!g.vecA || !g.vecB) return false;
     const int64_t kc = g.kchunk < g.K ? g.kchunk : g.K;
     if (g.K < G2_BK || g.K % G2_BK != 0 || kc % G2_BK != 0) return false;
     if (!A_KC && g.M < 4) return false;

@@ -536,15 +536,7 @@ __global__ void __launch_bounds__(256) k_host_rows(int T, int D4, const int64_t*
     }
 }
 
-static int host_rows_grid() {
-    static int g = -1;
-    if (g < 0) {
-        const char* e = getenv("CDLRM_HOSTROWS_GRID");     // development switch
-        g = e ? atoi(e) : 32;
-        if (g < 1) g = 1;
-    }
-    return g;
-}
+static int host_rows_grid() { return 32; }
 
 extern "C" int cdlrm_plan_fetch(cdlrm_ctx* ctx, const cdlrm_plan* plan, const float* const* src_rows, int by_position,
                                 void* stream) {

@@ -118,7 +118,7 @@ class WindowPipeline:
         self.host_gather = bool(host_gather) and not parity_rng and S.is_hip(self.dev)
         self.gather_threads = int(gather_threads)
         if shard_fetch is None:
-            shard_fetch = os.environ.get("CDLRM_SHARD_FETCH", "1") != "0"
+            shard_fetch = True
         self.shard = bool(shard_fetch) and self.host_gather and self.multi
         self.pg = process_group
         self._exchange = []          # (buffer, chunk rows) all-gathers commit() owes for the plan in flight
@@ -327,8 +327,9 @@ class WindowResolver:
     allocations: the resolve writes them on the prefetch stream while takes read them on the side stream, streams the
     caching allocator knows nothing about -- a block freed on the host while queued takes still read it would be handed
     straight to the next chunk's resolve.  A slot is recycled behind an event recorded on the side stream when the recycling
-    resolve is issued: every take of the chunk that held the slot (two chunks back) has been ISSUED by then, so the event
-    covers them all however far the host runs ahead of the GPU."""
+    resolve is issued, and chunk c is only issued once batch() has been asked for the SECOND batch of chunk c - 2 (the step
+    of that chunk's first batch is then on the queues): every take of chunk c - 3, the slot's previous holder, has been
+    ISSUED by then, so the event covers them all however far the host runs ahead of the GPU."""
 
     RING = 3
 
@@ -347,6 +348,7 @@ class WindowResolver:
         self.CH = max(1, int(chunk))
         self.chunks = {}            # chunk number -> (wslots, wsrc, ready event)
         self.done = 0               # chunks issued
+        self.maxj = -1              # highest batch handed out by batch()
         key = ("wres", self.CH * self.B)
         if key not in engine._bufs:
             T = self.ctx.T
@@ -362,7 +364,9 @@ class WindowResolver:
         want = min(nchunks, -(-min(int(upto_batch), self.nb) // self.CH))
         while self.done < want:
             c = self.done
-            assert (c - self.RING) not in self.chunks, "ring slot still handed out: ensure() ran more than two chunks ahead"
+            if c >= self.RING and self.maxj < (c - 2) * self.CH + 1:
+                break               # the slot's previous chunk may still have takes to issue: a later ensure() / batch() issues it
+            self.chunks.pop(c - self.RING, None)
             b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
             cols = self.idx[:, b0 * self.B:b1 * self.B]
             w = int(cols.shape[1])
@@ -384,6 +388,7 @@ class WindowResolver:
     def batch(self, j: int):
         """(wslots view, wsrc view, ready event) of this rank's lookups of batch j of the window."""
         c = j // self.CH
+        self.maxj = max(self.maxj, j)
         self.ensure(j + 1)
         ws, wsrc, ev = self.chunks[c]
         col = (j - c * self.CH) * self.B + self.col0
@@ -436,7 +441,7 @@ class TrainEngine:
         self.agg_rows = None
         # rows per chunk of the touched-row merge (32 MB at D = 128: large enough for xGMI bandwidth, small enough that
         # the gather of chunk i+1 hides under the reduction of chunk i)
-        self.agg_chunk_rows = int(os.environ.get("CDLRM_AGG_CHUNK_ROWS", str(1 << 16)))
+        self.agg_chunk_rows = 1 << 16
         self._pref = None
         self._phase = 0                             # aux region of the batch being trained
         self._emb_done = None
@@ -446,31 +451,27 @@ class TrainEngine:
         self._head_scratch = ops.head_scratch(self.dev)
         # output head in one launch (last layer + loss + its input gradient) when the last top layer is 1-wide + sigmoid
         l_last, a_last = self.top[-1]
-        self.fused_head = (l_last.out_features == 1 and a_last == 2 and os.environ.get("CDLRM_FUSED_HEAD", "1") != "0")
+        self.fused_head = l_last.out_features == 1 and a_last == 2
         # top-MLP weight gradients at long local batches: the SAME stream as the prefetch (their work never overlaps in
         # time: probe/fill right after the gather, weight gradients late in the backward) -- four streams in all
         # (main, side, pref, the window plan's), one per default hardware queue
-        self.wst = self.pref if os.environ.get("CDLRM_WST_OWN_STREAM", "0") != "1" else S.new_stream(self.dev)
+        self.wst = self.pref
         # measured (c3 shapes): the split loses ~3 % at B <= 2048 (two more launches on a latency-bound step), gains
         # 8 % at 4096 (0.580 -> 0.534 ms) and at 8192 (0.853 -> 0.782 ms)
-        self.split_wgrad_min = int(os.environ.get("CDLRM_SPLIT_WGRAD_MIN", "2049"))
-        self.split_wgrad_max = int(os.environ.get("CDLRM_SPLIT_WGRAD_MAX", str(1 << 30)))
+        self.split_wgrad_min = 2049
         # local batches below this run the gather on the side stream beside the bottom MLP's forward (measured: 0.216 ->
         # 0.211 ms at 1024, 0.307 -> 0.301 at 2048, 0.493 -> 0.461 at 4096); from it on the gather stays alone on the
         # main stream: at 8192 the overlap buys 2 % (0.783 -> 0.766 ms) and costs the roofline kernel 6 points of its
         # own rate (35.4 -> 38.3 us, 78 % -> 72 % of peak)
-        self.gather_alone_min = int(os.environ.get("CDLRM_GATHER_ALONE_MIN", "8192"))
+        self.gather_alone_min = 8192
         self._gslot = None
         self._res = self._next_res = None
         self._tapes = {}
-        self.use_tape = S.is_hip(self.dev) and os.environ.get("CDLRM_TAPE", "1") != "0"
-        self.chain_take = os.environ.get("CDLRM_CHAIN_TAKE", "1") != "0"
-        self.native_tape = os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0"
-        self.wgrad_late = os.environ.get("CDLRM_WGRAD_LATE", "0") == "1"
-        self.fuse_sgd = os.environ.get("CDLRM_FUSE_SGD", "1") != "0"
-        # (interaction backward split by rows, see _fwd_bwd: measured SLOWER at c3, 0.718 vs 0.663 ms -- beside the GEMMs the
-        #  HBM-bound rest kernel takes 112 us instead of 52 and the embedding chain behind it becomes the long pole -- so off)
-        self.split_ibwd = os.environ.get("CDLRM_SPLIT_IBWD", "0") == "1"
+        # schedule knobs (attributes, not environment switches: tests/test_engine_parity.py runs each of them both ways)
+        self.use_tape = S.is_hip(self.dev)      # replay recorded launch sequences (_step_taped)
+        self.native_tape = True                 # ... from the C side (csrc/tape.hip) instead of from Python
+        self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
+        self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -517,19 +518,6 @@ class TrainEngine:
         """Short local batches run the gather on the side stream (see _fwd_bwd)."""
         return B < self.gather_alone_min and not (self.defer_top and self.cat)
 
-    def _alt_feat(self, B: int, lS_o) -> bool:
-        """Long batches on the Criteo layout with the dot interaction: the interaction backward runs split by rows and the
-        feature block alternates between two buffers (see _fwd_bwd)."""
-        D4 = self.D // 4
-        return (self.split_ibwd and not self.cat and lS_o is None and not self._side_gather(B) and self.D % 4 == 0
-                and (D4 & (D4 - 1)) == 0 and D4 <= 64 and self.r_width % 4 == 0)
-
-    def _feat_pair(self, B: int):
-        buf = self._buffers(B)
-        if "feat_pair" not in buf:
-            buf["feat_pair"] = (buf["feat"], torch.zeros(B + 1, self.F, self.D, dtype=torch.float32, device=self.dev)[:B])
-        return buf["feat_pair"]
-
     def _chain(self, B: int, next_idx, lS_o) -> bool:
         """Long batches on the window-resident probe: the next batch's take rides behind this step's embedding update on
         the side stream (see _fwd_bwd)."""
@@ -544,7 +532,7 @@ class TrainEngine:
         r = getattr(self, "_avg_ok", None)
         if r is None:
             W = self.world
-            r = (W & (W - 1)) == 0 and dist.get_backend(self.pg) == "nccl" and os.environ.get("CDLRM_REDUCE_AVG", "1") != "0"
+            r = (W & (W - 1)) == 0 and dist.get_backend(self.pg) == "nccl"
             self._avg_ok = r
         return r
 
@@ -594,7 +582,7 @@ class TrainEngine:
         # long local batches: the top MLP's weight gradients run on their own stream beside the interaction backward
         # and the bottom MLP's backward -- (bottom plan, top plan), each with its own scratch
         b["wgrad_split"] = None
-        if self.defer_top or (S.is_hip(dev) and self.split_wgrad_min <= B <= self.split_wgrad_max):
+        if self.defer_top or (S.is_hip(dev) and B >= self.split_wgrad_min):
             nb = len(self.bot)
             gw = [self.gW[l] for l in layers]
             gb = [self.gb[l] for l in layers]
@@ -785,11 +773,6 @@ class TrainEngine:
         chain = self._chain(B, next_idx, lS_o)
         if chain:
             two_phase = False
-        # Long batches: the interaction backward is split by rows (see below); the side stream then still reads THIS step's
-        # feature block while the main stream starts the next step, so the block alternates between two buffers
-        alt_feat = self._alt_feat(B, lS_o)
-        if alt_feat:
-            feat = self._feat_pair(B)[self.iter & 1]
         if self.defer_top and self.cat:
             # the previous step's top weight gradients read R = the feature block this step's first kernels overwrite
             rec(main.wait_event, ev["top_updated"])
@@ -933,37 +916,24 @@ class TrainEngine:
                     ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_top, self.lr, stream=wst)
                 rec(ev["top_updated"].record, wst)
 
-        # CDLRM_WGRAD_LATE=1: one event on the main queue for both side streams (recorded behind the interaction backward)
-        # instead of one in front of it for the weight gradients and one behind it for the embedding backward.  Measured
-        # slower at c3 (0.698 vs 0.675 ms): the saved bubble is worth less than the 57 us the weight gradients start later.
-        wgrad_late = self.wgrad_late and split is not None and not self.cat
-        if split is not None and not wgrad_late:
+        # (One event on the main queue for both side streams -- recorded behind the interaction backward -- instead of one in
+        #  front of it for the weight gradients and one behind it for the embedding backward measured slower at c3, 0.698 vs
+        #  0.675 ms: the saved bubble is worth less than the 57 us the weight gradients start later.  The interaction backward
+        #  split by rows -- the dense feature's row as its own launch, the rest on the side queue -- measured slower too, 0.718
+        #  vs 0.663 ms.  Both schedules were removed in round 3.)
+        if split is not None:
             rec(ev["top_dz"].record, main)
             top_wgrad(ev["top_dz"])
-        # Interaction backward by rows (long batches): the bottom MLP's backward -- MFMA-bound, the rest of the step's critical
-        # path -- needs ONE of the F gradient rows, the dense feature's.  That row is its own small launch on the main stream
-        # (cdlrm_interact_bwd_rows(rows = 1): 13.8 KB read per sample, vector ALU); the other F-1 rows, which only the
-        # embedding backward consumes, are computed on the side stream in front of it (rows = 2: the HBM-bound kernel), beside
-        # the bottom MLP's GEMMs.  The side stream starts from the `top_dz` event the weight gradients wait for anyway, so the
-        # main queue also loses the `interacted` record.
-        split_ibwd = alt_feat and not self.cat and split is not None and not wgrad_late
         if self.cat:
             # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
             # derivative (the dot path applies it in the interaction backward's epilogue)
             ops.act_bwd(dfeat[:, 0, :], feat[:, 0, :], self.bot[-1][1])
-        elif split_ibwd:
-            rec(side.wait_event, ev["top_dz"])
-            ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1], rows=2, stream=side)
-            ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1], rows=1)
         else:
             ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
-        if not split_ibwd:
-            rec(ev["interacted"].record, main)
-            if wgrad_late:
-                top_wgrad(ev["interacted"])
-            rec(side.wait_event, ev["interacted"])
+        rec(ev["interacted"].record, main)
+        rec(side.wait_event, ev["interacted"])
         ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
                              cg.touched if self.multi else None, stream=side)
         emb_done = ev["emb_done"]
@@ -1090,7 +1060,7 @@ class TrainEngine:
         nxt = next_idx is not None
         key = (B, n, main.cuda_stream, hit, phase, nxt, self._emb_done is not None, X.stride(0), lS_i.stride(0),
                next_idx.stride(0) if nxt else 0,
-               (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None) or self._alt_feat(B, None)) else 0,
+               (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
                self._gslot is not None,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,

@@ -350,10 +350,8 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", rank=rank, world_size=world)
     local_batch_size = math.ceil(args.mini_batch_size / world)
-    prio = int(os.environ.get("CDLRM_MAIN_PRIORITY", "-1"))
-    if prio != 0:
-        # the trainer's queue outranks the engine's side queues (see bench.py)
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=prio))
+    # the trainer's queue outranks the engine's side queues (see bench.py)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 
     # multi-hot bags (--data-generation=random): a batch has up to mini_batch_size * num_indices_per_lookup lookups per
     # table, each miss takes its own aux row (model_no_ddp.py:176-179) -- the reference sizes the aux region for one
@@ -388,13 +386,14 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
             dist.barrier()
     eng = TrainEngine(cache_group, dlrm, emb_tables, lr=args.learning_rate, lr_embeds=args.lr_embeds, world_size=world,
                       rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op,
-                      loss=args.loss_function, loss_weights=loss_ws, defer_top_update=os.environ.get("CDLRM_DEFER_TOP", "1") != "0")
+                      loss=args.loss_function, loss_weights=loss_ws, defer_top_update=True)
     L = args.lookahead
     # --device-rng (performance mode): the plan of window w+1 is made while window w trains -- what the reference's
     # Prefetcher process is for (cache_manager.py:66-115) -- with its rows gathered by CPU threads in the background.  The
     # plan reads the tag state and the host rows as the previous commit left them, nothing the training changes, so the
     # result is the synchronous plan's.  Parity mode draws the way choices in line at the boundary, as the reference does.
-    lookahead_plan = bool(args.device_rng) and os.environ.get("CDLRM_RUN_LOOKAHEAD", "1") != "0"
+    # (`args.plan_at_boundary`: not a CLI flag -- tests set it to compare against planning every window at its boundary)
+    lookahead_plan = bool(args.device_rng) and not getattr(args, "plan_at_boundary", False)
     pipe = WindowPipeline(cache_group, emb_tables, L * aux_rows * 2, parity_rng=not args.device_rng,
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
                           world_size=world, host_gather=lookahead_plan)
@@ -456,7 +455,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 pipe.wait_writeback()
                 # window-resident probe (one lookup per bag): the window's lookups are resolved against the new tags once
                 resolver, wj = None, 0
-                if not multi_hot and os.environ.get("CDLRM_WINDOW_RESOLVE", "1") != "0":
+                if not multi_hot:
                     if cur_win_idx is None:
                         cur_win_idx = window_indices(window)
                     if cur_win_idx.shape[1] == len(window) * args.mini_batch_size:      # whole batches only

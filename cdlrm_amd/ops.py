@@ -377,13 +377,12 @@ def interact_fwd(feat: torch.Tensor, itself: bool, R: torch.Tensor, stream=None)
                                         stream_ptr(stream)))
 
 
-def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None, x_act: int = 0,
-                 rows: int = 0):
+def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torch.Tensor, stream=None, x_act: int = 0):
     """x_act: activation that produced feature 0 (the bottom MLP's output); its gradient row then leaves as the
-    pre-activation gradient.  rows: 0 all gradient rows, 1 the dense feature's row only, 2 all but that row."""
+    pre-activation gradient."""
     B, F, D = feat.shape
-    check(_lib.lib().cdlrm_interact_bwd_rows(feat.data_ptr(), dR.data_ptr(), dR.stride(0), B, F, D, int(bool(itself)),
-                                             int(x_act), dfeat.data_ptr(), int(rows), stream_ptr(stream)))
+    check(_lib.lib().cdlrm_interact_bwd(feat.data_ptr(), dR.data_ptr(), dR.stride(0), B, F, D, int(bool(itself)),
+                                        int(x_act), dfeat.data_ptr(), stream_ptr(stream)))
 
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
@@ -496,53 +495,6 @@ def loss_fwd_bwd(Z: torch.Tensor, target: torch.Tensor, loss_buf: torch.Tensor, 
     check(_lib.lib().cdlrm_loss_fwd_bwd(Z.data_ptr(), target.data_ptr(), Z.numel(), int(kind), float(weights[0]),
                                         float(weights[1]), float(threshold), loss_buf.data_ptr(), ptr(dZ), ptr(Zc),
                                         1 if sigmoid_bwd else 0, stream_ptr(stream)))
-
-
-class ChainPlan:
-    """Argument block of one layer chain (cdlrm_mlp_fwd_chain / cdlrm_mlp_dgrad_chain): pointer tables built once over
-    persistent buffers, plus the chain's own device sync words.  kind "fwd": layers = [(W, bias, Y, act)], x = the first
-    layer's input; kind "dgrad": layers = [(W, Xin or None, x_act, dX)] top-most first, x = dY of the first."""
-
-    def __init__(self, kind: str, x: torch.Tensor, layers, M: int, device, chained: bool = True):
-        assert kind in ("fwd", "dgrad") and len(layers) >= 1
-        self.kind, self.n, self.M = kind, len(layers), int(M)
-        n = self.n
-        P, I64, I32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
-        self.x, self.ld_x = x.data_ptr(), x.stride(0)
-        self._keep = [x, layers]
-        if kind == "fwd":
-            self.W = P(*[l[0].data_ptr() for l in layers])
-            self.bias = P(*[ptr(l[1]) for l in layers])
-            self.Y = P(*[l[2].data_ptr() for l in layers])
-            self.ld_y = I64(*[l[2].stride(0) for l in layers])
-            self.N = I32(*[l[0].shape[0] for l in layers])
-            self.K = I32(*[l[0].shape[1] for l in layers])
-            self.act = I32(*[int(l[3]) for l in layers])
-        else:
-            self.W = P(*[l[0].data_ptr() for l in layers])
-            self.Xin = P(*[ptr(l[1]) for l in layers])
-            self.ld_xin = I64(*[(l[1].stride(0) if l[1] is not None else 0) for l in layers])
-            self.x_act = I32(*[int(l[2]) for l in layers])
-            self.dX = P(*[l[3].data_ptr() for l in layers])
-            self.ld_dx = I64(*[l[3].stride(0) for l in layers])
-            self.N = I32(*[l[0].shape[0] for l in layers])
-            self.K = I32(*[l[0].shape[1] for l in layers])
-        self.sync = torch.zeros(int(_lib.lib().cdlrm_chain_sync_ints()), dtype=torch.int32, device=device) if chained else None
-
-    def error(self) -> int:
-        """The chain's device error word (synchronises): 0, or 1 = a bounded wait gave up, 2 = an XCD had no workgroups."""
-        return 0 if self.sync is None else int(self.sync[int(_lib.lib().cdlrm_chain_err_index())].item())
-
-
-def mlp_chain(plan: ChainPlan, stream=None):
-    """Run the chain: one launch where it applies, layer by layer otherwise (decided inside the library)."""
-    L = _lib.lib()
-    if plan.kind == "fwd":
-        check(L.cdlrm_mlp_fwd_chain(plan.n, plan.x, plan.ld_x, plan.W, plan.bias, plan.Y, plan.ld_y, plan.M, plan.N, plan.K,
-                                    plan.act, ptr(plan.sync), stream_ptr(stream)))
-    else:
-        check(L.cdlrm_mlp_dgrad_chain(plan.n, plan.x, plan.ld_x, plan.W, plan.Xin, plan.ld_xin, plan.x_act, plan.dX,
-                                      plan.ld_dx, plan.M, plan.N, plan.K, ptr(plan.sync), stream_ptr(stream)))
 
 
 def head_scratch(device) -> torch.Tensor:

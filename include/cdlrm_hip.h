@@ -326,13 +326,6 @@ int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32
  * act'(feat[b,0,:]) here, so the bottom MLP's backward starts from the pre-activation gradient. */
 int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F,
                        int32_t D, int32_t itself, int32_t x_act, float* dfeat, void* stream);
-/* The same, by rows: 0 = all F gradient rows (cdlrm_interact_bwd), 1 = the dense feature's row only (row 0: all the bottom
- * MLP's backward waits for -- a small launch on the training queue), 2 = every row but row 0 (the embedding rows, for the
- * embedding backward: the training step runs it on the side queue beside the bottom MLP's backward).  1 and 2 together write
- * what 0 writes (row 0 summed in j order by the vector ALU instead of the MFMA: equal within fp32 rounding). */
-int cdlrm_interact_bwd_rows(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
-                            int32_t itself, int32_t x_act, float* dfeat, int32_t rows, void* stream);
-
 /* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
  * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */
 int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y,
@@ -421,33 +414,14 @@ int cdlrm_sgd_step2(float* param, const float* grad, int64_t off0, int64_t n0, i
 /* x /= divisor (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239, 244). */
 int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream);
 
-/* ---- layer chains: n consecutive Linear layers in ONE launch at local batches <= 2048 ---------------------------------
- * (the per-rank shapes of a multi-GPU run: a layer is 3-4 us of MFMA work inside a launch that holds its queue for >= 5 us).
- * A persistent kernel over (layer, 32-row block, 32-column tile) items; a row block moves on to the next layer when ITS
- * tiles of the previous one are done, and stays on one XCD (row block % 8) through all layers, so the hand-off needs no
- * L2 write-back (csrc/chain.h).  `sync`: cdlrm_chain_sync_ints() int32 on the device, zeroed once by the caller, one
- * buffer per chain that may be in flight; sync[cdlrm_chain_err_index()] != 0 after a launch = a bounded wait gave up (1)
- * or an XCD got no workgroups (2).  sync == NULL, M > 2048, n < 2 or a layer off the staged kernel's shape conditions:
- * the layers are launched one by one (same results).
- *   fwd:   Y[i] = act_i(Y[i-1] W[i]^T + b[i]), Y[-1] = X       (model_no_ddp.py:264-283, one nn.Sequential)
- *   dgrad: dX[i] = dZ[i] W[i] * act'(Xin[i]) (x_act[i]; 0 none), dZ[i+1] = dX[i], dZ[0] = dY; layers top-most first,
- *          W[i] is [N[i], K[i]]                                  (what cdlrm_linear_bwd(dW = NULL) does per layer) */
-int64_t cdlrm_chain_sync_ints(void);
-int64_t cdlrm_chain_err_index(void);
-int cdlrm_mlp_fwd_chain(int32_t n, const float* X, int64_t ld_x, const float* const* W, const float* const* bias,
-                        float* const* Y, const int64_t* ld_y, int64_t M, const int32_t* N, const int32_t* K,
-                        const int32_t* act, int32_t* sync, void* stream);
-int cdlrm_mlp_dgrad_chain(int32_t n, const float* dY, int64_t ld_dy, const float* const* W, const float* const* Xin,
-                          const int64_t* ld_xin, const int32_t* x_act, float* const* dX, const int64_t* ld_dx, int64_t M,
-                          const int32_t* N, const int32_t* K, int32_t* sync, void* stream);
-
 /* ---- launch tapes -------------------------------------------------------------------------------------------------
  * A training step's call sequence (this library's entry points + event records / stream waits), recorded once per control
  * path by the host and re-issued by ONE call per step (the reference issues the same ops from Python every iteration,
  * main_no_ddp.py:404-415; at a per-rank batch of 1024 the interpreter alone costs more than the GPU work).  Calls are
  * stored as (function, integer-class arguments, float arguments); an integer argument may be a "cell" -- a slot of the
- * tape's cell array that the host patches before a replay (the batch's tensors).  x86-64 System V only: see
- * csrc/tape.hip; cdlrm_tape_selftest() returns 0 where the generic call works. */
+ * tape's cell array that the host patches before a replay (the batch's tensors).  Every entry point a tape may hold is
+ * registered in csrc/tape.hip with its true type and called through a pointer of that type (cdlrm_tape_add refuses
+ * anything else); cdlrm_tape_selftest() checks the argument unpacking. */
 typedef struct cdlrm_tape cdlrm_tape;
 cdlrm_tape* cdlrm_tape_create(int32_t n_cells);
 void cdlrm_tape_destroy(cdlrm_tape* t);

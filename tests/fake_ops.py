@@ -199,16 +199,13 @@ def _act_bwd(d, y, act):
     return d * (y > 0) if act == 1 else d * ((1 - y) * y) if act == 2 else d
 
 
-def interact_bwd(feat, dR, itself, dfeat, stream=None, x_act=0, rows=0):
+def interact_bwd(feat, dR, itself, dfeat, stream=None, x_act=0):
     f = feat.detach().clone().requires_grad_(True)
     out = O.interact_features(f[:, 0, :], [f[:, k, :] for k in range(1, f.shape[1])], "dot", itself)
     out.backward(dR[:, :out.shape[1]])
     g = f.grad.clone()
     g[:, 0, :] = _act_bwd(g[:, 0, :], feat[:, 0, :], x_act)
-    if rows in (0, 1):
-        dfeat[:, 0, :] = g[:, 0, :]
-    if rows in (0, 2):
-        dfeat[:, 1:, :] = g[:, 1:, :]
+    dfeat.copy_(g)
 
 
 def linear_fwd(X, W, b, Y, act, stream=None):

@@ -102,22 +102,24 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, reso
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,defer,split_rows", [("train_small", True, False), ("train_small", False, False),
-                                                   ("train_c1", True, False), ("train_stream", True, False),
-                                                   # + the interaction backward split by rows (CDLRM_SPLIT_IBWD=1 schedule)
-                                                   ("train_small", True, True), ("train_c1", True, True)])
-def test_chained_take_long_batch_path(golden, name, defer, split_rows):
+@pytest.mark.parametrize("name,defer,chunk,delay", [("train_small", True, 2, False), ("train_small", False, 2, False),
+                                                    ("train_c1", True, 2, False), ("train_stream", True, 2, False),
+                                                    # the host far ahead of a slow side stream, a ring slot recycled every 3 steps
+                                                    ("train_c1", True, 1, True), ("train_c1", False, 2, True)])
+def test_chained_take_long_batch_path(golden, name, defer, chunk, delay):
     """The long-batch schedule (gather alone on the main stream, B >= gather_alone_min) on the window-resident probe: the
     next batch's take follows the embedding update on the side stream and the next gather waits for ONE event recorded
     behind it (and behind the deferred top-MLP update).  Forced here at the goldens' small batches; same trajectory,
-    tags and weights as the reference, taped and untaped steps alike."""
+    tags and weights as the reference, taped and untaped steps alike.
+    delay: every step's side-stream work (embedding update, the next batch's take) is held back by a ~1 ms spin kernel while
+    the host issues the whole window without a sync, so resolves of later chunks are issued long before the takes that read
+    the ring slots they recycle have run (engine.WindowResolver's ring + side-stream event must order them)."""
     from cdlrm_amd.engine import TrainEngine, WindowResolver
     g = golden(name)
     host, cg, dl, eng0, pipe = build(g, aux_phases=2)
     eng = TrainEngine(cg, dl, host, lr=eng0.lr, lr_embeds=eng0.lr_embeds, table_agg_freq=eng0.agg_freq,
                       table_agg_op=eng0.agg_op, defer_top_update=defer)
     eng.gather_alone_min = 1
-    eng.split_ibwd = split_rows
     assert eng.chain_take
     L = int(g["L"])
     batches = make_batches(g)
@@ -131,8 +133,11 @@ def test_chained_take_long_batch_path(golden, name, defer, split_rows):
             pipe.plan_window(win)
             pipe.commit()
             pipe.wait_writeback()
-            rs = WindowResolver(eng, win, int(g["B"]), chunk=2)
+            rs = WindowResolver(eng, win, int(g["B"]), chunk=chunk)
         nxt = dev_idx[j + 1] if j + 1 < len(batches) and (j + 1) % L != 0 else None
+        if delay:
+            with torch.cuda.stream(eng.side):
+                torch.cuda._sleep(2_500_000)
         loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt, res=rs.batch(j % L),
                         next_res=rs.batch(j % L + 1) if nxt is not None else None)
         chained += int(eng._pref is not None and bool(eng._pref.get("chained_top")) == (defer and eng.world == 1))

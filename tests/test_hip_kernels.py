@@ -544,18 +544,6 @@ def test_interaction_kernels_vs_torch(ops, B, F, D, itself, pad):
     dfeat = torch.empty_like(fd)
     ops.interact_bwd(fd, G.to(DEV), bool(itself), dfeat)
     np.testing.assert_allclose(dfeat.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
-    # by rows: the dense feature's row (vector ALU, its own launch) + every other row = the whole, each touching only its part
-    if D % 4 == 0 and (D // 4) & (D // 4 - 1) == 0 and D // 4 <= 64 and width % 4 == 0:
-        for x_act in (0, 1):
-            whole = torch.empty_like(fd)
-            ops.interact_bwd(fd, G.to(DEV), bool(itself), whole, x_act=x_act)
-            parts = torch.full_like(fd, 3.0)
-            ops.interact_bwd(fd, G.to(DEV), bool(itself), parts, x_act=x_act, rows=2)
-            assert bool((parts[:, 0, :] == 3.0).all())                              # row 0 untouched
-            assert torch.equal(parts[:, 1:, :], whole[:, 1:, :])                    # the other rows: the same kernel
-            ops.interact_bwd(fd, G.to(DEV), bool(itself), parts, x_act=x_act, rows=1)
-            assert torch.equal(parts[:, 1:, :], whole[:, 1:, :])                    # rows 1.. untouched by the dense launch
-            np.testing.assert_allclose(parts[:, 0, :].cpu().numpy(), whole[:, 0, :].cpu().numpy(), rtol=2e-5, atol=2e-4)
 
 
 @pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 4096, 8192])
@@ -897,60 +885,6 @@ def test_head_vs_torch_fp32(ops, B, K, x_act):
     ops.head_finish(scratch, B, lb2)
     torch.cuda.synchronize()
     assert torch.equal(lb2[:3], lb[:3])
-
-
-@pytest.mark.parametrize("M", [1024, 1000, 2048, 96, 33])
-def test_mlp_layer_chains_equal_per_layer_launches(ops, M):
-    """cdlrm_mlp_fwd_chain / cdlrm_mlp_dgrad_chain (one persistent launch, row blocks pinned to an XCD, per-row-block
-    dependency counters) against the same layers launched one by one: bit-identical outputs (same tile arithmetic), on the
-    top MLP's shapes and a ragged last row block; repeated launches reuse the sync words; the error word stays 0."""
-    g = torch.Generator().manual_seed(M)
-    dims = [480, 512, 512, 256]
-    X = (torch.randn(M, dims[0], generator=g) * 0.5).to(DEV)
-    Ws = [(torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i])).to(DEV) for i in range(3)]
-    bs = [torch.randn(dims[i + 1], generator=g).to(DEV) for i in range(3)]
-    Yc = [torch.empty(M, dims[i + 1], device=DEV) for i in range(3)]
-    Yl = [torch.empty(M, dims[i + 1], device=DEV) for i in range(3)]
-    plan = ops.ChainPlan("fwd", X, [(Ws[i], bs[i], Yc[i], 1) for i in range(3)], M, DEV)
-    for rep in range(3):
-        for y in Yc:
-            y.fill_(float("nan"))
-        ops.mlp_chain(plan)
-    cur = X
-    for i in range(3):
-        ops.linear_fwd(cur, Ws[i], bs[i], Yl[i], 1)
-        cur = Yl[i]
-    torch.cuda.synchronize()
-    assert plan.error() == 0
-    for i in range(3):
-        assert torch.equal(Yc[i], Yl[i]), i
-    ref = X.double()
-    for i in range(3):
-        ref = torch.relu(ref @ Ws[i].double().t() + bs[i].double())
-    np.testing.assert_allclose(Yc[2].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
-    # input-gradient chain, top-most layer first: dZ3 [M, 256] -> dX3 [M, 512] -> dX2 [M, 512] -> dX1 [M, 480]
-    dY = torch.randn(M, dims[3], generator=g).to(DEV)
-    ins = [X, Yl[0], Yl[1]]                      # input of layer i (ReLU outputs for i >= 1)
-    dXc = [torch.empty(M, dims[i], device=DEV) for i in range(3)]
-    dXl = [torch.empty(M, dims[i], device=DEV) for i in range(3)]
-    layers = [(Ws[i], ins[i] if i > 0 else None, 1 if i > 0 else 0, dXc[i]) for i in (2, 1, 0)]
-    dplan = ops.ChainPlan("dgrad", dY, layers, M, DEV)
-    for rep in range(2):
-        ops.mlp_chain(dplan)
-    cur = dY.clone()
-    for i in (2, 1, 0):
-        work = ops.linear_bwd_work(M, dims[i + 1], dims[i], DEV)
-        ops.linear_bwd(ins[i], Ws[i], None, cur, dXl[i], None, None, 0, work, x_act=1 if i > 0 else 0)
-        cur = dXl[i]
-    torch.cuda.synchronize()
-    assert dplan.error() == 0
-    for i in range(3):
-        assert torch.equal(dXc[i], dXl[i]), i
-    # sync == None (chained=False) and a single layer take the per-layer path inside the library
-    plan1 = ops.ChainPlan("fwd", X, [(Ws[0], bs[0], Yc[0], 1)], M, DEV)
-    Yc[0].fill_(0.0)
-    ops.mlp_chain(plan1)
-    assert torch.equal(Yc[0], Yl[0])
 
 
 def test_gather_launch_timing_events(ops):

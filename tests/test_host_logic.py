@@ -41,13 +41,13 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_launch_tape_generic_call(built_lib):
-    """csrc/tape.hip: the generic call reaches interleaved float / int32 / pointer / stack arguments and cells (the
+    """csrc/tape.hip: the typed call reaches interleaved float / int32 / pointer / int64 arguments and cells (the
     library's own self-test), and a tape built from Python replays a recorded call with a patched cell -- no GPU needed:
     the probe entry point only adds its arguments up."""
     import ctypes as C
     from cdlrm_amd import _lib
     assert built_lib.cdlrm_tape_selftest() == 0
-    assert _lib.native_tape_ok() == (os.environ.get("CDLRM_NATIVE_TAPE", "1") != "0")
+    assert _lib.native_tape_ok()
     L = _lib.raw()
     probe = L.cdlrm_tape_probe
     probe.restype = C.c_int
@@ -61,6 +61,9 @@ def test_launch_tape_generic_call(built_lib):
     assert tape.replay() == 0          # (the sums live in the library; the self-test above checks their values)
     with pytest.raises(_lib.TapeUnsupported):
         _lib.NativeTape([(print, ("x",), False)], {})
+    # an entry point that is not registered with its type in csrc/tape.hip is refused, not called through a guessed one
+    with pytest.raises(_lib.TapeUnsupported, match="not a registered tape entry point"):
+        _lib.NativeTape([(L.cdlrm_ctx_destroy, (None,), True)], {})
 
 
 def test_no_cpu_fallback():
@@ -239,3 +242,71 @@ def test_tape_recording_is_per_thread_and_destructors_bypass_it():
         _lib.stop_recording()
     import inspect
     assert "_lib.raw()" in inspect.getsource(ops.CacheCtx.__del__)
+
+
+@pytest.mark.parametrize("CH,nb,skip_next_at", [(16, 200, 63), (4, 37, 7), (1, 9, 3), (3, 10, None)])
+def test_window_resolver_ring_never_recycles_a_live_chunk(monkeypatch, CH, nb, skip_next_at):
+    """engine.WindowResolver keeps chunk results in a ring of three engine-owned buffers (no per-chunk allocation: the
+    caching allocator knows nothing about the prefetch / side streams that write and read them).  Host-side invariant,
+    checked here with the library call stubbed out: when chunk c's resolve is issued into slot c % 3, every batch of the
+    chunk that held the slot has already been handed out AND its step issued; bench.py's call pattern (batch j, batch
+    j + 1, ensure) including the iteration at which it hands no next batch over (the plan launch) runs to the end."""
+    import cdlrm_amd.engine as engine
+    issued = []
+
+    class Ctx:
+        T = 2
+
+    class Eng:
+        ctx, world, rank, dev = Ctx(), 1, 0, torch.device("cpu")
+        pref = side = engine.S._NullStream()
+        _bufs = {}
+
+    monkeypatch.setattr(engine.ops, "window_resolve",
+                        lambda ctx, cols, lbs, ws, wsrc, stream=None, batch_len=0: issued.append((ws.data_ptr(), cols.shape[1])))
+    B = 8
+    win = torch.zeros(2, nb * B, dtype=torch.int64)
+    eng = Eng()
+    rs = engine.WindowResolver(eng, win, B, chunk=CH)
+    stepped = -1                    # last batch whose step has been issued
+    seen_issue = len(issued)
+    for j in range(nb):
+        r = rs.batch(j)
+        assert r[0].shape == (2, B)
+        if j + 1 < nb and j != skip_next_at:
+            rs.batch(j + 1)
+        stepped = j                 # eng.step(...) would be issued here
+        rs.ensure(j + rs.CH + 2)
+        for c in range(seen_issue, len(issued)):        # chunk c was issued: the slot's previous holder is chunk c - 3
+            assert c < 3 or (c - 2) * CH - 1 <= stepped, (c, stepped)
+            assert issued[c][0] == issued[c % 3][0]     # ... and it is the ring slot, not a new allocation
+        seen_issue = len(issued)
+    assert len(issued) == -(-nb // CH)
+    assert len(eng._bufs) == 1
+
+
+def test_tape_registry_matches_the_ctypes_prototypes(built_lib):
+    """Every entry point a recorded step can issue is registered in csrc/tape.hip with its true C type, and that type has
+    the same number of integer-class and float parameters as the ctypes prototype the host marshals with (a mismatch would
+    make the native tape fall back to Python replay silently)."""
+    import ctypes as C
+    from cdlrm_amd import _lib
+    L = _lib.raw()
+    step_calls = {"cdlrm_embbag_probe", "cdlrm_embbag_take", "cdlrm_embbag_fwd", "cdlrm_embbag_bwd_prepare",
+                  "cdlrm_embbag_bwd_apply", "cdlrm_interact_fwd", "cdlrm_interact_bwd", "cdlrm_linear_fwd", "cdlrm_linear_bwd",
+                  "cdlrm_mlp_wgrad", "cdlrm_mlp_wgrad_sgd", "cdlrm_loss_fwd_bwd", "cdlrm_head_fwd_bwd", "cdlrm_head_finish",
+                  "cdlrm_act_bwd", "cdlrm_sgd_step", "cdlrm_sgd_step2", "cdlrm_scale_div", "cdlrm_ctx_time_next_gather",
+                  "cdlrm_event_record", "cdlrm_stream_wait_event"}
+    accepted = set()
+    for name, (res, argtypes) in _lib.PROTOTYPES.items():
+        if res is not C.c_int or name.startswith("cdlrm_tape_"):
+            continue
+        args = tuple(0.0 if ty is C.c_float else None if ty is C.c_void_p else 0 for ty in argtypes)
+        if any(hasattr(ty, "contents") for ty in argtypes):     # struct pointers: not step calls
+            continue
+        try:
+            _lib.NativeTape([(getattr(L, name), args, True)], {})
+            accepted.add(name)
+        except _lib.TapeUnsupported as e:
+            assert "not a registered tape entry point" in str(e), (name, str(e))
+    assert step_calls <= accepted, sorted(step_calls - accepted)

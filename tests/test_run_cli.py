@@ -295,8 +295,8 @@ def test_run_device_rng_lookahead_plan_equals_boundary_plan(capsys, monkeypatch)
     np.random.seed(seed)
     host0 = O.init_host_tables([int(n) for n in ln_emb], m_spa)
     outs = []
-    for look in ("1", "0"):
-        monkeypatch.setenv("CDLRM_RUN_LOOKAHEAD", look)
+    for at_boundary in (False, True):
+        args.plan_at_boundary = at_boundary
         eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
         for k in range(len(ln_emb)):
             eg.emb_l[k].weight.data = host0[k].clone()

@@ -148,26 +148,6 @@ def main():
         byt = B * (2 * F * D * 4 + (D + npairs) * 4)
         print("interact_bwd         %8.1f us   %7.1f GB/s" % (us, byt / us / 1e3))
 
-    if want("chain"):
-        # the top MLP's forward / input-gradient chains at a per-rank batch: one launch against three
-        dims = [480, 512, 512, 256]
-        M = B
-        X = torch.randn(M, dims[0], device=DEV)
-        Ws = [torch.randn(dims[i + 1], dims[i], device=DEV) / np.sqrt(dims[i]) for i in range(3)]
-        bs = [torch.randn(dims[i + 1], device=DEV) for i in range(3)]
-        Y = [torch.empty(M, dims[i + 1], device=DEV) for i in range(3)]
-        dXs = [torch.empty(M, dims[i], device=DEV) for i in range(3)]
-        dY = torch.randn(M, dims[3], device=DEV)
-        for chained in (False, True):
-            fp = ops.ChainPlan("fwd", X, [(Ws[i], bs[i], Y[i], 1) for i in range(3)], M, DEV, chained=chained)
-            ins = [X, Y[0], Y[1]]
-            dp = ops.ChainPlan("dgrad", dY, [(Ws[i], ins[i] if i > 0 else None, 1 if i > 0 else 0, dXs[i]) for i in (2, 1, 0)],
-                               M, DEV, chained=chained)
-            uf = timeit(lambda: ops.mlp_chain(fp))
-            ub = timeit(lambda: ops.mlp_chain(dp))
-            print("top MLP at M=%d, %s: forward %6.1f us   input gradients %6.1f us   (errors %d %d)" % (
-                M, "ONE launch each " if chained else "layer by layer  ", uf, ub, fp.error(), dp.error()))
-
     if want("gemm"):
         layers = [(13, 512, 1), (512, 256, 1), (256, 128, 1), (D + 351, 512, 1), (512, 512, 1), (512, 256, 1), (256, 1, 2)]
         tot_f = tot_b = 0.0
