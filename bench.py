@@ -269,6 +269,8 @@ def main():
             refills["first_commit_ms"] = (time.perf_counter() - t_c) * 1e3
         if timed:
             refills["commits"] += 1
+        if pipe.breakdown is not None:      # where this window's plan spent its time (first window: planned stand-alone)
+            refills["breakdown_first" if "breakdown_first" not in refills else "breakdown_last"] = dict(pipe.breakdown)
         state["win"], state["next"], state["w"] = state["next"], None, w
         # window-resident probe: the window's lookups are resolved against the new tags once, in chunks ahead of the
         # training position (streamed windows: per chunk, when the chunk is loaded)
@@ -313,7 +315,8 @@ def main():
         gev = ev_pool[j] if sample else (warm_pair if (not timed and a.gather_sample > 0 and sample_every == 1) else None)
         eng.step(X, idx, T, j=jj, gather_events=gev, next_idx=nxt,
                  res=rs.batch(jloc) if rs is not None else None,
-                 next_res=rs.batch(jloc + 1) if (rs is not None and nxt is not None) else None)
+                 next_res=rs.batch(jloc + 1) if (rs is not None and nxt is not None) else None,
+                 loss_sync=False)        # the loss buffer is read once, after finish()
         if rs is not None:
             rs.ensure(jloc + rs.CH + 2)
 
@@ -372,6 +375,10 @@ def main():
                        "dist_backend": dist.get_backend() if dist.is_initialized() else "none (one process, no collectives)",
                        "final_loss": loss, "setup_s": round(setup_s, 1),
                        "host_issue_ms_per_step": t_issued / a.steps * 1e3,
+                       # launch tapes of the step's control paths: replayed by one library call each (native) or from Python
+                       "launch_tapes": {"native": sum(1 for t in eng._tapes.values() if t["native"] is not None),
+                                        "python": sum(1 for t in eng._tapes.values() if t["native"] is None),
+                                        "fallback_reasons": sorted(set(eng.tape_fallbacks))[:4]},
                        # what of the look-ahead side fell INTO the timed steps (a 20-step run of a 3000-step window holds
                        # none; the default 3000-step run crosses one boundary and one background plan)
                        "refills_in_timed_region": {"window_commits": refills["commits"], "plans_launched": refills["plans"],
@@ -380,6 +387,13 @@ def main():
                        # runs in the background of the previous window in steady state) and of its commit (row swap +
                        # tag write on the main stream: the only part on the critical path), for amortising over L
                        "refill_cost": {"plan_ms_standalone": refills["first_plan_ms"],
+                                       # the stand-alone plan itemised (ms): GPU half (window scan, tag probe, way choice,
+                                       # victim list), list copies to the host, first-touch allocation of the pinned staging
+                                       # (first window only), CPU-thread row gather, DMA copies; `rows` = list lengths
+                                       "plan_breakdown_ms": refills.get("breakdown_first"),
+                                       # ... and of the last plan that ran in the background of the timed steps (steady state:
+                                       # staging already pinned; its GPU half shares the device with the training step)
+                                       "plan_breakdown_ms_background": refills.get("breakdown_last"),
                                        "commit_ms": refills["first_commit_ms"],
                                        "commit_ms_per_step_amortised": (refills["first_commit_ms"] / L)
                                        if refills["first_commit_ms"] is not None else None}},

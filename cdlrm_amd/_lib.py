@@ -98,7 +98,7 @@ PROTOTYPES = {
     "cdlrm_head_scratch_floats": (c_i64, []),
     "cdlrm_head_fwd_bwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32,
                                      vp, vp, vp, vp, c_i64, vp, vp, c_i32, vp]),
-    "cdlrm_head_finish": (C.c_int, [vp, c_i64, vp, vp]),
+    "cdlrm_head_finish": (C.c_int, [vp, c_i64, vp, vp, vp]),
     "cdlrm_sgd_step2": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, c_i64, C.c_float, vp]),
     "cdlrm_act_bwd": (C.c_int, [vp, c_i64, vp, c_i64, c_i64, c_i32, c_i32, vp]),
     "cdlrm_sgd_step": (C.c_int, [vp, vp, c_i64, c_f32, vp]),
@@ -115,6 +115,8 @@ PROTOTYPES = {
     "cdlrm_tape_selftest": (C.c_int, []),
     "cdlrm_event_record": (C.c_int, [vp, vp]),
     "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
+    "cdlrm_stream_create": (vp, [c_i32]),
+    "cdlrm_stream_destroy": (C.c_int, [vp]),
     "cdlrm_event_create": (vp, [c_i32]),
     "cdlrm_event_destroy": (C.c_int, [vp]),
     "cdlrm_event_elapsed_us": (C.c_int, [vp, vp, vp]),

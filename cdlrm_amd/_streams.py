@@ -37,6 +37,30 @@ def new_stream(device, priority=None):
     return torch.cuda.Stream(device=device) if priority is None else torch.cuda.Stream(device=device, priority=priority)
 
 
+_BACKGROUND = {}        # device index -> the process's background stream (created once, never destroyed)
+
+
+def background_stream(device):
+    """The look-ahead plan's stream: the LEAST urgent priority the device offers (torch's own stream pool only hands out
+    the default and the high level), created through the library and wrapped as a torch stream.  Where the plan's scans
+    and the training step compete for CUs the step goes first.  One per device and process, kept for the life of the
+    process: the caching allocator may hold events on it (record_stream) long after a pipeline is gone."""
+    if not is_hip(device):
+        return _NullStream()
+    from . import _lib
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _BACKGROUND.get(idx)
+    if st is None:
+        with torch.cuda.device(idx):
+            h = _lib.raw().cdlrm_stream_create(1 << 20)
+        if not h:
+            raise _lib.CdlrmError(-22, _lib.raw().cdlrm_last_error().decode("utf-8", "replace"))
+        st = torch.cuda.ExternalStream(int(h), device=torch.device("cuda", idx))
+        _BACKGROUND[idx] = st
+    return st
+
+
 def current_stream(device):
     return torch.cuda.current_stream(device) if is_hip(device) else _NullStream()
 

@@ -1285,7 +1285,7 @@ __global__ void __launch_bounds__(256) k_head(const float* __restrict__ Y, int64
 
 // fixed order for a given number of partials: lane i sums partials i, i + 64, ..., then a butterfly over the lanes
 __global__ void __launch_bounds__(64) k_head_finish(const float* __restrict__ scratch, int nparts, int64_t B,
-                                                    float* __restrict__ loss) {
+                                                    float* __restrict__ loss, double* __restrict__ acc) {
     const int lane = threadIdx.x;
     float s = 0.f, cnt = 0.f;
     for (int i = lane; i < nparts; i += 64) {
@@ -1297,7 +1297,12 @@ __global__ void __launch_bounds__(64) k_head_finish(const float* __restrict__ sc
     if (lane == 0) {
         loss[0] = s / (float)B;
         loss[1] = cnt;                              // correct predictions of this batch
-        loss[2] = (s / (float)B) * (float)B;        // L * mbs as the reference accumulates it (:433), in fp32
+        const float lm = (s / (float)B) * (float)B; // L * mbs as the reference accumulates it (:433), in fp32
+        loss[2] = lm;
+        if (acc) {                                  // running print statistics (main_no_ddp.py:427-433): float64 sums over steps
+            acc[0] += (double)cnt;
+            acc[1] += (double)lm;
+        }
     }
 }
 
@@ -1329,13 +1334,13 @@ extern "C" int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, c
 #undef HEAD_CALL
     CDLRM_LAUNCH_CHECK();
     if (tail) return 0;
-    if (finish) return cdlrm_head_finish(scratch, B, loss_out, stream);
+    if (finish) return cdlrm_head_finish(scratch, B, loss_out, nullptr, stream);
     return 0;
 }
 
-extern "C" int cdlrm_head_finish(const float* scratch, int64_t B, float* loss_out, void* stream) {
+extern "C" int cdlrm_head_finish(const float* scratch, int64_t B, float* loss_out, double* acc, void* stream) {
     CDLRM_REQUIRE(scratch && loss_out && B >= 1, "bad argument");
-    hipLaunchKernelGGL(k_head_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, (int)head_grid(B), B, loss_out);
+    hipLaunchKernelGGL(k_head_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, (int)head_grid(B), B, loss_out, acc);
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

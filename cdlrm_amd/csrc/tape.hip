@@ -168,6 +168,29 @@ extern "C" int cdlrm_stream_wait_event(void* stream, void* event) {
     return 0;
 }
 
+// A HIP stream at an explicit priority (hipDeviceGetStreamPriorityRange: numerically lower = more urgent; the value is
+// clamped into the device's range).  The look-ahead plan runs on the LEAST urgent one: its scans share the GPU with the
+// training step (main_no_ddp.py runs the same work in a separate Prefetcher process on CPU cores, cache_manager.py:66-115),
+// and where they compete for CUs the step goes first.
+extern "C" void* cdlrm_stream_create(int32_t priority) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    int p = priority;
+    if (p > least) p = least;
+    if (p < greatest) p = greatest;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p) != hipSuccess) {
+        cdlrm_set_error("cdlrm_stream_create: hipStreamCreateWithPriority failed");
+        return nullptr;
+    }
+    return (void*)s;
+}
+
+extern "C" int cdlrm_stream_destroy(void* stream) {
+    if (stream) CDLRM_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 // timing events of the library's own (a torch event has no HIP handle before its first record; a tape needs the handle
 // when it is built)
 extern "C" void* cdlrm_event_create(int32_t timing) {

@@ -105,7 +105,8 @@ class WindowPipeline:
         self.victims = [ops.Victims(self.ctx, victim_rows) for _ in range(2)] if victim_rows > 0 else None
         self._vnext = 0
         self.dev = cache_group.weight.device
-        self.side = S.new_stream(self.dev)
+        # the plan's stream: least urgent priority -- the window scan shares the GPU with the training step, which goes first
+        self.side = S.background_stream(self.dev)
         self.parity_rng, self.seed, self.avg = parity_rng, int(seed), average_on_writeback
         self.rank, self.world = rank, world_size
         self.multi = self.world > 1 or bool(force_collectives)
@@ -125,14 +126,33 @@ class WindowPipeline:
         self._worker = None          # background thread of a host-gather plan
         self._worker_err = None
         self._pin = {}               # pinned host staging, grown on demand
+        # where the last host-gather plan's time went (ms, host clock of the plan thread; `dma` from events at commit()):
+        # the GPU half (window scan, tag probe, way choice, victim list), list copies to the host, first-touch allocation of
+        # pinned staging (first window only, or when a list outgrows it), the CPU threads' row gather, the DMA copies
+        self.breakdown = None
+        self._bd = None
 
     def _pinned(self, key, shape, dtype):
         t = self._pin.get(key)
         if t is None or t.shape[0] < shape[0]:
+            import time as _time
+            t0 = _time.perf_counter()
             rows = int(shape[0] * 1.25) + 1024
             t = torch.empty((rows,) + tuple(shape[1:]), dtype=dtype, pin_memory=True)
             self._pin[key] = t
+            if self._bd is not None:
+                self._bd["pinned_alloc"] += (_time.perf_counter() - t0) * 1e3
         return t
+
+    def reserve_staging(self, win_rows: int, victim_rows: int):
+        """Allocate the pinned host staging of a host-gather plan up front (rows of the winners' / victims' lists a window
+        may produce): pinning GBs of host memory costs ~1 s the first time a plan needs it; a trainer that knows its window
+        size pays it at set-up, not inside its first window."""
+        D = self.ctx.D
+        for key, rows in (("win", win_rows), ("vic", victim_rows)):
+            if rows > 0:
+                self._pinned(key + "_idx", (int(rows),), torch.int64)
+                self._pinned(key + "_rows", (int(rows), D), torch.float32)
 
     def _shard_range(self, n, cap_rows):
         """This rank's slice of a list of n rows that travels as `world` equal chunks: (chunk, lo, hi), or None when the
@@ -148,22 +168,36 @@ class WindowPipeline:
     def _fetch_list(self, key, idx_dev, off, n, dst_dev, D):
         """Rows of one plan list (n entries, `off` = per-table offsets into it) -> dst_dev[:n]: CPU-thread gather into
         pinned staging + one DMA copy, of the whole list or of this rank's slice (the exchange is queued for commit())."""
-        side = self.side
+        import time as _time
+        side, bd = self.side, self._bd
         sh = self._shard_range(n, dst_dev.shape[0])
         chunk, lo, hi = sh if sh is not None else (0, 0, n)
         m = hi - lo
+        t0 = _time.perf_counter()
         idx_h = self._pinned(key + "_idx", (max(m, 1),), torch.int64)
         idx_h[:m].copy_(idx_dev[lo:hi], non_blocking=True)
         side.synchronize()
+        t1 = _time.perf_counter()
         if m > 0:
             rows_h = self._pinned(key + "_rows", (m, D), torch.float32)
+            t2 = _time.perf_counter()
             off_r = [min(max(int(o), lo), hi) - lo for o in off]
             ops.host_gather_rows(self.host_ptrs, idx_h, off_r, D, rows_h, self.gather_threads)
+            t3 = _time.perf_counter()
+            ev0, ev1 = S.new_event(self.dev, timing=True), S.new_event(self.dev, timing=True)
+            ev0.record(side)
             dst_dev[lo:hi].copy_(rows_h[:m], non_blocking=True)
+            ev1.record(side)
+            if bd is not None:
+                bd["cpu_gather"] += (t3 - t2) * 1e3
+                bd["_dma_events"].append((ev0, ev1))
+                bd["rows"][key] = m
+        if bd is not None:
+            bd["lists_to_host"] += (t1 - t0) * 1e3
         if sh is not None:
             self._exchange.append((dst_dev, chunk))
 
-    def _plan_host_gather(self, window_idx, lists_ready):
+    def _plan_host_gather(self, window_idx, lists_ready, t_launch):
         """Background half of a host-gather plan: wait for the winner / victim lists, copy them down, gather the rows on
         the CPU, issue the two DMA copies and the `planned` event on the plan stream."""
         try:
@@ -171,28 +205,25 @@ class WindowPipeline:
             torch.cuda.set_device(self.dev)
             plan, side, T, D = self.plan, self.side, self.ctx.T, self.ctx.D
             vic = self.victims[self._vnext] if self.victims is not None else None
-            t_0 = _time.perf_counter()
+            bd = self._bd = dict(gpu_scan_probe_assign=0.0, lists_to_host=0.0, pinned_alloc=0.0, cpu_gather=0.0, dma=None,
+                                 rows={}, threads=self.gather_threads, sharded=self.shard, _dma_events=[])
             lists_ready.synchronize()
-            t_lists = _time.perf_counter()
+            bd["gpu_scan_probe_assign"] = (_time.perf_counter() - t_launch) * 1e3
+            t0 = _time.perf_counter()
             _, _, wo = plan.offsets(stream=side)
             W = wo[T]
+            bd["lists_to_host"] += (_time.perf_counter() - t0) * 1e3
             with torch.cuda.stream(side):
-                t_g0 = _time.perf_counter()
                 self._fetch_list("win", plan.win_idx, wo, W, plan.stage, D)
-                t_g1 = _time.perf_counter()
-                V = 0
                 if vic is not None:
+                    t0 = _time.perf_counter()
                     voff = vic.off.cpu().tolist()
+                    bd["lists_to_host"] += (_time.perf_counter() - t0) * 1e3
                     V = min(voff[T], vic.cap)
                     voff = [min(o, V) for o in voff]
                     self._fetch_list("vic", vic.idx, voff, V, vic.rows, D)
-                t_g2 = _time.perf_counter()
-                if os.environ.get("CDLRM_PLAN_TIMING"):
-                    side.synchronize()
-                    print("[plan] rank %d lists %.0f ms | winners %d rows: %.0f ms | victims %d rows: %.0f ms | copies done "
-                          "+%.0f ms | threads %d | sharded %s" % (
-                              self.rank, (t_lists - t_0) * 1e3, W, (t_g1 - t_g0) * 1e3, V, (t_g2 - t_g1) * 1e3,
-                              (_time.perf_counter() - t_g2) * 1e3, self.gather_threads, bool(self._exchange)), flush=True)
+                bd["lists_to_host"] -= bd["pinned_alloc"]       # (allocations happen inside the timed list copies)
+                bd["host_total"] = (_time.perf_counter() - t_launch) * 1e3
                 if isinstance(window_idx, torch.Tensor) and window_idx.is_cuda:
                     window_idx.record_stream(side)
                 self.planned = S.new_event(self.dev)
@@ -219,7 +250,9 @@ class WindowPipeline:
         side.wait_stream(S.current_stream(self.dev))          # window_idx may have been produced there
         if self.host_gather:
             import threading
+            import time as _time
             assert self._worker is None, "the previous plan was never committed"
+            t_launch = _time.perf_counter()
             with S.on_stream(side):
                 self._unique(window_idx, side)
                 plan.probe(stream=side)
@@ -231,7 +264,8 @@ class WindowPipeline:
             self.planned = None
             self._worker_err = None
             self._exchange = []
-            self._worker = threading.Thread(target=self._plan_host_gather, args=(window_idx, lists_ready), daemon=True)
+            self._worker = threading.Thread(target=self._plan_host_gather, args=(window_idx, lists_ready, t_launch),
+                                            daemon=True)
             self._worker.start()
             self.window_no += 1
             return
@@ -268,6 +302,15 @@ class WindowPipeline:
                 raise self._worker_err
         assert self.planned is not None, "plan_window() first"
         main.wait_event(self.planned)
+        if self._bd is not None:
+            # the DMA copies' own duration (timing events around them on the plan stream; they have completed or are about
+            # to: this wait belongs to the refill either way)
+            bd, self._bd = self._bd, None
+            evs = bd.pop("_dma_events")
+            if evs and S.is_hip(self.dev):
+                evs[-1][1].synchronize()
+                bd["dma"] = float(sum(a.elapsed_time(b) for a, b in evs))
+            self.breakdown = bd
         # sharded fetch: every rank holds its slice of each list in place; one in-place all-gather per list (RCCL over
         # xGMI) completes them.  Issued here, on the main thread and stream, at the same point of the step sequence on
         # every rank, so it orders with the per-step gradient exchanges on the same communicator.
@@ -449,6 +492,11 @@ class TrainEngine:
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
                             emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne())
         self._head_scratch = ops.head_scratch(self.dev)
+        # running print statistics [correct predictions, loss * mbs] summed over steps in float64 on the device
+        # (main_no_ddp.py:427-433 keeps them on the host and synchronises twice per step for it): the head's finish launch adds
+        # to them; readers call finish() first and zero them when they start a new interval
+        self.stat_acc = torch.zeros(2, dtype=torch.float64, device=self.dev)
+        self.loss_sync = True                   # see step()
         # output head in one launch (last layer + loss + its input gradient) when the last top layer is 1-wide + sigmoid
         l_last, a_last = self.top[-1]
         self.fused_head = l_last.out_features == 1 and a_last == 2
@@ -467,6 +515,7 @@ class TrainEngine:
         self._gslot = None
         self._res = self._next_res = None
         self._tapes = {}
+        self.tape_fallbacks = []                # why a recorded step could not become a native tape (should stay empty)
         # schedule knobs (attributes, not environment switches: tests/test_engine_parity.py runs each of them both ways)
         self.use_tape = S.is_hip(self.dev)      # replay recorded launch sequences (_step_taped)
         self.native_tape = True                 # ... from the C side (csrc/tape.hip) instead of from Python
@@ -660,7 +709,7 @@ class TrainEngine:
 
     def step(self, X: torch.Tensor, lS_i: torch.Tensor, T: torch.Tensor, lS_o: Optional[torch.Tensor] = None,
              j: Optional[int] = None, gather_events: Optional[list] = None, next_idx: Optional[torch.Tensor] = None,
-             res=None, next_res=None):
+             res=None, next_res=None, loss_sync: bool = True):
         """One training iteration on this rank's slice (next_idx: the NEXT batch's indices, if it belongs to the same
         window: its tag probe and aux fill are then issued behind this step's embedding backward).  X [B, m_den] fp32, lS_i [T, n] int64, T [B, 1] fp32, all
         on the device; lS_o None = Criteo layout (one lookup per bag), else int64 [T, B] offsets -- or [T, B + 1] from
@@ -668,8 +717,13 @@ class TrainEngine:
         res / next_res: WindowResolver.batch(j) / .batch(j + 1) -- the window-resident probe: this batch's (the next
         batch's) slot ids and miss sources were resolved once for the whole window, the per-step tag probe shrinks to
         cdlrm_embbag_take.
-        Returns the device loss buffer (element 0 = BCE loss)."""
+        loss_sync=False: the loss buffer is completed OFF the training queue -- the head kernel leaves per-workgroup partial
+        sums, and the one-workgroup launch that adds them up (and accumulates `stat_acc`) runs on the side stream in front of
+        the embedding backward instead of holding the training queue for ~6 us; the returned buffer and `stat_acc` are then
+        valid after finish() (bench.py, Run), not right behind step() on the current stream.
+        Returns the device loss buffer (element 0 = the loss, 1 = correct predictions, 2 = loss * batch)."""
         B, n = X.shape[0], lS_i.shape[1]
+        self.loss_sync = bool(loss_sync) or not self.fused_head
         self._res, self._next_res = res, (next_res if next_idx is not None else None)
         if lS_o is not None:
             assert lS_o.shape[1] in (B, B + 1) and (not self.multi or lS_o.shape[1] == B)
@@ -886,11 +940,14 @@ class TrainEngine:
             ops.head_fwd_bwd(top_acts[-2][:, :l.in_features], self.W[l], l.bias.data, T, Z, buf["top_dy"][-1],
                              dX[:, :l.in_features], buf["loss"], self._head_scratch,
                              x_act=(self.top[-2][1] if n_top > 1 else 0), kind=self.loss_kind,
-                             weights=self.loss_weights, threshold=self.loss_threshold, Zc=buf["Zc"])
+                             weights=self.loss_weights, threshold=self.loss_threshold, Zc=buf["Zc"], finish=False)
+            if self.loss_sync:      # partial sums -> loss, running statistics: here, or on the side stream below
+                ops.head_finish(self._head_scratch, B, buf["loss"], acc=self.stat_acc)
             dY = dX
         else:
             ops.loss_fwd_bwd(Z, T, buf["loss"], buf["top_dy"][-1], kind=self.loss_kind, weights=self.loss_weights,
                              threshold=self.loss_threshold, Zc=buf["Zc"], sigmoid_bwd=(last_act == 2))
+            rec(self.stat_acc.add_, buf["loss"][1:3])
             dY = buf["top_dy"][-1]
         for i in reversed(range(n_top - 1 if fused_head else n_top)):
             l, act = self.top[i]
@@ -934,6 +991,10 @@ class TrainEngine:
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
         rec(ev["interacted"].record, main)
         rec(side.wait_event, ev["interacted"])
+        if fused_head and not self.loss_sync:
+            # the head's partial sums -> loss buffer + running statistics, off the training queue.  The next head kernel
+            # overwrites the partials only behind the next gather, which is ordered behind this stream's embedding update
+            ops.head_finish(self._head_scratch, B, buf["loss"], stream=side, acc=self.stat_acc)
         ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
                              cg.touched if self.multi else None, stream=side)
         emb_done = ev["emb_done"]
@@ -1062,7 +1123,7 @@ class TrainEngine:
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
-               self._gslot is not None,
+               self._gslot is not None, self.loss_sync,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
@@ -1104,8 +1165,9 @@ class TrainEngine:
                 # host time per step, more than the GPU needs at a per-rank batch of 1024)
                 try:
                     native = _lib.NativeTape(prog, cells)
-                except _lib.TapeUnsupported:
+                except _lib.TapeUnsupported as e:
                     native = None
+                    self.tape_fallbacks.append(str(e))      # this control path replays from Python (bench.py reports it)
             self._tapes[key] = dict(prog=prog, cells=cells, phase=self._phase, native=native,
                                     pref=None if post is None else (post["phase"], post["res"], post.get("chained_top", False),
                                                                     post.get("prepared", False)))

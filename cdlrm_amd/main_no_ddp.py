@@ -398,13 +398,14 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
                           world_size=world, host_gather=lookahead_plan)
 
-    # Print statistics (main_no_ddp.py:427-476) stay on the device between print boundaries: the loss / head kernel leaves
-    # [loss, #correct, loss * mbs] per step, ONE small add per step folds them into a float64 accumulator, and the host
-    # reads (and, at world > 1, all-reduces) it every print_freq iterations only.  The reference synchronises the device
+    # Print statistics (main_no_ddp.py:427-476) stay on the device between print boundaries: the head's finish launch adds
+    # [#correct, loss * mbs] of every step to the engine's float64 accumulator (`eng.stat_acc`, on the side stream: no launch on
+    # the training queue for it), and the host reads (and, at world > 1, all-reduces) it every print_freq iterations only.  The reference synchronises the device
     # twice per step for its timer (time_wrap, :401, 425) and moves Z and T to the host every step (:428-431); here the
     # wall time between two print boundaries, minus the refills and the test loop inside it, is the ms/it it prints --
     # the same quantity (iteration time without caching overhead) without stopping the pipeline every step.
-    acc = torch.zeros(2, dtype=torch.float64, device=dev)        # [sum of correct, sum of loss * mbs]
+    acc = eng.stat_acc                                           # [sum of correct, sum of loss * mbs]
+    acc.zero_()
     total_iter = total_samp = 0
     caching_overhead = []
     print_interval_stats = args.print_freq > 0
@@ -490,18 +491,19 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
             rs = resolver if (resolver is not None and Xr.shape[0] == resolver.width) else None
             lossbuf = eng.step(Xr, Ir, Tr, lS_o=Or, j=j, next_idx=nxt,
                                res=rs.batch(wj) if rs is not None else None,
-                               next_res=rs.batch(wj + 1) if (rs is not None and nxt is not None) else None)
+                               next_res=rs.batch(wj + 1) if (rs is not None and nxt is not None) else None,
+                               loss_sync=False)
             if rs is not None:
                 rs.ensure(wj + rs.CH + 2)
             wj += 1
             mbs = Tr.shape[0]
-            acc.add_(lossbuf[1:3])              # [#correct, loss * mbs] of this step, left there by the loss kernel
             total_iter += 1
             total_samp += mbs
             last = (j == len(train_ld) - 1)
             should_print = print_interval_stats and j > 0 and j % args.print_freq == 0
             should_test = test_ld is not None and ((j > 0 and args.test_freq > 0 and j % args.test_freq == 0) or last)
             if should_print:
+                eng.finish()                    # the statistics of the steps issued so far are complete behind this
                 if world > 1:
                     dist.all_reduce(acc)
                 torch.cuda.synchronize(dev)

@@ -516,8 +516,10 @@ def head_fwd_bwd(Y: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
                                         loss_buf.data_ptr(), scratch.data_ptr(), 1 if finish else 0, stream_ptr(stream)))
 
 
-def head_finish(scratch: torch.Tensor, B: int, loss_buf: torch.Tensor, stream=None):
-    check(_lib.lib().cdlrm_head_finish(scratch.data_ptr(), int(B), loss_buf.data_ptr(), stream_ptr(stream)))
+def head_finish(scratch: torch.Tensor, B: int, loss_buf: torch.Tensor, stream=None, acc: Optional[torch.Tensor] = None):
+    """acc: float64 [2] on the device, += [correct predictions, loss * B] of this batch."""
+    assert acc is None or (acc.dtype == torch.float64 and acc.numel() >= 2 and acc.is_contiguous())
+    check(_lib.lib().cdlrm_head_finish(scratch.data_ptr(), int(B), loss_buf.data_ptr(), ptr(acc), stream_ptr(stream)))
 
 
 def act_bwd(dX: torch.Tensor, X: torch.Tensor, act: int, stream=None):

@@ -389,14 +389,16 @@ int cdlrm_loss_fwd_bwd(const float* Z, const float* target, int64_t n, int32_t k
  * prediction, dZ [B] = dL/d(pre-activation of the last layer), dY [B, K] (pitch lddy; may be NULL) = dZ w^T times
  * the derivative of x_act, loss_out[0..2] as for cdlrm_loss_fwd_bwd.  scratch: cdlrm_head_scratch_floats() floats,
  * zeroed once by the caller (per-workgroup partial sums of the loss + one arrival counter the kernel leaves zero).  finish != 0: loss_out is complete when the call's work on `stream` is;
- * finish == 0: the partial sums are left in `scratch` and cdlrm_head_finish(scratch, B, loss_out, any stream ordered
- * behind this call) turns them into loss_out -- the training step runs it beside the backward, not in front of it. */
+ * finish == 0: the partial sums are left in `scratch` and cdlrm_head_finish(scratch, B, loss_out, acc, any stream ordered
+ * behind this call) turns them into loss_out -- the training step runs it beside the backward, not in front of it.
+ * acc (may be NULL): device float64 [2], acc[0] += correct predictions, acc[1] += loss * B of this batch -- the running sums
+ * the reference keeps on the host between two print boundaries (main_no_ddp.py:427-433), kept on the device instead. */
 int64_t cdlrm_head_scratch_floats(void);
 int cdlrm_head_fwd_bwd(const float* Y, int64_t ldy, const float* w, const float* bias, const float* target,
                        int64_t B, int32_t K, int32_t kind, float w0, float w1, float threshold, int32_t x_act,
                        float* Z, float* Zc, float* dZ, float* dY, int64_t lddy, float* loss_out, float* scratch,
                        int32_t finish, void* stream);
-int cdlrm_head_finish(const float* scratch, int64_t B, float* loss_out, void* stream);
+int cdlrm_head_finish(const float* scratch, int64_t B, float* loss_out, double* acc, void* stream);
 
 /* p -= lr * g over a flat fp32 buffer (optim.SGD without momentum, main_no_ddp.py:375, 415). */
 int cdlrm_sgd_step(float* param, const float* grad, int64_t n, float lr, void* stream);
@@ -436,6 +438,10 @@ int cdlrm_tape_selftest(void);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
 int cdlrm_event_record(void* event, void* stream);
 int cdlrm_stream_wait_event(void* stream, void* event);
+/* a stream at an explicit priority (lower = more urgent, clamped into the device's range): the look-ahead plan's stream is
+ * created at the least urgent level so that the training step goes first wherever the two compete for CUs */
+void* cdlrm_stream_create(int32_t priority);
+int cdlrm_stream_destroy(void* stream);
 /* events of the library's own (handles exist from creation on); elapsed time in microseconds, waits for `stop` */
 void* cdlrm_event_create(int32_t timing);
 int cdlrm_event_destroy(void* event);

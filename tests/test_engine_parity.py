@@ -56,13 +56,16 @@ def build(g, world=1, rank=0, host=None, aux_phases=2):
     ("train_stream", True, 2, False),
     # window-resident probe (engine.WindowResolver): the window's lookups resolved once per window, cdlrm_embbag_take per step
     ("train_small", True, 2, True), ("train_c1", True, 2, True), ("train_small", False, 2, True),
-    ("train_small", True, 1, True), ("train_stream", True, 2, True)])
+    ("train_small", True, 1, True), ("train_stream", True, 2, True),
+    # loss completed off the training queue (step(loss_sync=False), what bench.py and Run use): read behind finish()
+    ("train_small", True, 2, "async"), ("train_c1", True, 2, "async")])
 def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, resolved):
     """pipelined: the next batch's indices are handed to step() (as bench.py does inside a window), so its tag probe
     and aux-row fill run during the current step, into the other aux region (aux_phases = 2) or behind the current
     embedding update (aux_phases = 1).  Same trajectory either way."""
     g = golden(name)
     host, cg, dl, eng, pipe = build(g, aux_phases=aux_phases)
+    async_loss = resolved == "async"
     L = int(g["L"])
     batches = make_batches(g)
     dev_idx = [b[1].to(DEV) for b in batches]
@@ -83,11 +86,16 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, reso
         nxt = dev_idx[j + 1] if pipelined and j + 1 < len(batches) and (j + 1) % L != 0 else None
         loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt,
                         res=rs.batch(j % L) if rs is not None else None,
-                        next_res=rs.batch(j % L + 1) if (rs is not None and nxt is not None) else None)
+                        next_res=rs.batch(j % L + 1) if (rs is not None and nxt is not None) else None,
+                        loss_sync=not async_loss)
         if rs is not None:
             rs.ensure(j % L + rs.CH + 2)
-        losses.append(loss[0:1].clone())
-    losses = [float(x) for x in losses]
+        if async_loss:
+            eng.finish()
+        losses.append(loss[0:3].clone())
+    stats = eng.stat_acc.tolist()
+    np.testing.assert_allclose(stats, [sum(float(x[1]) for x in losses), sum(float(x[2]) for x in losses)], rtol=1e-12)
+    losses = [float(x[0]) for x in losses]
     cg.ctx.check()
     np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-5)
     occ = cg.occupancy_tables

@@ -882,9 +882,13 @@ def test_head_vs_torch_fp32(ops, B, K, x_act):
     ops.head_fwd_bwd(Yd[:, :K], w.to(DEV), b.to(DEV), tt.to(DEV), Z, dZ, dYd[:, :K], lb2, scratch, x_act=x_act, finish=False)
     torch.cuda.synchronize()
     assert float(lb2[0]) == -1.0
-    ops.head_finish(scratch, B, lb2)
+    acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    ops.head_finish(scratch, B, lb2, acc=acc)
     torch.cuda.synchronize()
     assert torch.equal(lb2[:3], lb[:3])
+    # ... and the running float64 sums of [correct predictions, loss * B] over steps (main_no_ddp.py:427-433)
+    ops.head_finish(scratch, B, lb2, acc=acc)
+    assert acc.tolist() == [2.0 * float(lb[1]), 2.0 * float(lb[2])]
 
 
 def test_gather_launch_timing_events(ops):
