@@ -173,11 +173,14 @@ class WindowPipeline:
         sh = self._shard_range(n, dst_dev.shape[0])
         chunk, lo, hi = sh if sh is not None else (0, 0, n)
         m = hi - lo
+        alloc0 = bd["pinned_alloc"] if bd is not None else 0.0
         t0 = _time.perf_counter()
         idx_h = self._pinned(key + "_idx", (max(m, 1),), torch.int64)
         idx_h[:m].copy_(idx_dev[lo:hi], non_blocking=True)
         side.synchronize()
         t1 = _time.perf_counter()
+        if bd is not None:          # (a first-touch allocation of the index staging is itemised as pinned_alloc, not here)
+            bd["lists_to_host"] -= bd["pinned_alloc"] - alloc0
         if m > 0:
             rows_h = self._pinned(key + "_rows", (m, D), torch.float32)
             t2 = _time.perf_counter()
@@ -222,7 +225,6 @@ class WindowPipeline:
                     V = min(voff[T], vic.cap)
                     voff = [min(o, V) for o in voff]
                     self._fetch_list("vic", vic.idx, voff, V, vic.rows, D)
-                bd["lists_to_host"] -= bd["pinned_alloc"]       # (allocations happen inside the timed list copies)
                 bd["host_total"] = (_time.perf_counter() - t_launch) * 1e3
                 if isinstance(window_idx, torch.Tensor) and window_idx.is_cuda:
                     window_idx.record_stream(side)
