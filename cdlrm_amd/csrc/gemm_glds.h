@@ -330,7 +330,16 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
 //     tile traffic into the CU's LDS itself, not the issue slots;
 //   * starting half of the workgroups 2.5-8 k cycles late so that the store tails of the co-resident pairs do not
 //     coincide: 40.6 against 42.0 us on the forward layout, nothing on the weight-gradient layout;
-//   * 128x128 tiles (one workgroup per CU): 42.3-43.4 us, no better than 128x64 with two.
+//   * 128x128 tiles (one workgroup per CU): 42.3-43.4 us, no better than 128x64 with two;
+//   * (round 3) the output tile taken through LDS behind the loop and stored row-major -- a wave instruction = 4 whole rows of
+//     256 bytes instead of 32 rows x 32 bytes, the dgrad's mask read the same way: bit-identical, and no faster in the step
+//     (tools/ab_step.py, c3: 0.6481 against 0.6463 ms; c5: 4.139 against 4.132): the store tail is not bound by the number
+//     of write requests;
+//   * (round 3) a whole MLP direction as ONE launch, a workgroup taking 32 rows through every layer (no launch boundaries, no
+//     lock-step tail; weights streamed per workgroup, the activations re-read from L2): correct, and LDS-bound -- a 32-row
+//     block moves 2.3x the LDS bytes per MFMA of the 128x64 tile (136 KB of stages, 62 % of the LDS bandwidth at the MFMA
+//     rate) -- top MLP forward 100 us against 108 layer by layer, its input-gradient chain 124 against 106, bottom MLP 63
+//     against 51; in the step 0.647 (top forward only) / 0.672 / 0.717 ms (all four chains) against 0.646.  Removed.
 // Where a workgroup's 83 k cycles go at 8192 x 512 x 512 (128x64 tile, two workgroups per CU, 2.3-2.4 GHz): prologue 2.5 k,
 // loop 73.7 k (ideal 65.5 k), epilogue 10.5 k -- the 16 MB of output leave all 512 workgroups at the same moment.
 

@@ -21,7 +21,8 @@ from cdlrm_amd.engine import WindowResolver  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--attr", required=True, help="TrainEngine attribute to switch")
+    ap.add_argument("--attr", required=True, help="TrainEngine attribute to switch; debug:<key> = a development toggle "
+                                                  "inside the library (cdlrm_debug_set, when the build has one)")
     ap.add_argument("--values", required=True, help="values separated by ';' (python literals)")
     ap.add_argument("--config", default="c3")
     ap.add_argument("--batch", type=int, default=-1)
@@ -57,15 +58,26 @@ def main():
             if pos[0] % (L - 1) == 0:       # wrapped: the resolver's chunks are behind us -- start over
                 raise SystemExit("window exhausted: raise --steps margin")
 
+    if a.attr.startswith("debug:"):
+        from cdlrm_amd import _lib
+        key = int(a.attr.split(":")[1])
+        fn = _lib.raw().cdlrm_debug_set
+
+        def set_knob(v):
+            torch.cuda.synchronize()
+            assert fn(key, int(v)) == 0
+    else:
+        def set_knob(v):
+            setattr(eng, a.attr, v)
     res = {repr(v): [] for v in vals}
     nper = max(20, a.steps // (a.rounds * len(vals)) - 10)
     for v in vals:                           # warm every control path
-        setattr(eng, a.attr, v)
+        set_knob(v)
         run(10)
     torch.cuda.synchronize()
     for r in range(a.rounds):
         for v in vals:
-            setattr(eng, a.attr, v)
+            set_knob(v)
             run(3)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
