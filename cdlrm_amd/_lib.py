@@ -112,6 +112,7 @@ PROTOTYPES = {
     "cdlrm_tape_cells": (vp, [vp]),
     "cdlrm_tape_length": (c_i64, [vp]),
     "cdlrm_tape_replay": (C.c_int, [vp]),
+    "cdlrm_tape_set_lanes": (C.c_int, [vp, vp, vp, c_i64]),
     "cdlrm_tape_selftest": (C.c_int, []),
     "cdlrm_event_record": (C.c_int, [vp, vp]),
     "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
@@ -224,7 +225,10 @@ class NativeTape:
     Library calls are stored by address with their arguments split by register class (ctypes argtypes tell which);
     torch stream / event calls become cdlrm_stream_wait_event / cdlrm_event_record on the raw HIP handles."""
 
-    def __init__(self, prog, cells: dict):
+    def __init__(self, prog, cells: dict, main_stream: Optional[int] = None):
+        """main_stream: raw handle of the training queue's stream.  Given (and not the null stream), the tape is replayed in
+        two lanes: ops on that stream by the replaying thread, every other stream's by the library's helper thread, ordered
+        against each other on the host the way their events order them on the GPU (cdlrm_tape_set_lanes)."""
         import torch
         L = raw()
         order = list(cells.values())
@@ -235,10 +239,15 @@ class NativeTape:
         if not h:
             raise CdlrmError(-22, L.cdlrm_last_error().decode("utf-8", "replace"))
         self._h = h
+        ops = []
         try:
             for fn, args, _ in prog:
                 for target, cargs in self._translate(fn, args, torch):
                     self._add(L, target, cargs, index)
+                    ops.append((target, cargs))
+            self.lanes = 1
+            if main_stream:
+                self.lanes = self._set_lanes(L, ops, int(main_stream))
         except Exception:
             L.cdlrm_tape_destroy(h)
             self._h = None
@@ -263,6 +272,40 @@ class NativeTape:
             return [(L.cdlrm_event_record, (ev.cuda_event, args[0].cuda_stream)),
                     (L.cdlrm_stream_wait_event, (obj.cuda_stream, ev.cuda_event))]
         raise TapeUnsupported(repr(fn))
+
+    def _set_lanes(self, L, ops, main_stream: int) -> int:
+        """Split the recorded ops by stream and order the lanes on every event both of them touch."""
+        names = [getattr(fn, "__name__", "") for fn, _ in ops]
+        val = lambda a: (a.value or 0) if isinstance(a, C._SimpleCData) else (0 if a is None else a)
+        streams, events = [], []
+        for (fn, args), name in zip(ops, names):
+            if name == "cdlrm_stream_wait_event":
+                streams.append(int(val(args[0]))); events.append(int(val(args[1])))
+            elif name == "cdlrm_event_record":
+                streams.append(int(val(args[1]))); events.append(int(val(args[0])))
+            elif name == "cdlrm_ctx_time_next_gather":      # no stream of its own: it arms the NEXT gather launch
+                streams.append(None); events.append(None)
+            else:
+                streams.append(int(val(args[-1]))); events.append(None)     # kernel entry points: the stream is the last argument
+        lane = [0] * len(ops)
+        nxt = 0
+        for k in reversed(range(len(ops))):
+            if streams[k] is not None:
+                nxt = 0 if streams[k] == main_stream else 1
+            lane[k] = nxt
+        dep, last = [-1] * len(ops), {}
+        for k in range(len(ops)):
+            e = events[k]
+            if e is None:
+                continue
+            if e in last and lane[last[e]] != lane[k]:
+                dep[k] = last[e]
+            last[e] = k
+        if 1 not in lane:
+            return 1
+        n = len(ops)
+        check(L.cdlrm_tape_set_lanes(self._h, (C.c_int32 * n)(*lane), (C.c_int32 * n)(*dep), n))
+        return 2
 
     @staticmethod
     def _event(ev) -> int:

@@ -521,6 +521,9 @@ class TrainEngine:
         # schedule knobs (attributes, not environment switches: tests/test_engine_parity.py runs each of them both ways)
         self.use_tape = S.is_hip(self.dev)      # replay recorded launch sequences (_step_taped)
         self.native_tape = True                 # ... from the C side (csrc/tape.hip) instead of from Python
+        # ... in two lanes: the training queue's calls by this thread, the side queues' by the library's helper thread.  At a
+        # per-rank batch of 1024 the thread that issues a step's ~45 runtime calls, not the GPU, sets the step time
+        self.tape_lanes = 2
         self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
         self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
 
@@ -1125,7 +1128,7 @@ class TrainEngine:
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
-               self._gslot is not None, self.loss_sync,
+               self._gslot is not None, self.loss_sync, self.tape_lanes,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
@@ -1166,7 +1169,7 @@ class TrainEngine:
                 # the same calls as a C-side tape: one library call per step instead of ~45 interpreted ones (0.22 ms of
                 # host time per step, more than the GPU needs at a per-rank batch of 1024)
                 try:
-                    native = _lib.NativeTape(prog, cells)
+                    native = _lib.NativeTape(prog, cells, main_stream=main.cuda_stream if self.tape_lanes == 2 else None)
                 except _lib.TapeUnsupported as e:
                     native = None
                     self.tape_fallbacks.append(str(e))      # this control path replays from Python (bench.py reports it)

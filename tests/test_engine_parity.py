@@ -166,11 +166,13 @@ def test_chained_take_long_batch_path(golden, name, defer, chunk, delay):
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["train_small", "train_c1"])
-def test_native_tape_replays_the_recorded_step(golden, name):
+@pytest.mark.parametrize("name,long_batch", [("train_small", False), ("train_c1", False), ("train_c1", True)])
+def test_native_tape_replays_the_recorded_step(golden, name, long_batch):
     """The C-side launch tape (csrc/tape.hip: one library call re-issues the ~45 recorded calls of a step, event records
     and stream waits included) against the same tape replayed from Python: bit-identical losses, tags and weights; and
-    the native tapes really are the ones that ran."""
+    the native tapes really are the ones that ran -- single-lane on the null stream, and in TWO LANES on a stream of the
+    trainer's own (what bench.py and Run use): the training queue's calls issued by this thread, the side queues' by the
+    library's helper thread, ordered on the host by the events they share.  long_batch: the chained-take schedule."""
     from cdlrm_amd import _lib
     from cdlrm_amd.engine import WindowResolver
     assert _lib.native_tape_ok()
@@ -178,9 +180,32 @@ def test_native_tape_replays_the_recorded_step(golden, name):
     L = int(g["L"])
     batches = make_batches(g)
     runs = []
-    for native in (False, True):
+    for native in (False, True, "lanes"):
+        if native == "lanes":
+            torch.cuda.synchronize()
+            own = torch.cuda.Stream(priority=-1)
+            own.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(own):
+                runs.append(_native_tape_run(g, batches, L, True, long_batch, want_lanes=2))
+            torch.cuda.current_stream().wait_stream(own)
+        else:
+            runs.append(_native_tape_run(g, batches, L, native, long_batch, want_lanes=1))
+    for r in runs[1:]:
+        assert torch.equal(runs[0][0], r[0])
+        assert torch.equal(runs[0][1], r[1]) and torch.equal(runs[0][2], r[2])
+        for a, b in zip(runs[0][3], r[3]):
+            assert torch.equal(a, b)
+    np.testing.assert_allclose(runs[1][0].numpy(), g["losses"], rtol=1e-5)
+
+
+def _native_tape_run(g, batches, L, native, long_batch, want_lanes):
+    from cdlrm_amd import _lib
+    from cdlrm_amd.engine import WindowResolver
+    if True:
         host, cg, dl, eng, pipe = build(g, aux_phases=2)
-        eng.native_tape = native
+        eng.native_tape = bool(native)
+        if long_batch:
+            eng.gather_alone_min = 1
         dev_idx = [b[1].to(DEV) for b in batches]
         losses = []
         for j, (X, lS_i, Tt) in enumerate(batches):
@@ -200,16 +225,12 @@ def test_native_tape_replays_the_recorded_step(golden, name):
         eng.finish()
         torch.cuda.synchronize()
         n_native = sum(1 for t in eng._tapes.values() if t["native"] is not None)
-        assert (n_native > 0) == native and len(eng._tapes) > 0
+        assert (n_native > 0) == bool(native) and len(eng._tapes) > 0 and not eng.tape_fallbacks
         if native:
             assert all(int(_lib.raw().cdlrm_tape_length(t["native"]._h)) >= len(t["prog"]) for t in eng._tapes.values())
-        runs.append((torch.cat(losses).cpu(), cg.tags.cpu().clone(), cg.weight.data.cpu().clone(),
-                     [l.weight.data.cpu().clone() for l in dl.top_l if hasattr(l, "weight")]))
-    assert torch.equal(runs[0][0], runs[1][0])
-    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
-    for a, b in zip(runs[0][3], runs[1][3]):
-        assert torch.equal(a, b)
-    np.testing.assert_allclose(runs[1][0].numpy(), g["losses"], rtol=1e-5)
+            assert all(t["native"].lanes == want_lanes for t in eng._tapes.values())
+        return (torch.cat(losses).cpu(), cg.tags.cpu().clone(), cg.weight.data.cpu().clone(),
+                [l.weight.data.cpu().clone() for l in dl.top_l if hasattr(l, "weight")])
 
 
 def test_host_gather_plan_equals_device_fetch(golden):

@@ -310,3 +310,43 @@ def test_tape_registry_matches_the_ctypes_prototypes(built_lib):
         except _lib.TapeUnsupported as e:
             assert "not a registered tape entry point" in str(e), (name, str(e))
     assert step_calls <= accepted, sorted(step_calls - accepted)
+
+
+def test_two_lane_tape_replay_orders_the_lanes(built_lib):
+    """csrc/tape.hip, two-lane replay: lane-0 ops are issued by the replaying thread, lane-1 ops by the library's helper
+    thread at the same time; an op with a dependency is held back until the named op of the other lane has been issued (the
+    host-side order of record / wait calls on one event), and each lane keeps its own tape order.  A logging probe stands in
+    for the runtime calls: no GPU involved."""
+    import ctypes as C
+    from cdlrm_amd import _lib
+    L = _lib.raw()
+    log = L.cdlrm_tape_probe_log
+    log.restype, log.argtypes = C.c_int, [C.c_int64, C.c_int64]
+    take = L.cdlrm_tape_probe_log_take
+    take.restype, take.argtypes = C.c_int64, [C.c_void_p, C.c_int64]
+    buf = (C.c_int64 * 4096)()
+    take(buf, 4096)
+    n = 40
+    # (a) a chain across the lanes: op k waits for op k - 1 of the other lane -> the global order is 0, 1, 2, ...
+    tape = _lib.NativeTape([(log, (k, 2000 * (k % 3)), True) for k in range(n)], {})
+    lane = (C.c_int32 * n)(*[k % 2 for k in range(n)])
+    dep = (C.c_int32 * n)(*[k - 1 for k in range(n)])
+    _lib.check(L.cdlrm_tape_set_lanes(tape._h, lane, dep, n))
+    for _ in range(50):
+        assert tape.replay() == 0
+        assert take(buf, 4096) == n and list(buf[:n]) == list(range(n))
+    # (b) no dependencies: each lane in its own tape order, the two free against each other
+    tape2 = _lib.NativeTape([(log, (k, 500), True) for k in range(n)], {})
+    lane2 = [0 if k % 3 else 1 for k in range(n)]
+    _lib.check(L.cdlrm_tape_set_lanes(tape2._h, (C.c_int32 * n)(*lane2), (C.c_int32 * n)(*([-1] * n)), n))
+    for _ in range(50):
+        assert tape2.replay() == 0
+        assert take(buf, 4096) == n
+        got = list(buf[:n])
+        for ln in (0, 1):
+            assert [k for k in got if lane2[k] == ln] == [k for k in range(n) if lane2[k] == ln]
+    # (c) a dependency on a LATER op or on the same lane is refused
+    bad = (C.c_int32 * n)(*([-1] * (n - 1) + [n - 1]))
+    assert L.cdlrm_tape_set_lanes(tape2._h, (C.c_int32 * n)(*lane2), bad, n) != 0
+    same = (C.c_int32 * n)(*([-1, -1, 1] + [-1] * (n - 3)))     # op 2 (lane 0) on op 1 (lane 0)
+    assert L.cdlrm_tape_set_lanes(tape2._h, (C.c_int32 * n)(*lane2), same, n) != 0
