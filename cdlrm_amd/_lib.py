@@ -106,6 +106,7 @@ PROTOTYPES = {
     "cdlrm_scatter_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, C.c_int, vp]),
     "cdlrm_blend_rows": (C.c_int, [vp, vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_mark_rows": (C.c_int, [vp, vp, c_i64, vp, vp]),
+    "cdlrm_synth_indices": (C.c_int, [vp, c_i64, c_i64, c_i64, C.c_double, c_u64, vp]),
     "cdlrm_tape_create": (vp, [c_i32]),
     "cdlrm_tape_destroy": (None, [vp]),
     "cdlrm_tape_add": (C.c_int, [vp, vp, c_i32, vp, vp, c_i32, vp]),

@@ -339,7 +339,10 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
 //     lock-step tail; weights streamed per workgroup, the activations re-read from L2): correct, and LDS-bound -- a 32-row
 //     block moves 2.3x the LDS bytes per MFMA of the 128x64 tile (136 KB of stages, 62 % of the LDS bandwidth at the MFMA
 //     rate) -- top MLP forward 100 us against 108 layer by layer, its input-gradient chain 124 against 106, bottom MLP 63
-//     against 51; in the step 0.647 (top forward only) / 0.672 / 0.717 ms (all four chains) against 0.646.  Removed.
+//     against 51; in the step 0.647 (top forward only) / 0.672 / 0.717 ms (all four chains) against 0.646.  Removed;
+//   * (round 3) the split-M weight gradients of a sub-network's layers as ONE grouped launch of this kernel (1536 workgroups
+//     for the top MLP: one ramp, the problems' store tails under each other's loops): 0.667 against 0.641 ms per step --
+//     the side queue's kernel then holds every workgroup slot for 250 us and the training queue's GEMMs wait for slots.
 // Where a workgroup's 83 k cycles go at 8192 x 512 x 512 (128x64 tile, two workgroups per CU, 2.3-2.4 GHz): prologue 2.5 k,
 // loop 73.7 k (ideal 65.5 k), epilogue 10.5 k -- the 16 MB of output leave all 512 workgroups at the same moment.
 

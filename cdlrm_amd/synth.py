@@ -9,14 +9,15 @@ restates the batch LAYOUT the hot path consumes, exactly as data_loader_terabyte
     lS_i int64 [T, B]       sparse indices
     T    fp32  [B, 1]       click targets in {0, 1}
 
-Indices are counter-based: window w is a pure function of (seed, w), generated on the device, so the
-trainer-side batches and the look-ahead side see identical data without a second loader
-(dlrm_data_pytorch.py:465-483 relies on two loaders over the same data for this).
+Indices are counter-based: lookup p of table k is a pure function of (seed, k, p) (csrc/synth.hip, one launch per
+table), so the trainer-side batches and the look-ahead side regenerate identical data independently, in any chunking,
+without a second loader (dlrm_data_pytorch.py:465-483 relies on two loaders over the same data for this).
 """
 from __future__ import annotations
 
 from typing import List, Sequence
 
+import numpy as np
 import torch
 
 # public Criteo cardinalities (SURVEY.md 8): the reference reads them from *_fea_count.npz
@@ -38,31 +39,56 @@ class CriteoSynth:
         self.T_pool = torch.round(torch.rand(pool, self.B, 1, generator=g, device=self.device))
         self.pool = pool
 
-    def _table_indices(self, g, n: int, count: int) -> torch.Tensor:
-        u = torch.rand(count, generator=g, device=self.device, dtype=torch.float64)
-        if self.alpha <= 0.0:                      # uniform: worst-case hit rate
-            r = torch.floor(u * n).to(torch.int64)
+    @staticmethod
+    def _mix64(z: np.ndarray) -> np.ndarray:
+        """splitmix64 finaliser on uint64 arrays (csrc/synth.hip: synth_mix64)."""
+        with np.errstate(over="ignore"):
+            z = z + np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return z ^ (z >> np.uint64(31))
+
+    def _key(self, k: int) -> int:
+        """The key of table k's lookup stream."""
+        z = (self.seed * 0x9E3779B97F4A7C15 + (k + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        return int(self._mix64(np.array([z], dtype=np.uint64))[0])
+
+    def _table_indices_host(self, k: int, n: int, first: int, count: int) -> torch.Tensor:
+        """The stream of csrc/synth.hip restated in numpy (CPU device: the oracle's baseline run, CPU tests).  Same integers
+        wherever float64 pow rounds alike on host and device (a last-place difference can move a rank across an integer
+        boundary for a few lookups in a million)."""
+        with np.errstate(over="ignore"):
+            z = self._mix64(np.uint64(self._key(k)) + np.arange(first, first + count, dtype=np.uint64))
+        u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        a = self.alpha
+        if a <= 0.0:
+            r = np.minimum(np.floor(u * n).astype(np.int64), n - 1)
         else:
-            a = self.alpha
             if abs(a - 1.0) < 1e-9:
-                x = torch.exp(u * torch.log(torch.tensor(float(n + 1), dtype=torch.float64, device=self.device)))
+                x = np.exp(u * np.log(float(n) + 1.0))
             else:
-                top = float(n + 1) ** (1.0 - a) - 1.0
-                x = (top * u + 1.0) ** (1.0 / (1.0 - a))
-            r = torch.floor(x).to(torch.int64) - 1   # Zipf-like rank in [0, n)
-            r.clamp_(0, n - 1)
-            r = (r * 2654435761 + 40503) % n         # scatter the hot ranks over the id space
-        return r
+                x = (((float(n) + 1.0) ** (1.0 - a) - 1.0) * u + 1.0) ** (1.0 / (1.0 - a))
+            r = np.clip(np.floor(x).astype(np.int64) - 1, 0, n - 1)
+            r = ((r.astype(np.uint64) * np.uint64(2654435761) + np.uint64(40503)) % np.uint64(n)).astype(np.int64)
+        return torch.from_numpy(r)
 
     def window(self, w: int, num_batches: int) -> torch.Tensor:
         """Indices of `num_batches` consecutive batches starting at batch w*num_batches: int64 [T, num_batches*B];
-        batch j of the window is columns [j*B, (j+1)*B)."""
-        g = torch.Generator(device=self.device)
-        g.manual_seed((self.seed * 1000003 + int(w)) & 0x7FFFFFFFFFFF)
+        batch j of the window is columns [j*B, (j+1)*B).  Table k's row is lookups [w * num_batches * B, ...) of its
+        counter-based stream: the same batches whatever the window / chunk size they are asked for in."""
         count = num_batches * self.B
+        first = int(w) * count
         out = torch.empty(len(self.ln_emb), count, dtype=torch.int64, device=self.device)
-        for k, n in enumerate(self.ln_emb):
-            out[k] = self._table_indices(g, n, count)
+        if self.device.type != "cuda":
+            for k, n in enumerate(self.ln_emb):
+                out[k] = self._table_indices_host(k, n, first, count)
+            return out
+        from . import _lib
+        L = _lib.lib()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            for k, n in enumerate(self.ln_emb):
+                _lib.check(L.cdlrm_synth_indices(out[k].data_ptr(), count, first, n, float(self.alpha), self._key(k), st))
         return out
 
     def dense(self, j: int):

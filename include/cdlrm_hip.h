@@ -416,6 +416,13 @@ int cdlrm_sgd_step2(float* param, const float* grad, int64_t off0, int64_t n0, i
 /* x /= divisor (aggregate_gradients: layer.weight.grad /= world_size, main_no_ddp.py:239, 244). */
 int cdlrm_scale_div(float* x, int64_t n, float divisor, void* stream);
 
+/* ---- synthetic input (cdlrm_amd/synth.py; the reference has no Criteo-shaped generator: dlrm_data_pytorch.py:763-805 is
+ * uniform multi-hot) ---------------------------------------------------------------------------------------------------------
+ * out[i] = index of lookup first + i of one table's infinite, counter-based lookup stream: Zipf-like ranks (exponent alpha;
+ * <= 0: uniform) scattered over [0, n_rows).  A pure function of (key, position): the trainer's batches and the look-ahead's
+ * second pass over the same indices (cache_manager.py:87-90) regenerate identical data independently, one launch per table. */
+int cdlrm_synth_indices(int64_t* out, int64_t count, int64_t first, int64_t n_rows, double alpha, uint64_t key, void* stream);
+
 /* ---- launch tapes -------------------------------------------------------------------------------------------------
  * A training step's call sequence (this library's entry points + event records / stream waits), recorded once per control
  * path by the host and re-issued by ONE call per step (the reference issues the same ops from Python every iteration,

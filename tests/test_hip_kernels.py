@@ -989,3 +989,30 @@ def test_embbag_multihot_empty_bags_and_scratch_bag(ops, T, nb, D):
         w = w0[k].clone()
         O.embbag_bwd_sgd(w, real_slots, real_offs, grad[:real_b, k, :], 0.3)
         np.testing.assert_allclose(st.w(k).numpy(), w.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("alpha", [1.05, 1.0, 0.0])
+def test_synthetic_index_stream_device_vs_host(ops, alpha):
+    """cdlrm_synth_indices (csrc/synth.hip): the counter-based index stream of cdlrm_amd.synth.CriteoSynth generated on the
+    device against its numpy restatement -- the same integers except where float64 pow rounds differently on host and device
+    (a handful of lookups in a million, each landing on a neighbouring rank) --, inside every table's range, and independent of
+    how the stream is cut into windows / chunks (the look-ahead plan and the trainer ask for different chunkings)."""
+    from cdlrm_amd.synth import CriteoSynth
+    ln = [39884406, 17289, 3, 2953546, 1]
+    B = 1000
+    dev_s = CriteoSynth(ln, 13, B, seed=77, alpha=alpha, device=DEV)
+    cpu_s = CriteoSynth(ln, 13, B, seed=77, alpha=alpha, device="cpu")
+    a = dev_s.window(3, 7).cpu()
+    b = cpu_s.window(3, 7)
+    assert a.shape == b.shape == (5, 7000) and a.dtype == torch.int64
+    for k, n in enumerate(ln):
+        assert int(a[k].min()) >= 0 and int(a[k].max()) < n
+    assert float((a != b).double().mean()) < 1e-4
+    # chunking independence: batches 21 .. 27 as one window of 7, or as seven windows of 1
+    parts = torch.cat([dev_s.window(21 + j, 1) for j in range(7)], dim=1).cpu()
+    assert torch.equal(parts, a)
+    # another seed, another stream
+    assert not torch.equal(CriteoSynth(ln, 13, B, seed=78, alpha=alpha, device=DEV).window(3, 7).cpu(), a)
+    if alpha > 0:       # skew: the hottest id of the big table takes far more than its uniform share
+        big = dev_s.window(0, 50)[0]
+        assert int(torch.bincount(big % 1000003).max()) > 50 * big.numel() / 1000003

@@ -302,7 +302,7 @@ def test_tape_registry_matches_the_ctypes_prototypes(built_lib):
         if res is not C.c_int or name.startswith("cdlrm_tape_"):
             continue
         args = tuple(0.0 if ty is C.c_float else None if ty is C.c_void_p else 0 for ty in argtypes)
-        if any(hasattr(ty, "contents") for ty in argtypes):     # struct pointers: not step calls
+        if any(hasattr(ty, "contents") or ty is C.c_double for ty in argtypes):     # struct pointers, doubles: not step calls
             continue
         try:
             _lib.NativeTape([(getattr(L, name), args, True)], {})
