@@ -350,7 +350,8 @@ def main():
         # HBM traffic of the gather kernel comes from separate rocprofv3 --pmc passes of this same command (PMC
         # counters cannot be read from inside the process); a committed summary applies only to its own workload
         traffic = traffic_src = None
-        for name in ("r02_gather_pmc_%s_a%s.json" % (a.config, ("%g" % a.alpha).replace(".", "p")), "r01_gather_pmc.json"):
+        tag = "%s_a%s.json" % (a.config, ("%g" % a.alpha).replace(".", "p"))
+        for name in ("r03_gather_pmc_" + tag, "r02_gather_pmc_" + tag):
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))
