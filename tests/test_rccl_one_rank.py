@@ -81,6 +81,7 @@ def _train(g, *, force, defer, chunk, long_batch, device_rng, agg_freq, agg_op):
     torch.cuda.synchronize()
     return dict(losses=torch.cat(losses).cpu(), tags=cg.tags.cpu().clone(), params=eng.param_flat.cpu().clone(),
                 weight=cg.weight.data.cpu().clone(), host=[E.weight.data.clone() for E in host.emb_l], merges=merges,
+                lanes=sorted({t["native"].lanes for t in eng._tapes.values() if t["native"] is not None}),
                 avg=bool(eng._reduce_avg()) if force else None)
 
 
@@ -96,9 +97,12 @@ def _child(port, name, case, ret):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
         g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        # as bench.py and Run: the trainer on a high-priority stream of its own -- launch tapes then replay in two lanes (the side
+        # queues' calls from the library's helper thread) around the collectives
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
         forced = _train(g, force=True, **case)
         plain = _train(g, force=False, **case)
-        out = dict(merges=forced["merges"], avg=forced["avg"], losses=forced["losses"].numpy())
+        out = dict(merges=forced["merges"], avg=forced["avg"], losses=forced["losses"].numpy(), lanes=forced["lanes"])
         for key in ("losses", "tags", "params", "weight"):
             out["same_" + key] = bool(torch.equal(forced[key], plain[key]))
         out["same_host"] = all(torch.equal(a, b) for a, b in zip(forced["host"], plain["host"]))
@@ -138,6 +142,7 @@ def test_multi_rank_path_over_one_rank_rccl_is_the_fast_path(golden, case, port)
     assert "error" not in out, out["error"]
     assert out["avg"] is True, "the ReduceOp.AVG branch is the one RCCL runs"
     assert out["merges"] >= 2
+    assert out["lanes"] == [2], "the steps replayed as two-lane native tapes"
     for key in ("losses", "tags", "params", "weight", "host"):
         assert out["same_" + key], "%s differs between the forced multi-rank path and the one-rank fast path" % key
     if not CASES[case]["device_rng"]:       # parity RNG: also the reference's own trajectory and tag state
