@@ -117,6 +117,7 @@ PROTOTYPES = {
     "cdlrm_tape_selftest": (C.c_int, []),
     "cdlrm_event_record": (C.c_int, [vp, vp]),
     "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
+    "cdlrm_event_attach_next": (C.c_int, [vp, vp]),
     "cdlrm_stream_create": (vp, [c_i32]),
     "cdlrm_stream_destroy": (C.c_int, [vp]),
     "cdlrm_event_create": (vp, [c_i32]),
@@ -282,7 +283,7 @@ class NativeTape:
         for (fn, args), name in zip(ops, names):
             if name == "cdlrm_stream_wait_event":
                 streams.append(int(val(args[0]))); events.append(int(val(args[1])))
-            elif name == "cdlrm_event_record":
+            elif name in ("cdlrm_event_record", "cdlrm_event_attach_next"):
                 streams.append(int(val(args[1]))); events.append(int(val(args[0])))
             elif name == "cdlrm_ctx_time_next_gather":      # no stream of its own: it arms the NEXT gather launch
                 streams.append(None); events.append(None)
@@ -302,6 +303,12 @@ class NativeTape:
             if e in last and lane[last[e]] != lane[k]:
                 dep[k] = last[e]
             last[e] = k
+            if names[k] == "cdlrm_event_attach_next":
+                # the event is recorded by the NEXT call of this lane (the launch that carries it), not by the attach itself:
+                # a wait of the other lane has to be held back until THAT call has been issued
+                if k + 1 >= len(ops) or lane[k + 1] != lane[k] or events[k + 1] is not None:
+                    raise TapeUnsupported("cdlrm_event_attach_next is not followed by the launch that carries its event")
+                last[e] = k + 1
         if 1 not in lane:
             return 1
         n = len(ops)

@@ -1,6 +1,7 @@
 // Internal helpers shared by the gfx950 kernels of libcdlrm_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -73,6 +74,34 @@ void cdlrm_set_error(const char* fmt, ...);
     } while (0)
 
 #define CDLRM_LAUNCH_CHECK() CDLRM_HIP_CHECK(hipGetLastError())
+
+// Completion events attached to a launch (cdlrm_event_attach_next).  An event RECORDED on the training queue is a marker
+// packet of its own and leaves a 6-8 us bubble there; handed to hipExtLaunchKernel as the stop event of
+// the kernel it is meant to follow, the same event completes with that kernel and costs the queue nothing.  The pending
+// event is per host thread (the thread that issues the launch); a launch site that can carry it takes it with
+// cdlrm_take_stop_event, an entry point that could not place it records it the ordinary way before it returns.
+extern thread_local hipEvent_t cdlrm_pending_stop_event;
+extern thread_local hipStream_t cdlrm_pending_stop_stream;
+static inline hipEvent_t cdlrm_take_stop_event(hipStream_t s) {
+    hipEvent_t e = cdlrm_pending_stop_event;
+    if (e && cdlrm_pending_stop_stream == s) {
+        cdlrm_pending_stop_event = nullptr;
+        return e;
+    }
+    return nullptr;
+}
+#define CDLRM_LAUNCH_EV(kernel, grid, block, lds, stream, ...)                                                     \
+    do {                                                                                                           \
+        hipEvent_t se__ = cdlrm_take_stop_event(stream);                                                           \
+        if (se__) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, se__, 0, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                    \
+    } while (0)
+// an entry point's last word: an event its launches could not carry is recorded behind them
+#define CDLRM_FLUSH_STOP_EVENT(stream)                                                                             \
+    do {                                                                                                           \
+        hipEvent_t se__ = cdlrm_take_stop_event((hipStream_t)(stream));                                            \
+        if (se__) CDLRM_HIP_CHECK(hipEventRecord(se__, (hipStream_t)(stream)));                                    \
+    } while (0)
 // hipGetLastError() is sticky per host thread: an error some OTHER caller of the runtime left behind (the host
 // framework probes pointers and events with calls that are allowed to fail) would be reported by our next launch
 // check.  Entry points that launch without a preceding checked call drop such a stale error first

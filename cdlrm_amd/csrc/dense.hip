@@ -216,6 +216,9 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
     CDLRM_REQUIRE(act >= 0 && act <= 2 && x_act >= 0 && x_act <= 2, "bad activation code");
     CDLRM_REQUIRE(((uintptr_t)work & 255) == 0, "work must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    // a completion event waiting for this call (cdlrm_event_attach_next) rides on the dgrad GEMM when that is the call's only
+    // launch (the training step's use); with several launches it is recorded behind the last one
+    hipEvent_t held = (act != 0 || dW || !dX) ? cdlrm_take_stop_event(s) : nullptr;
     const int splits = wgrad_splits(M, N, K);
     float* slabs = (float*)work;
     float* cs = (float*)((char*)work + ((((uint64_t)splits * N * K * 4) + 255) & ~(uint64_t)255));
@@ -256,6 +259,8 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
         }
     }
     CDLRM_LAUNCH_CHECK();
+    if (held) CDLRM_HIP_CHECK(hipEventRecord(held, s));
+    CDLRM_FLUSH_STOP_EVENT(s);          // (a GEMM path without the plumbing)
     return 0;
 }
 
@@ -913,10 +918,10 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         if (!rc) rc = interact_set_lds(k_interact_bwd_p<D4_, true>, ldsp, &A_##s);                             \
         if (rc) return rc;                                                                                     \
         if (staged)                                                                                            \
-            hipLaunchKernelGGL((k_interact_bwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
+            CDLRM_LAUNCH_EV((k_interact_bwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
                                feat, dR, ld_r, B, F, itself, x_act, dfeat);                             \
         else                                                                                                   \
-            hipLaunchKernelGGL((k_interact_bwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
+            CDLRM_LAUNCH_EV((k_interact_bwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
                                feat, dR, ld_r, B, F, itself, x_act, dfeat);                             \
     } while (0)
         if (D == 32) IBWD(8, b32);
@@ -924,6 +929,7 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         else IBWD(32, b128);
 #undef IBWD
         CDLRM_LAUNCH_CHECK();
+        CDLRM_FLUSH_STOP_EVENT(stream);
         return 0;
     }
     const size_t lds = (size_t)4 * (32 * (D + 1) + 32 + ((npairs + 3) & ~3)) * sizeof(float);
@@ -938,6 +944,7 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     hipLaunchKernelGGL(k_interact_bwd, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, feat, dR, ld_r, B, F, D,
                        itself, x_act, dfeat);
     CDLRM_LAUNCH_CHECK();
+    CDLRM_FLUSH_STOP_EVENT(stream);
     return 0;
 }
 

@@ -761,9 +761,9 @@ static void launch_gemm_staged(const GemmArgs& g, dim3 grid, int mode, hipStream
         staged_lds_attr(k_gemm_staged<A_KC, B_KC, 2>);
         attr = true;
     }
-    if (mode == 2) hipLaunchKernelGGL((k_gemm_staged<A_KC, B_KC, 2>), grid, dim3(256), ST_LDS_BYTES, s, g);
-    else if (mode == 1) hipLaunchKernelGGL((k_gemm_staged<A_KC, B_KC, 1>), grid, dim3(256), ST_LDS_BYTES, s, g);
-    else hipLaunchKernelGGL((k_gemm_staged<A_KC, B_KC, 0>), grid, dim3(256), ST_LDS_BYTES, s, g);
+    if (mode == 2) CDLRM_LAUNCH_EV((k_gemm_staged<A_KC, B_KC, 2>), grid, dim3(256), ST_LDS_BYTES, s, g);
+    else if (mode == 1) CDLRM_LAUNCH_EV((k_gemm_staged<A_KC, B_KC, 1>), grid, dim3(256), ST_LDS_BYTES, s, g);
+    else CDLRM_LAUNCH_EV((k_gemm_staged<A_KC, B_KC, 0>), grid, dim3(256), ST_LDS_BYTES, s, g);
 }
 
 template <bool A_KC, bool B_KC>

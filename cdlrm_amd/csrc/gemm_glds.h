@@ -367,10 +367,10 @@ template <bool A_KC, bool B_KC>
 static void launch_gemm2(const GemmArgs& g, int tm, int tn, int splits, hipStream_t s) {
     dim3 grid((unsigned)cdiv(g.N, 64 * tn), (unsigned)cdiv(g.M, 64 * tm), (unsigned)splits);
     const size_t dyn = (size_t)G2_EXTRA_LDS(tm, tn);
-    if (tm == 2 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 2>), grid, dim3(256), dyn, s, g);
-    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 2, 1>), grid, dim3(256), dyn, s, g);
-    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 2>), grid, dim3(256), dyn, s, g);
-    else hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, 1, 1>), grid, dim3(256), dyn, s, g);
+    if (tm == 2 && tn == 2) CDLRM_LAUNCH_EV((k_gemm2<A_KC, B_KC, 2, 2>), grid, dim3(256), dyn, s, g);
+    else if (tm == 2 && tn == 1) CDLRM_LAUNCH_EV((k_gemm2<A_KC, B_KC, 2, 1>), grid, dim3(256), dyn, s, g);
+    else if (tm == 1 && tn == 2) CDLRM_LAUNCH_EV((k_gemm2<A_KC, B_KC, 1, 2>), grid, dim3(256), dyn, s, g);
+    else CDLRM_LAUNCH_EV((k_gemm2<A_KC, B_KC, 1, 1>), grid, dim3(256), dyn, s, g);
 }
 
 template <bool A_KC, bool B_KC>

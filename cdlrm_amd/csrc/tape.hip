@@ -83,7 +83,7 @@ static const std::vector<TapeEntry>& tape_registry() {
         TAPE_FN(cdlrm_linear_bwd), TAPE_FN(cdlrm_mlp_wgrad), TAPE_FN(cdlrm_mlp_wgrad_sgd), TAPE_FN(cdlrm_bce_fwd_bwd),
         TAPE_FN(cdlrm_loss_fwd_bwd), TAPE_FN(cdlrm_head_fwd_bwd), TAPE_FN(cdlrm_head_finish), TAPE_FN(cdlrm_act_bwd),
         TAPE_FN(cdlrm_sgd_step), TAPE_FN(cdlrm_sgd_step2), TAPE_FN(cdlrm_scale_div), TAPE_FN(cdlrm_ctx_time_next_gather),
-        TAPE_FN(cdlrm_event_record), TAPE_FN(cdlrm_stream_wait_event), TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather),
+        TAPE_FN(cdlrm_event_record), TAPE_FN(cdlrm_stream_wait_event), TAPE_FN(cdlrm_event_attach_next), TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather),
         TAPE_FN(cdlrm_agg_scatter), TAPE_FN(cdlrm_tape_probe), TAPE_FN(cdlrm_tape_probe_log),
     };
     return reg;
@@ -275,6 +275,22 @@ extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
 extern "C" int cdlrm_event_record(void* event, void* stream) {
     CDLRM_REQUIRE(event, "null event");
     CDLRM_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return 0;
+}
+
+thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
+thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
+
+// `event` completes with the NEXT kernel this thread launches on `stream` through cdlrm_linear_bwd or cdlrm_interact_bwd
+// (attached to the launch as its stop event: no marker packet on the queue); where that call cannot attach it -- a kernel
+// path without the plumbing, more than one launch -- the call records it behind its launches instead.  Same ordering
+// guarantees as cdlrm_event_record issued right behind that call.
+extern "C" int cdlrm_event_attach_next(void* event, void* stream) {
+    CDLRM_REQUIRE(event, "null event");
+    if (cdlrm_pending_stop_event)       // (never the case in the training step: one attach per consuming call)
+        CDLRM_HIP_CHECK(hipEventRecord(cdlrm_pending_stop_event, cdlrm_pending_stop_stream));
+    cdlrm_pending_stop_event = (hipEvent_t)event;
+    cdlrm_pending_stop_stream = (hipStream_t)stream;
     return 0;
 }
 

@@ -493,6 +493,12 @@ class TrainEngine:
         ne = lambda: S.new_event(self.dev)
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
                             emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne())
+        if S.is_hip(self.dev):
+            # torch creates the HIP event at the first record: give every engine event its handle now (a launch tape stores
+            # handles; a wait recorded before the event's first real record would otherwise push that tape back to Python)
+            cur = S.current_stream(self.dev)
+            for e in list(self._events["probed"].values()) + [v for k, v in self._events.items() if k != "probed"]:
+                e.record(cur)
         self._head_scratch = ops.head_scratch(self.dev)
         # running print statistics [correct predictions, loss * mbs] summed over steps in float64 on the device
         # (main_no_ddp.py:427-433 keeps them on the host and synchronises twice per step for it): the head's finish launch adds
@@ -524,6 +530,9 @@ class TrainEngine:
         # ... in two lanes: the training queue's calls by this thread, the side queues' by the library's helper thread.  At a
         # per-rank batch of 1024 the thread that issues a step's ~45 runtime calls, not the GPU, sets the step time
         self.tape_lanes = 2
+        # cross-stream events of the step complete WITH the kernel they follow (attached to its launch) instead of being
+        # recorded behind it: no marker packet, no bubble on the training queue
+        self.attach_events = True
         self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
         self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
 
@@ -935,6 +944,7 @@ class TrainEngine:
         # for the bottom MLP's output, and the bias gradients are column sums taken inside the wgrad GEMMs.
         last_act = self.top[-1][1]
         split = buf["wgrad_split"]
+        attach = self.attach_events and S.is_hip(self.dev)
         nb_, wst = len(self.bot), self.wst
 
         n_top = len(self.top)
@@ -961,6 +971,11 @@ class TrainEngine:
             elif i < len(self.top) - 1:
                 act = 0                                      # applied by the dgrad epilogue of layer i+1
             dX = dR if i == 0 else buf["top_dy"][i - 1]
+            if i == 0 and attach and split is not None:
+                # `top_dz` (every top-layer dZ is final: the weight gradients may start) completes WITH the chain's last GEMM
+                # -- attached to its launch instead of recorded behind it: a record is a marker packet of its own and left
+                # a 6-8 us bubble on the training queue
+                ops.event_attach_next(ev["top_dz"], main)
             ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, None, None, act,
                            buf["lin_work"], x_act=(self.top[i - 1][1] if i > 0 else 0))
             dY = dX
@@ -984,17 +999,21 @@ class TrainEngine:
         #  split by rows -- the dense feature's row as its own launch, the rest on the side queue -- measured slower too, 0.718
         #  vs 0.663 ms.  Both schedules were removed in round 3.)
         if split is not None:
-            rec(ev["top_dz"].record, main)
+            if not (attach and n_top - (1 if fused_head else 0) > 0):
+                rec(ev["top_dz"].record, main)
             top_wgrad(ev["top_dz"])
         if self.cat:
             # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
             # derivative (the dot path applies it in the interaction backward's epilogue)
             ops.act_bwd(dfeat[:, 0, :], feat[:, 0, :], self.bot[-1][1])
         else:
+            if attach:
+                ops.event_attach_next(ev["interacted"], main)      # completes with the interaction backward's launch
             ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
-        rec(ev["interacted"].record, main)
+        if not attach or self.cat:
+            rec(ev["interacted"].record, main)
         rec(side.wait_event, ev["interacted"])
         if fused_head and not self.loss_sync:
             # the head's partial sums -> loss buffer + running statistics, off the training queue.  The next head kernel
@@ -1128,7 +1147,7 @@ class TrainEngine:
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
-               self._gslot is not None, self.loss_sync, self.tape_lanes,
+               self._gslot is not None, self.loss_sync, self.tape_lanes, self.attach_events,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)

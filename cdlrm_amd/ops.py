@@ -158,6 +158,14 @@ class TimingEvent:
                 pass
 
 
+def event_attach_next(event: "torch.cuda.Event", stream):
+    """`event` completes with the next linear_bwd / interact_bwd launched on `stream` (attached to the launch: no marker
+    packet on the queue).  The event must have been recorded once before (torch creates the HIP event lazily)."""
+    h = event.cuda_event
+    assert h, "record the event once before attaching it"
+    check(_lib.lib().cdlrm_event_attach_next(int(h), stream.cuda_stream))
+
+
 def time_next_gather(ctx: CacheCtx, start: TimingEvent, stop: TimingEvent):
     """The next embbag_fwd on this context leaves its own start / stop timestamps in the two events (attached to the
     launch: nothing is added to the queue)."""

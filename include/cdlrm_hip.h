@@ -450,6 +450,11 @@ int cdlrm_tape_selftest(void);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
 int cdlrm_event_record(void* event, void* stream);
 int cdlrm_stream_wait_event(void* stream, void* event);
+/* `event` completes with the next kernel the calling thread launches on `stream` through cdlrm_linear_bwd or
+ * cdlrm_interact_bwd -- attached to that launch as its stop event instead of recorded behind it: a record is a marker packet
+ * and a 6-8 us bubble on the training queue, an attached event is free.  If the call cannot attach it (several launches, a
+ * kernel path without the plumbing) it records the event behind its launches: same guarantees either way. */
+int cdlrm_event_attach_next(void* event, void* stream);
 /* a stream at an explicit priority (lower = more urgent, clamped into the device's range): the look-ahead plan's stream is
  * created at the least urgent level so that the training step goes first wherever the two compete for CUs */
 void* cdlrm_stream_create(int32_t priority);
