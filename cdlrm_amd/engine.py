@@ -533,6 +533,7 @@ class TrainEngine:
         # cross-stream events of the step complete WITH the kernel they follow (attached to its launch) instead of being
         # recorded behind it: no marker packet, no bubble on the training queue
         self.attach_events = True
+        self.fold_top_wait = True               # short batches: the wait for the deferred top-MLP update rides on the side stream
         self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
         self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
 
@@ -874,6 +875,13 @@ class TrainEngine:
         side_gather = self._side_gather(B)
         if side_gather:
             rec(side.wait_event, probed)
+            if self.fold_top_wait and self.defer_top and not self.cat and not top_waited:
+                # the previous step's deferred top-MLP update is waited for HERE, on the side stream in front of the gather:
+                # the one wait the training queue has in front of the interaction (`gathered`) then covers it too -- one
+                # barrier packet less on that queue.  (The update has landed long before the embedding update the gather
+                # follows in order.)
+                rec(side.wait_event, ev["top_updated"])
+                top_waited = True
             gather(side)
             rec(ev["gathered"].record, side)
         cur = X
@@ -1147,7 +1155,7 @@ class TrainEngine:
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
-               self._gslot is not None, self.loss_sync, self.tape_lanes, self.attach_events,
+               self._gslot is not None, self.loss_sync, self.tape_lanes, self.attach_events, self.fold_top_wait,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
