@@ -1,0 +1,23 @@
+"""Race check "the strong way" (tools/race_check.py): the same training steps from the same initial state under every SCHEDULE
+the engine can run -- two-lane / one-lane / Python-replayed / untaped launch sequences, events attached to launches or recorded
+behind them, the deferred-update wait on the side stream or on the training queue -- must end on the same BITS: final loss,
+every dense parameter, the cache rows' checksum, the tags, the running statistics.  Same kernels, same inputs, same stream
+dependencies; only who issues which call, and when, differs -- so any difference is a missing dependency.  Run at the per-rank
+batch of an 8-GPU run (short-batch schedule: gather on the side stream, two-phase aux regions) and at the c3 batch (long-batch
+schedule: chained take, window-resident probe), across a window boundary, on c3's shapes with the tables capped at 2 M rows."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("batch,steps", [(1024, 400), (8192, 120)])
+def test_every_schedule_ends_on_the_same_bits(batch, steps):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "race_check.py"), "--batch", str(batch), "--steps", str(steps)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("bit-identical") == 5 and "DIFFERS" not in r.stdout, r.stdout

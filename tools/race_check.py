@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Race check "the strong way": the same N training steps from the same initial state under different SCHEDULES (launch-tape
+lanes, attached events, ...) must end on the same bits -- losses, dense parameters, cache rows, tags.  Same kernels, same
+inputs; only who issues what, and when, differs.
+
+    python tools/race_check.py [--config c3] [--batch 1024] [--steps 1500] [--max-ind-range 2000000]
+"""
+import argparse
+import os
+import sys
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from cdlrm_amd.engine import WindowResolver  # noqa: E402
+
+VARIANTS = {
+    "default (two lanes, attached events, folded wait)": {},
+    "one lane": {"tape_lanes": 1},
+    "recorded events": {"attach_events": False},
+    "wait on the training queue": {"fold_top_wait": False},
+    "python tape": {"native_tape": False},
+    "no tape": {"use_tape": False},
+}
+
+
+def run(a, knobs, host):
+    dev = torch.device("cuda", 0)
+    L = a.steps // 2
+    wl = bench.build_workload(a.config, lookahead=L, batch=a.batch, dev=dev, max_ind_range=a.max_ind_range, host=host,
+                              cache_init="zeros", write_back=False)
+    eng, pipe, syn, B, cg = wl["eng"], wl["pipe"], wl["syn"], wl["B"], wl["cg"]
+    for k, v in knobs.items():
+        setattr(eng, k, v)
+    own = torch.cuda.Stream(device=dev, priority=-1)
+    own.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(own):
+        for w in range(2):                                  # two windows: one boundary inside the run
+            win = syn.window(w, L)
+            pipe.plan_window(win)
+            pipe.commit()
+            rs = WindowResolver(eng, win, B)
+            for j in range(L):
+                idx = win[:, j * B:(j + 1) * B]
+                nxt = win[:, (j + 1) * B:(j + 2) * B] if j + 1 < L else None
+                X, T = syn.dense(w * L + j)
+                eng.step(X, idx, T, j=j, next_idx=nxt, res=rs.batch(j), next_res=rs.batch(j + 1) if nxt is not None else None,
+                         loss_sync=False)
+                rs.ensure(j + rs.CH + 2)
+        eng.finish()
+    torch.cuda.synchronize()
+    cg.ctx.check()
+    out = (float(eng._buffers(B)["loss"][0]), eng.param_flat.clone(), cg.weight.data.sum(dtype=torch.float64).item(),
+           cg.tags.clone(), eng.stat_acc.clone())
+    del wl, eng, pipe, syn, cg
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--max-ind-range", type=int, default=2000000)
+    a = ap.parse_args()
+    torch.cuda.set_device(0)
+    host = bench.build_host_tables(a.config, seed=123, dev=torch.device("cuda", 0), max_ind_range=a.max_ind_range)
+    ref, bad = None, 0
+    for name, knobs in VARIANTS.items():
+        r = run(a, knobs, host)
+        if ref is None:
+            ref = r
+            print("%-52s loss %.10f" % (name, r[0]))
+            continue
+        same = (r[0] == ref[0] and torch.equal(r[1], ref[1]) and r[2] == ref[2] and torch.equal(r[3], ref[3])
+                and torch.equal(r[4], ref[4]))
+        bad += 0 if same else 1
+        print("%-52s loss %.10f  %s" % (name, r[0], "bit-identical" if same else "DIFFERS"))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
