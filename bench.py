@@ -204,6 +204,10 @@ def main():
     cfg, ln_emb, cg, eng, pipe, syn = wl["cfg"], wl["ln_emb"], wl["cg"], wl["eng"], wl["pipe"], wl["syn"]
     D, B, L = wl["D"], wl["B"], wl["L"]
     lbs = math.ceil(B / world)
+    if B % world:
+        # (the engine and Run handle a short last rank slice -- tests/test_distributed_gloo.py, world 3 --; the bench's synthetic
+        #  stream is cut into equal rank slices)
+        raise SystemExit("bench.py: the global batch %d does not divide by %d ranks" % (B, world))
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
     # the step's critical-path queue outranks the side queues (weight gradients, embedding backward, take): where they
