@@ -259,6 +259,10 @@ extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
         }
         return 0;
     }
+    // one two-lane replay at a time per process: the helper thread takes one job (two trainer threads in one process would
+    // otherwise overwrite each other's; uncontended in the one-process-per-GPU layout)
+    static std::mutex replay_mutex;
+    std::lock_guard<std::mutex> hold(replay_mutex);
     t->done[0].store(-1, std::memory_order_relaxed);
     t->done[1].store(-1, std::memory_order_relaxed);
     t->helper_finished.store(0, std::memory_order_relaxed);
