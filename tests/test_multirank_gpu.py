@@ -57,7 +57,7 @@ def _worker_body(rank, world, port, name, host_shared, ret, defer=False, chunk=0
         eng.agg_chunk_rows = chunk
     if long_batch:  # the long-batch schedule (gather alone on the main stream, chained take on the window-resident probe)
         eng.gather_alone_min = 1
-    lbs = B // world
+    lbs = -(-B // world)           # ceil (main_no_ddp.py:344): the last rank's slice is shorter when world does not divide B
     losses = []
     dev_idx = {}
     batches = _batches(g)
@@ -124,6 +124,55 @@ def test_two_ranks_one_gpu_match_reference(golden, name, port, defer, chunk, lon
             np.testing.assert_allclose(got[r]["top_w"][i], g[f"r{r}_top_w{i}"], rtol=1e-4, atol=1e-6)
     for k in range(len(g["ln_emb"])):
         np.testing.assert_allclose(float(host[k].double().sum()), float(g[f"host_sum_{k}"]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,port,long_batch", [("train_w2_mean", 29841, True), ("train_w2_freq1", 29842, False)])
+def test_three_ranks_one_gpu_short_last_slice_vs_oracle(golden, name, port, long_batch):
+    """Three trainer processes with the real kernels on a batch of 32: lbs = ceil(32 / 3) = 11, the last rank trains on 10
+    samples (the reference raises there, main_no_ddp.py:388-391 -- oracle and engine define the natural extension).  With the
+    long-batch schedule the window-resident probe numbers the misses per GLOBAL batch and rank slice
+    (cdlrm_window_resolve(batch_len, seg_len)): a numbering that ran across batch boundaries would hand two misses of one
+    rank-batch the same aux row.  Against the oracle's 3-rank emulation: per-rank losses, shared tags, replicated weights."""
+    from oracle import cdlrm_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import make_batches as oracle_batches
+    world = 3
+    g = golden(name)
+    ln_emb = [int(x) for x in g["ln_emb"]]
+    L, m_spa = int(g["L"]), int(g["m_spa"])
+    ln_top = np.array([m_spa + (len(ln_emb) + 1) * len(ln_emb) // 2] + list(g["top"]))
+    tr = O.OracleTrainer(ln_emb, m_spa, g["ln_bot"], ln_top, cache_size=int(g["cache_size"]), num_ways=int(g["ways"]),
+                         mini_batch_size=int(g["B"]), world_size=world, lr=float(g["lr"]), lr_embeds=float(g["lr_emb"]),
+                         lookahead=L, table_agg_freq=int(g["agg_freq"]), table_agg_op=str(g["agg_op"]), seed=int(g["seed"]))
+    ob = oracle_batches(g)
+    for j, (X, lS_o, lS_i, Tt) in enumerate(ob):
+        if j % L == 0:
+            torch.manual_seed(5000 + j)
+            tr.refill(torch.cat([b[2] for b in ob[j:j + L]], dim=1))
+        tr.step(j, X, lS_o, lS_i, Tt)
+    np.random.seed(int(g["seed"]))
+    host = [h.share_memory_() for h in O.init_host_tables(ln_emb, m_spa)]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, host, ret, True, 0, long_batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, payload = ret.get(timeout=300)
+        assert "error" not in payload, payload["error"]
+        got[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], np.array([l[r] for l in tr.losses]), rtol=1e-5)
+        for k in range(len(ln_emb)):
+            assert np.array_equal(got[r]["occ"][k], tr.occ[k].numpy()), (r, k)
+        for i in range(len(got[r]["top_w"])):
+            np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=1e-4, atol=1e-6)
+            assert np.array_equal(got[r]["top_w"][i], got[0]["top_w"][i])
+    for k in range(len(ln_emb)):
+        np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=1e-6)
 
 
 def _shard_worker(rank, world, port, host_shared, ret):
