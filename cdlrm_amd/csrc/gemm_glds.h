@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
 //     132 with the DMA ablated altogether, 129 with the barrier ablated too, ideal 128): what costs them ~8 % is the
 //     tile traffic into the CU's LDS itself, not the issue slots;
 //   * starting half of the workgroups 2.5-8 k cycles late so that the store tails of the co-resident pairs do not
-//     coincide: 40.6 against 42.0 us on the forward layout, nothing on the weight-gradient layout;
+//     coincide: 40.6 against 42.0 us on the forward layout, nothing on the weight-gradient layout -- and in the step
+//     (round 3, tools/ab_step.py) 0.641 / 0.652 / 0.677 ms at 3 / 6 / 12 k cycles against 0.630: the delay is paid by every
+//     GEMM of the chain, the tails it separates were hidden under the side queues' kernels anyway;
 //   * 128x128 tiles (one workgroup per CU): 42.3-43.4 us, no better than 128x64 with two;
 //   * (round 3) the output tile taken through LDS behind the loop and stored row-major -- a wave instruction = 4 whole rows of
 //     256 bytes instead of 32 rows x 32 bytes, the dgrad's mask read the same way: bit-identical, and no faster in the step
