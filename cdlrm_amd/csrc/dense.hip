@@ -358,10 +358,7 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
         };
         for (size_t q = 0; q < direct.size(); ++q) slabbed(direct[q], direct_layer[q]);
         for (size_t q = 0; q < tiled.size(); ++q) slabbed(tiled[q], tiled_layer[q]);
-        if (!direct.empty()) {
-            int rc = launch_wgrad_group(direct.data(), (int)direct.size(), s);
-            if (rc) return rc;
-        }
+        bool direct_done = direct.empty();
         for (size_t q0 = 0; q0 < tiled.size(); q0 += GEMM_GROUP_MAX) {
             GemmGroup grp;
             memset(&grp, 0, sizeof(grp));
@@ -373,7 +370,17 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
                 grp.n++;
             }
             grp.first[grp.n] = blocks;
+            // the LDS-free layers ride in front of the first tiled group's launch where the combination allows (one launch less
+            // per sub-network on a launch-bound step: 0.2008 -> 0.1963 ms at a local batch of 1024, 0.2955 -> 0.2883 at 2048)
+            if (!direct_done && launch_wgrad_mixed(direct.data(), (int)direct.size(), grp, blocks, s)) {
+                direct_done = true;
+                continue;
+            }
             hipLaunchKernelGGL((k_gemm_group<false, false, true, true>), dim3(blocks), dim3(256), 0, s, grp);
+        }
+        if (!direct_done) {
+            int rc = launch_wgrad_group(direct.data(), (int)direct.size(), s);
+            if (rc) return rc;
         }
         for (size_t q0 = 0; q0 < jobs.size(); q0 += GEMM_GROUP_MAX) {
             ReduceGroup red;

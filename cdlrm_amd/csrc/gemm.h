@@ -797,6 +797,73 @@ static void launch_gemm_direct(GemmArgs g, int splits, hipStream_t s) {
 #undef CDLRM_DIRECT
 }
 
+// The two grouped weight-gradient launches of a short-batch step as ONE: the layers the LDS-free kernel takes (a 13-wide
+// input, a 1-wide output: a launch of ~8 us for next to no work, all of it launch floor) ride as extra workgroups in front of
+// the LDS-tiled layers' group.  One kernel, two bodies, picked by workgroup index; the LDS of the two is one raw buffer.
+template <int MODE, bool AL>
+__global__ void __launch_bounds__(256) k_wgrad_mixed(GemmGroup dgrp, GemmGroup tgrp, unsigned n_direct) {
+    constexpr int RED_FLOATS = 4 * 32 * 33 + 4 * 32, TILE_FLOATS = 2 * 64 * LDS_KC;
+    __shared__ __attribute__((aligned(16))) float lds[RED_FLOATS > TILE_FLOATS ? RED_FLOATS : TILE_FLOATS];
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    if (wgid < n_direct) {
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+            if (q < dgrp.n && wgid >= dgrp.first[q]) p = q;
+        const GemmArgs& g = dgrp.g[p];
+        const unsigned local = wgid - dgrp.first[p];
+        const unsigned gx = (unsigned)((g.N + 31) / 32), gy = (unsigned)((g.M + 31) / 32);
+        float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(lds);
+        float (*csr)[32] = reinterpret_cast<float (*)[32]>(lds + 4 * 32 * 33);
+        direct_body<false, false, false, false, MODE, AL>(g, local % gx, (local / gx) % gy, local / (gx * gy), red, csr);
+    } else {
+        const unsigned w = wgid - n_direct;
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+            if (q < tgrp.n && w >= tgrp.first[q]) p = q;
+        const GemmArgs& g = tgrp.g[p];
+        const unsigned local = w - tgrp.first[p];
+        const unsigned gx = (unsigned)((g.N + 63) / 64), gy = (unsigned)((g.M + 63) / 64);
+        gemm_tile_body<false, false, 1, 1, true, true>(g, local % gx, (local / gx) % gy, local / (gx * gy), lds, lds + 64 * LDS_KC);
+    }
+}
+
+// returns 1 when it launched, 0 when the combination is not one it takes (the caller then launches the groups separately)
+static inline int launch_wgrad_mixed(const GemmArgs* direct, int nd, const GemmGroup& tgrp, unsigned tblocks, hipStream_t s) {
+    if (nd < 1 || nd > GEMM_GROUP_MAX || tgrp.n < 1) return 0;
+    GemmGroup dgrp;
+    memset(&dgrp, 0, sizeof(dgrp));
+    unsigned blocks = 0;
+    int mode = -1;
+    bool al = false;
+    for (int i = 0; i < nd; ++i) {
+        const int64_t kc = direct[i].kchunk > 0 && direct[i].kchunk < direct[i].K ? direct[i].kchunk : direct[i].K;
+        GemmArgs pg = direct[i];
+        pg.kchunk = kc;
+        const bool a = direct_aligned<false, false>(pg, kc);
+        if (direct_staged<false, false>(pg, kc)) return 0;
+        const int m = direct_mode(kc, a);
+        if (i > 0 && (m != mode || a != al)) return 0;         // one variant of the LDS-free body per launch
+        mode = m; al = a;
+        dgrp.first[i] = blocks;
+        dgrp.g[i] = pg;
+        dgrp.g[i].vecC = aligned16(pg.C) && pg.ldc % 4 == 0 && pg.slab % 4 == 0;
+        blocks += (unsigned)(cdiv(pg.M, 32) * cdiv(pg.N, 32) * cdiv(pg.K, kc));
+    }
+    dgrp.n = nd;
+    dgrp.first[nd] = blocks;
+    const dim3 grid(blocks + tblocks);
+#define CDLRM_WMIX(MODE_, AL_) hipLaunchKernelGGL((k_wgrad_mixed<MODE_, AL_>), grid, dim3(256), 0, s, dgrp, tgrp, blocks)
+    if (al) {
+        if (mode == 2) CDLRM_WMIX(2, true); else if (mode == 1) CDLRM_WMIX(1, true); else CDLRM_WMIX(0, true);
+    } else {
+        if (mode == 2) CDLRM_WMIX(2, false); else if (mode == 1) CDLRM_WMIX(1, false); else CDLRM_WMIX(0, false);
+    }
+#undef CDLRM_WMIX
+    return 1;
+}
+
 // up to GEMM_GROUP_MAX un-split problems of the weight-gradient layout (both operands contraction-strided) per launch
 static inline int launch_wgrad_group(const GemmArgs* probs, int n, hipStream_t s) {
     static bool st_attr = false;
