@@ -227,10 +227,11 @@ class NativeTape:
     Library calls are stored by address with their arguments split by register class (ctypes argtypes tell which);
     torch stream / event calls become cdlrm_stream_wait_event / cdlrm_event_record on the raw HIP handles."""
 
-    def __init__(self, prog, cells: dict, main_stream: Optional[int] = None):
+    def __init__(self, prog, cells: dict, main_stream: Optional[int] = None, max_lanes: int = 2):
         """main_stream: raw handle of the training queue's stream.  Given (and not the null stream), the tape is replayed in
-        two lanes: ops on that stream by the replaying thread, every other stream's by the library's helper thread, ordered
-        against each other on the host the way their events order them on the GPU (cdlrm_tape_set_lanes)."""
+        up to `max_lanes` (<= 4) lanes: ops on that stream by the replaying thread, every other stream's by helper threads of
+        the library (one lane per stream in order of appearance, the last lane takes the rest), ordered against each other on
+        the host the way their events order them on the GPU (cdlrm_tape_set_lanes)."""
         import torch
         L = raw()
         order = list(cells.values())
@@ -248,8 +249,8 @@ class NativeTape:
                     self._add(L, target, cargs, index)
                     ops.append((target, cargs))
             self.lanes = 1
-            if main_stream:
-                self.lanes = self._set_lanes(L, ops, int(main_stream))
+            if main_stream and max_lanes > 1:
+                self.lanes = self._set_lanes(L, ops, int(main_stream), min(int(max_lanes), 4))
         except Exception:
             L.cdlrm_tape_destroy(h)
             self._h = None
@@ -275,7 +276,7 @@ class NativeTape:
                     (L.cdlrm_stream_wait_event, (obj.cuda_stream, ev.cuda_event))]
         raise TapeUnsupported(repr(fn))
 
-    def _set_lanes(self, L, ops, main_stream: int) -> int:
+    def _set_lanes(self, L, ops, main_stream: int, max_lanes: int) -> int:
         """Split the recorded ops by stream and order the lanes on every event both of them touch."""
         names = [getattr(fn, "__name__", "") for fn, _ in ops]
         val = lambda a: (a.value or 0) if isinstance(a, C._SimpleCData) else (0 if a is None else a)
@@ -289,11 +290,15 @@ class NativeTape:
                 streams.append(None); events.append(None)
             else:
                 streams.append(int(val(args[-1]))); events.append(None)     # kernel entry points: the stream is the last argument
+        lane_of = {main_stream: 0}
+        for st in streams:                      # lanes in order of appearance; the last lane takes every further stream
+            if st is not None and st not in lane_of:
+                lane_of[st] = min(len(lane_of), max_lanes - 1)
         lane = [0] * len(ops)
         nxt = 0
         for k in reversed(range(len(ops))):
             if streams[k] is not None:
-                nxt = 0 if streams[k] == main_stream else 1
+                nxt = lane_of[streams[k]]
             lane[k] = nxt
         dep, last = [-1] * len(ops), {}
         for k in range(len(ops)):
@@ -309,11 +314,11 @@ class NativeTape:
                 if k + 1 >= len(ops) or lane[k + 1] != lane[k] or events[k + 1] is not None:
                     raise TapeUnsupported("cdlrm_event_attach_next is not followed by the launch that carries its event")
                 last[e] = k + 1
-        if 1 not in lane:
+        if max(lane) == 0:
             return 1
         n = len(ops)
         check(L.cdlrm_tape_set_lanes(self._h, (C.c_int32 * n)(*lane), (C.c_int32 * n)(*dep), n))
-        return 2
+        return max(lane) + 1
 
     @staticmethod
     def _event(ev) -> int:

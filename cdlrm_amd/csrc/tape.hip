@@ -31,6 +31,7 @@
 
 #define TAPE_MAX_INT 24
 #define TAPE_MAX_FLT 8
+#define TAPE_MAX_LANES 4
 
 typedef int (*tape_invoke_fn)(void* fn, const int64_t* ia, const float* fa);
 
@@ -97,20 +98,20 @@ struct TapeOp {
     int64_t iargs[TAPE_MAX_INT];
     int32_t cell[TAPE_MAX_INT];     // -1: literal, else index of the cell whose value is the argument
     float fargs[TAPE_MAX_FLT];
-    int32_t lane = 0;       // 0: issued by the replaying thread, 1: by the helper thread (cdlrm_tape_set_lanes)
-    int32_t dep = -1;       // tape index of an op of the OTHER lane that has to be issued before this one (-1: none)
+    int32_t lane = 0;       // 0: issued by the replaying thread, 1 .. 3: by that helper thread (cdlrm_tape_set_lanes)
+    int32_t dep = -1;       // tape index of an op of ANOTHER lane that has to be issued before this one (-1: none)
 };
 
 struct cdlrm_tape {
     std::vector<TapeOp> ops;
     std::vector<int64_t> cells;
-    // two-lane replay
-    bool two_lanes = false;
+    // multi-lane replay
+    int lanes = 1;                      // lanes in use (1: single-threaded replay)
     int device = 0;
-    std::atomic<int> done[2];           // highest tape index each lane has issued (INT_MAX: the lane is through)
-    std::atomic<int> helper_finished{0};
-    int rc1 = 0;
-    char err1[256];
+    std::atomic<int> done[TAPE_MAX_LANES];           // highest tape index each lane has issued (INT_MAX: the lane is through)
+    std::atomic<int> finished[TAPE_MAX_LANES];       // helper lanes: this replay's ops are all issued
+    int rc[TAPE_MAX_LANES];
+    char err[TAPE_MAX_LANES][256];
 };
 
 static inline int tape_call(const TapeOp& o, const int64_t* a) { return o.invoke(o.fn, a, o.fargs); }
@@ -156,15 +157,16 @@ extern "C" int64_t* cdlrm_tape_cells(cdlrm_tape* t) { return t ? t->cells.data()
 
 extern "C" int64_t cdlrm_tape_length(cdlrm_tape* t) { return t ? (int64_t)t->ops.size() : -1; }
 
-// ---- two-lane replay ---------------------------------------------------------------------------------------------------
-// At a per-rank batch of 1024 a step is ~45 runtime calls of ~3-4 us of HOST time each: the thread that issues them, not
+// ---- multi-lane replay -------------------------------------------------------------------------------------------------
+// At a per-rank batch of 1024 a step is ~45 runtime calls of ~4.5 us of HOST time each: the thread that issues them, not
 // the GPU, sets the step time (0.20 ms of issue against ~0.17 ms of dependent GPU work).  A tape can therefore be split by
-// stream: lane 0 -- everything on the training queue -- is issued by the replaying thread, lane 1 -- the side queues: embedding
-// backward, the next batch's take / sort, the deferred weight gradients -- by one helper thread of the process, at the
-// same time.  What orders the two lanes on the HOST is exactly what orders the streams on the GPU, the events: a
-// hipStreamWaitEvent must be issued behind the hipEventRecord it is meant to see and in front of the next record of the
-// same event, so every op that touches an event carries `dep`, the latest earlier op of the other lane on that event, and
-// is held back until that one has been issued.  Dependencies point backwards in tape order: no cycles, no lost wake-ups.
+// stream: lane 0 -- everything on the training queue -- is issued by the replaying thread, lanes 1 .. 3 -- the side queues:
+// embedding backward, the next batch's take / sort, the deferred weight gradients -- by helper threads of the process, one
+// per lane, at the same time.  What orders the lanes on the HOST is exactly what orders the streams on the GPU, the events:
+// a hipStreamWaitEvent must be issued behind the hipEventRecord it is meant to see and in front of the next record of the
+// same event, so every op that touches an event carries `dep`, the latest earlier op of ANOTHER lane on that event, and is
+// held back until that one has been issued (program order inside a lane does the rest: the touches of one event are totally
+// ordered).  Dependencies point backwards in tape order: no cycles, no lost wake-ups.
 static inline void tape_pause() { __builtin_ia32_pause(); }
 
 static int tape_run_lane(cdlrm_tape* t, int lane) {
@@ -174,20 +176,24 @@ static int tape_run_lane(cdlrm_tape* t, int lane) {
     for (int k = 0; k < n; ++k) {
         const TapeOp& o = t->ops[k];
         if (o.lane != lane) continue;
-        if (o.dep >= 0)
-            while (t->done[1 - lane].load(std::memory_order_acquire) < o.dep) tape_pause();
+        if (o.dep >= 0) {
+            const std::atomic<int>& other = t->done[t->ops[o.dep].lane];
+            while (other.load(std::memory_order_acquire) < o.dep) tape_pause();
+        }
         int64_t a[TAPE_MAX_INT];
         for (int i = 0; i < TAPE_MAX_INT; ++i) a[i] = o.cell[i] >= 0 ? cells[o.cell[i]] : o.iargs[i];
         rc = tape_call(o, a);
         if (rc) break;
         t->done[lane].store(k, std::memory_order_release);
     }
-    t->done[lane].store(INT_MAX, std::memory_order_release);       // (also on failure: the other lane must not wait for ever)
+    t->done[lane].store(INT_MAX, std::memory_order_release);       // (also on failure: the other lanes must not wait for ever)
     return rc;
 }
 
-// the process's helper thread: spins for work while steps are being replayed, sleeps when none has come for a while
+// a helper thread of the process (one per lane > 0): spins for work while steps are being replayed, sleeps when none has come
+// for a while
 struct TapeHelper {
+    int lane = 1;
     std::atomic<cdlrm_tape*> job{nullptr};
     std::atomic<int> sleeping{0};
     std::mutex m;
@@ -199,57 +205,64 @@ struct TapeHelper {
             cdlrm_tape* t = job.exchange(nullptr, std::memory_order_acquire);
             if (!t) {
                 if (++idle < (1 << 16)) { tape_pause(); continue; }
+                // going to sleep: announce it, THEN look for a job once more (sequentially consistent on both sides: the
+                // submitter publishes the job, THEN looks at `sleeping` -- one of the two always sees the other; the bounded
+                // wait is a second line of defence, not the mechanism)
                 std::unique_lock<std::mutex> lk(m);
-                sleeping.store(1);
-                if (!job.load()) cv.wait_for(lk, std::chrono::milliseconds(200));
-                sleeping.store(0);
+                sleeping.store(1, std::memory_order_seq_cst);
+                if (!job.load(std::memory_order_seq_cst)) cv.wait_for(lk, std::chrono::milliseconds(5));
+                sleeping.store(0, std::memory_order_seq_cst);
                 idle = 0;
                 continue;
             }
             idle = 0;
             if (t->device >= 0 && t->device != device) { (void)hipSetDevice(t->device); device = t->device; }
             if (t->device >= 0) (void)hipGetLastError();
-            t->rc1 = tape_run_lane(t, 1);
-            if (t->rc1) snprintf(t->err1, sizeof(t->err1), "%s", cdlrm_last_error());
-            t->helper_finished.store(1, std::memory_order_release);
+            t->rc[lane] = tape_run_lane(t, lane);
+            if (t->rc[lane]) snprintf(t->err[lane], sizeof(t->err[lane]), "%s", cdlrm_last_error());
+            t->finished[lane].store(1, std::memory_order_release);
         }
     }
     void submit(cdlrm_tape* t) {
-        job.store(t, std::memory_order_release);
-        if (sleeping.load()) { std::lock_guard<std::mutex> lk(m); cv.notify_one(); }
+        job.store(t, std::memory_order_seq_cst);
+        if (sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(m); cv.notify_one(); }
     }
 };
 
-static TapeHelper* tape_helper() {
-    static TapeHelper* h = [] {         // never destroyed: the thread outlives every static destructor
+static TapeHelper* tape_helper(int lane) {
+    static TapeHelper* h[TAPE_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    if (!h[lane]) {                     // never destroyed: the thread outlives every static destructor
         TapeHelper* p = new TapeHelper();
+        p->lane = lane;
         std::thread([p] { p->loop(); }).detach();
-        return p;
-    }();
-    return h;
+        h[lane] = p;
+    }
+    return h[lane];
 }
 
-// lane / dep per op (arrays of cdlrm_tape_length entries).  Checked here: lanes are 0 / 1, a dependency points at an EARLIER
-// op of the OTHER lane.  A tape without lane-1 ops stays single-threaded.
+// lane / dep per op (arrays of cdlrm_tape_length entries).  Checked here: lanes are 0 .. 3, a dependency points at an EARLIER
+// op of ANOTHER lane.  A tape whose ops are all in lane 0 stays single-threaded.
 extern "C" int cdlrm_tape_set_lanes(cdlrm_tape* t, const int32_t* lane, const int32_t* dep, int64_t n) {
     CDLRM_REQUIRE(t && lane && dep && n == (int64_t)t->ops.size(), "one lane / dep entry per recorded op");
-    bool any1 = false;
+    int top = 0;
     for (int64_t k = 0; k < n; ++k) {
-        CDLRM_REQUIRE(lane[k] == 0 || lane[k] == 1, "lane: 0 or 1");
-        CDLRM_REQUIRE(dep[k] >= -1 && dep[k] < k && (dep[k] < 0 || lane[dep[k]] != lane[k]), "dep: an earlier op of the other lane");
-        any1 = any1 || lane[k] == 1;
+        CDLRM_REQUIRE(lane[k] >= 0 && lane[k] < TAPE_MAX_LANES, "lane: 0 .. 3");
+        CDLRM_REQUIRE(dep[k] >= -1 && dep[k] < k && (dep[k] < 0 || lane[dep[k]] != lane[k]), "dep: an earlier op of another lane");
+        top = lane[k] > top ? lane[k] : top;
     }
     for (int64_t k = 0; k < n; ++k) { t->ops[k].lane = lane[k]; t->ops[k].dep = dep[k]; }
-    t->two_lanes = any1;
+    t->lanes = top + 1;
     if (hipGetDevice(&t->device) != hipSuccess) { t->device = -1; (void)hipGetLastError(); }     // (a box without a GPU: tests)
     return 0;
 }
 
-// Re-issues the recorded calls -- in order, or in two lanes (cdlrm_tape_set_lanes); stops a lane at its first call that fails
-// and returns that code (cdlrm_last_error() describes it).
+// Re-issues the recorded calls -- in order, or in lanes (cdlrm_tape_set_lanes); stops a lane at its first call that fails and
+// returns that code (cdlrm_last_error() describes it).
 extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
     CDLRM_REQUIRE(t, "null tape");
-    if (!t->two_lanes) {
+    if (t->lanes <= 1) {
         const int64_t* cells = t->cells.data();
         for (const TapeOp& o : t->ops) {
             int64_t a[TAPE_MAX_INT];
@@ -259,19 +272,22 @@ extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
         }
         return 0;
     }
-    // one two-lane replay at a time per process: the helper thread takes one job (two trainer threads in one process would
+    // one multi-lane replay at a time per process: a helper thread takes one job (two trainer threads in one process would
     // otherwise overwrite each other's; uncontended in the one-process-per-GPU layout)
     static std::mutex replay_mutex;
     std::lock_guard<std::mutex> hold(replay_mutex);
-    t->done[0].store(-1, std::memory_order_relaxed);
-    t->done[1].store(-1, std::memory_order_relaxed);
-    t->helper_finished.store(0, std::memory_order_relaxed);
-    t->rc1 = 0;
-    tape_helper()->submit(t);
+    for (int l = 0; l < t->lanes; ++l) {
+        t->done[l].store(-1, std::memory_order_relaxed);
+        t->finished[l].store(0, std::memory_order_relaxed);
+        t->rc[l] = 0;
+    }
+    for (int l = 1; l < t->lanes; ++l) tape_helper(l)->submit(t);
     const int rc0 = tape_run_lane(t, 0);
-    while (!t->helper_finished.load(std::memory_order_acquire)) tape_pause();
+    for (int l = 1; l < t->lanes; ++l)
+        while (!t->finished[l].load(std::memory_order_acquire)) tape_pause();
     if (rc0) return rc0;
-    if (t->rc1) { cdlrm_set_error("%s", t->err1); return t->rc1; }
+    for (int l = 1; l < t->lanes; ++l)
+        if (t->rc[l]) { cdlrm_set_error("%s", t->err[l]); return t->rc[l]; }
     return 0;
 }
 

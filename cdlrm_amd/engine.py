@@ -527,9 +527,9 @@ class TrainEngine:
         # schedule knobs (attributes, not environment switches: tests/test_engine_parity.py runs each of them both ways)
         self.use_tape = S.is_hip(self.dev)      # replay recorded launch sequences (_step_taped)
         self.native_tape = True                 # ... from the C side (csrc/tape.hip) instead of from Python
-        # ... in two lanes: the training queue's calls by this thread, the side queues' by the library's helper thread.  At a
+        # ... in lanes: the training queue's calls by this thread, each side queue's by a helper thread of the library.  At a
         # per-rank batch of 1024 the thread that issues a step's ~45 runtime calls, not the GPU, sets the step time
-        self.tape_lanes = 2
+        self.tape_lanes = 3
         # cross-stream events of the step complete WITH the kernel they follow (attached to its launch) instead of being
         # recorded behind it: no marker packet, no bubble on the training queue
         self.attach_events = True
@@ -1196,7 +1196,8 @@ class TrainEngine:
                 # the same calls as a C-side tape: one library call per step instead of ~45 interpreted ones (0.22 ms of
                 # host time per step, more than the GPU needs at a per-rank batch of 1024)
                 try:
-                    native = _lib.NativeTape(prog, cells, main_stream=main.cuda_stream if self.tape_lanes == 2 else None)
+                    native = _lib.NativeTape(prog, cells, main_stream=main.cuda_stream if self.tape_lanes > 1 else None,
+                                             max_lanes=self.tape_lanes)
                 except _lib.TapeUnsupported as e:
                     native = None
                     self.tape_fallbacks.append(str(e))      # this control path replays from Python (bench.py reports it)

@@ -441,10 +441,11 @@ int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int64_t* iargs,
 int64_t* cdlrm_tape_cells(cdlrm_tape* t);
 int64_t cdlrm_tape_length(cdlrm_tape* t);
 int cdlrm_tape_replay(cdlrm_tape* t);      /* first non-zero return code of a replayed call, else 0 */
-/* Two-lane replay: at short per-rank batches the HOST thread that issues a step's ~45 runtime calls, not the GPU, sets the
- * step time.  lane[k] = 1 hands op k to one helper thread of the process (the side queues' work), lane[k] = 0 stays with the
- * thread that calls cdlrm_tape_replay (the training queue's); dep[k] >= 0 = the tape index of an earlier op of the OTHER lane
- * that has to be issued first -- the host-side order of the record / wait calls on one event.  n = cdlrm_tape_length. */
+/* Multi-lane replay: at short per-rank batches the HOST thread that issues a step's ~45 runtime calls, not the GPU, sets the
+ * step time.  lane[k] = 1 .. 3 hands op k to that helper thread of the process (one per side queue), lane[k] = 0 stays with
+ * the thread that calls cdlrm_tape_replay (the training queue's calls); dep[k] >= 0 = the tape index of an earlier op of
+ * ANOTHER lane that has to be issued first -- the host-side order of the record / wait calls on one event.
+ * n = cdlrm_tape_length. */
 int cdlrm_tape_set_lanes(cdlrm_tape* t, const int32_t* lane, const int32_t* dep, int64_t n);
 int cdlrm_tape_selftest(void);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */

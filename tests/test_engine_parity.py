@@ -228,7 +228,10 @@ def _native_tape_run(g, batches, L, native, long_batch, want_lanes):
         assert (n_native > 0) == bool(native) and len(eng._tapes) > 0 and not eng.tape_fallbacks
         if native:
             assert all(int(_lib.raw().cdlrm_tape_length(t["native"]._h)) >= len(t["prog"]) for t in eng._tapes.values())
-            assert all(t["native"].lanes == want_lanes for t in eng._tapes.values())
+            assert all((t["native"].lanes == 1) if want_lanes == 1 else (2 <= t["native"].lanes <= eng.tape_lanes)
+                       for t in eng._tapes.values())
+            if want_lanes > 1:      # main + side (+ the prefetch / weight-gradient queue of the short-batch schedule)
+                assert max(t["native"].lanes for t in eng._tapes.values()) == (2 if long_batch else 3)
         return (torch.cat(losses).cpu(), cg.tags.cpu().clone(), cg.weight.data.cpu().clone(),
                 [l.weight.data.cpu().clone() for l in dl.top_l if hasattr(l, "weight")])
 

@@ -313,8 +313,8 @@ def test_tape_registry_matches_the_ctypes_prototypes(built_lib):
 
 
 def test_two_lane_tape_replay_orders_the_lanes(built_lib):
-    """csrc/tape.hip, two-lane replay: lane-0 ops are issued by the replaying thread, lane-1 ops by the library's helper
-    thread at the same time; an op with a dependency is held back until the named op of the other lane has been issued (the
+    """csrc/tape.hip, multi-lane replay: lane-0 ops are issued by the replaying thread, the ops of lanes 1 .. 3 by the library's
+    helper threads at the same time; an op with a dependency is held back until the named op of the other lane has been issued (the
     host-side order of record / wait calls on one event), and each lane keeps its own tape order.  A logging probe stands in
     for the runtime calls: no GPU involved."""
     import ctypes as C
@@ -345,6 +345,13 @@ def test_two_lane_tape_replay_orders_the_lanes(built_lib):
         got = list(buf[:n])
         for ln in (0, 1):
             assert [k for k in got if lane2[k] == ln] == [k for k in range(n) if lane2[k] == ln]
+    # (a') the same chain over THREE lanes (two helper threads): still the global order 0, 1, 2, ...
+    tape3 = _lib.NativeTape([(log, (k, 1500 * (k % 4)), True) for k in range(n)], {})
+    _lib.check(L.cdlrm_tape_set_lanes(tape3._h, (C.c_int32 * n)(*[k % 3 for k in range(n)]), dep, n))
+    for _ in range(50):
+        assert tape3.replay() == 0
+        assert take(buf, 4096) == n and list(buf[:n]) == list(range(n))
+    assert L.cdlrm_tape_set_lanes(tape3._h, (C.c_int32 * n)(*([4] + [0] * (n - 1))), (C.c_int32 * n)(*([-1] * n)), n) != 0   # lanes 0 .. 3
     # (c) a dependency on a LATER op or on the same lane is refused
     bad = (C.c_int32 * n)(*([-1] * (n - 1) + [n - 1]))
     assert L.cdlrm_tape_set_lanes(tape2._h, (C.c_int32 * n)(*lane2), bad, n) != 0

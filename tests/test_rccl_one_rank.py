@@ -142,7 +142,7 @@ def test_multi_rank_path_over_one_rank_rccl_is_the_fast_path(golden, case, port)
     assert "error" not in out, out["error"]
     assert out["avg"] is True, "the ReduceOp.AVG branch is the one RCCL runs"
     assert out["merges"] >= 2
-    assert out["lanes"] == [2], "the steps replayed as two-lane native tapes"
+    assert out["lanes"] and min(out["lanes"]) >= 2, "the steps replayed as multi-lane native tapes"
     for key in ("losses", "tags", "params", "weight", "host"):
         assert out["same_" + key], "%s differs between the forced multi-rank path and the one-rank fast path" % key
     if not CASES[case]["device_rng"]:       # parity RNG: also the reference's own trajectory and tag state

@@ -1,5 +1,5 @@
 """Race check "the strong way" (tools/race_check.py): the same training steps from the same initial state under every SCHEDULE
-the engine can run -- two-lane / one-lane / Python-replayed / untaped launch sequences, events attached to launches or recorded
+the engine can run -- three-lane / two-lane / one-lane / Python-replayed / untaped launch sequences, events attached to launches or recorded
 behind them, the deferred-update wait on the side stream or on the training queue -- must end on the same BITS: final loss,
 every dense parameter, the cache rows' checksum, the tags, the running statistics.  Same kernels, same inputs, same stream
 dependencies; only who issues which call, and when, differs -- so any difference is a missing dependency.  Run at the per-rank
@@ -20,4 +20,4 @@ def test_every_schedule_ends_on_the_same_bits(batch, steps):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "race_check.py"), "--batch", str(batch), "--steps", str(steps)],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("bit-identical") == 5 and "DIFFERS" not in r.stdout, r.stdout
+    assert r.stdout.count("bit-identical") == 6 and "DIFFERS" not in r.stdout, r.stdout

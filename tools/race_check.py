@@ -18,7 +18,8 @@ import bench  # noqa: E402
 from cdlrm_amd.engine import WindowResolver  # noqa: E402
 
 VARIANTS = {
-    "default (two lanes, attached events, folded wait)": {},
+    "default (three lanes, attached events, folded wait)": {},
+    "two lanes": {"tape_lanes": 2},
     "one lane": {"tape_lanes": 1},
     "recorded events": {"attach_events": False},
     "wait on the training queue": {"fold_top_wait": False},
