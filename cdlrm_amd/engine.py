@@ -530,6 +530,9 @@ class TrainEngine:
         # ... in lanes: the training queue's calls by this thread, each side queue's by a helper thread of the library.  At a
         # per-rank batch of 1024 the thread that issues a step's ~45 runtime calls, not the GPU, sets the step time
         self.tape_lanes = 3
+        # ... below this local batch only: from it on the GPU needs several times the host's issue time per step and a
+        # single issuing thread keeps the program order of the tape (A / B at c3: 0.6331 one lane, 0.6396 three)
+        self.tape_lanes_below = 4096
         # cross-stream events of the step complete WITH the kernel they follow (attached to its launch) instead of being
         # recorded behind it: no marker packet, no bubble on the training queue
         self.attach_events = True
@@ -1155,7 +1158,7 @@ class TrainEngine:
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
-               self._gslot is not None, self.loss_sync, self.tape_lanes, self.attach_events, self.fold_top_wait,
+               self._gslot is not None, self.loss_sync, self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
@@ -1196,8 +1199,8 @@ class TrainEngine:
                 # the same calls as a C-side tape: one library call per step instead of ~45 interpreted ones (0.22 ms of
                 # host time per step, more than the GPU needs at a per-rank batch of 1024)
                 try:
-                    native = _lib.NativeTape(prog, cells, main_stream=main.cuda_stream if self.tape_lanes > 1 else None,
-                                             max_lanes=self.tape_lanes)
+                    lanes = self.tape_lanes if B < self.tape_lanes_below else 1
+                    native = _lib.NativeTape(prog, cells, main_stream=main.cuda_stream if lanes > 1 else None, max_lanes=lanes)
                 except _lib.TapeUnsupported as e:
                     native = None
                     self.tape_fallbacks.append(str(e))      # this control path replays from Python (bench.py reports it)

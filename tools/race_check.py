@@ -34,6 +34,7 @@ def run(a, knobs, host):
     wl = bench.build_workload(a.config, lookahead=L, batch=a.batch, dev=dev, max_ind_range=a.max_ind_range, host=host,
                               cache_init="zeros", write_back=False)
     eng, pipe, syn, B, cg = wl["eng"], wl["pipe"], wl["syn"], wl["B"], wl["cg"]
+    eng.tape_lanes_below = 1 << 30          # (multi-lane replay at every batch size here)
     for k, v in knobs.items():
         setattr(eng, k, v)
     own = torch.cuda.Stream(device=dev, priority=-1)
