@@ -133,6 +133,40 @@ def main():
                         us.append(e0.elapsed_us(e1))
                 print("gather stream priority %2d, %-30s: %6.1f us (min %.1f max %.1f)" % (prio, mode, np.mean(us), min(us), max(us)))
 
+    if want("interact_beside"):
+        # the interaction forward (HBM-bound, on the critical path) beside a weight-gradient GEMM on another stream: how much
+        # does each lose?  (Would deferring the last top-MLP weight gradient under the next step's interaction pay?)
+        F = 27
+        feat = torch.randn(B, F, D, device=DEV)
+        npairs = F * (F - 1) // 2
+        R = torch.empty(B, (D + npairs + 3) // 4 * 4, device=DEV)
+        X = torch.randn(B, 512, device=DEV)
+        dZ = torch.randn(B, 256, device=DEV)
+        W = torch.randn(256, 512, device=DEV) / 22.0
+        dW, db = torch.empty(256, 512, device=DEV), torch.empty(256, device=DEV)
+        work = ops.linear_bwd_work(B, 256, 512, DEV)
+        gs = torch.cuda.Stream()
+        def ev_time(fn, stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream); fn(); e1.record(stream)
+            return e0, e1
+        for mode in ("alone", "together"):
+            ti, tg = [], []
+            for rep in range(14):
+                torch.cuda.synchronize()
+                main = torch.cuda.current_stream()
+                gs.wait_stream(main)
+                if mode == "together":
+                    g0, g1 = ev_time(lambda: ops.linear_bwd(X, W, None, dZ, None, dW, db, 0, work, stream=gs), gs)
+                i0, i1 = ev_time(lambda: ops.interact_fwd(feat, False, R), main)
+                if mode == "alone":
+                    torch.cuda.synchronize()
+                    g0, g1 = ev_time(lambda: ops.linear_bwd(X, W, None, dZ, None, dW, db, 0, work, stream=gs), gs)
+                torch.cuda.synchronize()
+                if rep >= 2:
+                    ti.append(i0.elapsed_time(i1) * 1e3); tg.append(g0.elapsed_time(g1) * 1e3)
+            print("%-9s interact_fwd %6.1f us   weight gradient 256x512 (+ reduce) %6.1f us" % (mode, np.mean(ti), np.mean(tg)))
+
     if want("interact"):
         F = 27
         feat = torch.randn(B, F, D, device=DEV)
