@@ -66,6 +66,23 @@ def main():
         def set_knob(v):
             torch.cuda.synchronize()
             assert fn(key, int(v)) == 0
+    elif a.attr in ("pref_priority", "side_priority"):
+        # the priority of the engine's prefetch / weight-gradient stream or of its side stream (numerically lower = more
+        # urgent; the training queue runs at -1): a stream of that priority replaces the engine's, recorded tapes are dropped
+        from cdlrm_amd import _lib
+        made = {}
+
+        def set_knob(v):
+            torch.cuda.synchronize()
+            if v not in made:
+                h = _lib.raw().cdlrm_stream_create(int(v))
+                made[v] = torch.cuda.ExternalStream(int(h), device=dev)
+            if a.attr == "pref_priority":
+                eng.pref = eng.wst = made[v]
+            else:
+                eng.side = made[v]
+            eng._tapes.clear()
+            eng._pref = None
     else:
         def set_knob(v):
             setattr(eng, a.attr, v)
