@@ -345,6 +345,14 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
 //   * (round 3) the split-M weight gradients of a sub-network's layers as ONE grouped launch of this kernel (1536 workgroups
 //     for the top MLP: one ramp, the problems' store tails under each other's loops): 0.667 against 0.641 ms per step --
 //     the side queue's kernel then holds every workgroup slot for 250 us and the training queue's GEMMs wait for slots.
+//   * (round 3, second session) write-through C stores (buffer stores with sc1 / sc0 sc1 / nt cache bits, so that nothing
+//     stays dirty in the XCDs' L2s for the end-of-kernel write-back): 41.9 / 41.9 / 42.5 us against 41.9 plain on the forward
+//     layout, the epilogue itself 15.6 k cycles instead of 11.6 k -- back-to-back launches of this kernel are 1.4 us apart
+//     (first workgroup start -> last end 40.5 us of 41.9), the boundary is not where the time is;
+//   * (same session) bias words / the dgrad's activation-mask words fetched into registers BEFORE the K loop (144 VGPRs):
+//     the epilogue stays at 10.8 k / 9.6 k cycles (11.6 k / 11.0 k) and the kernel at 41.9 / 42.6 us -- the store tail is the
+//     write burst itself (16 MB leaving 512 lock-stepped workgroups in ~5 us = 3.3 TB/s; the weight-gradient layout, whose
+//     workgroups drift apart in the loop, shows 5.0 k cycles for the same bytes), not the latency of its operands.
 // Where a workgroup's 83 k cycles go at 8192 x 512 x 512 (128x64 tile, two workgroups per CU, 2.3-2.4 GHz): prologue 2.5 k,
 // loop 73.7 k (ideal 65.5 k), epilogue 10.5 k -- the 16 MB of output leave all 512 workgroups at the same moment.
 
