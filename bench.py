@@ -246,9 +246,13 @@ def main():
     ev_flags = []                           # per sampled launch: did a window plan run beside it?
     refills = {"commits": 0, "plans": 0, "merges": 0, "first_plan_ms": None, "first_commit_ms": None}
     # the roofline kernel is timed with HIP events ATTACHED TO ITS LAUNCH (cdlrm_ctx_time_next_gather -> hipExtLaunchKernel:
-    # the kernel's own start / stop timestamps, no marker packets on the queue), so every launch of the timed region can be
-    # sampled without moving it; runs beyond 4096 steps keep every --gather-sample'th
-    sample_every = 1 if a.steps <= 4096 else max(1, a.gather_sample)
+    # the kernel's own start / stop timestamps, no marker packets on the queue).  A timed launch carries a completion signal
+    # and the queue handles it before the next packet: measured on one box, 1500 steps, sampling EVERY launch costs the step
+    # 0.007 ms (0.6473 / 0.6464 against 0.6397 / 0.6401 untimed).  So every SECOND launch of the timed region is sampled (10 of
+    # the driver's 20 steps); runs beyond 4096 steps keep every --gather-sample'th
+    sample_every = min(2, max(1, a.gather_sample)) if a.steps <= 4096 else max(1, a.gather_sample)
+    if world > 1:       # a per-rank step is 3x shorter and latency-bound: the same 7 us weigh 3x more there
+        sample_every = max(sample_every, min(8, max(1, a.gather_sample)))
     # the events exist before the timed region starts; their handles are cells of the engine's launch tape
     from cdlrm_amd import ops as _ops
     ev_pool = {j: (_ops.TimingEvent(), _ops.TimingEvent())
@@ -314,9 +318,9 @@ def main():
         if timed and world > 1 and jj > 0 and jj % cfg["agg"] == 0:
             refills["merges"] += 1
         rs = state.get("res")
-        # (warm-up steps time their gather into a scratch pair: the launch tapes the timed steps replay -- a timed launch is
-        #  another control path than an untimed one -- are then recorded before the timed region starts)
-        gev = ev_pool[j] if sample else (warm_pair if (not timed and a.gather_sample > 0 and sample_every == 1) else None)
+        # (warm-up steps time their gather into a scratch pair at the same cadence: the launch tapes the timed steps replay -- a
+        #  timed launch is another control path than an untimed one -- are then recorded before the timed region starts)
+        gev = ev_pool[j] if sample else (warm_pair if (not timed and a.gather_sample > 0 and j % sample_every == 0) else None)
         eng.step(X, idx, T, j=jj, gather_events=gev, next_idx=nxt,
                  res=rs.batch(jloc) if rs is not None else None,
                  next_res=rs.batch(jloc + 1) if (rs is not None and nxt is not None) else None,
