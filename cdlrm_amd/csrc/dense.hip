@@ -637,13 +637,12 @@ __device__ __forceinline__ void interact_stage(float* __restrict__ Ts, int FD4, 
     }
 }
 
-template <int D4, bool vec_out>
+template <int D4>
 __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict__ feat, int64_t B, int F, int itself,
                                                         float* __restrict__ R, int64_t ld_r) {
     constexpr int D = 4 * D4, PITCH = D + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lr = lane & 31, lk = lane >> 5;
     float* Ts = smem + wave * (32 * PITCH);
     for (int e = lane; e < 32 * PITCH; e += 64) Ts[e] = 0.f;        // rows F..31 stay zero
     const int FD4 = F * D4;
@@ -695,58 +694,122 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
 #if IA_ABL == 3
         if (acc00[0] + acc10[1] + acc11[2] == 1.2345f) out[0] = 1.f;
 #else
-        if (vec_out) {
-            // The output row [dense D | pairs] is put together in LDS, behind row 0 of T (the other rows are dead until the
-            // next sample is staged), and leaves as whole float4 words: a fixed number of unconditional, fully coalesced
-            // stores.  (Storing the accumulators straight from their lanes is a dozen 4-byte stores under lane-dependent
-            // conditions; behind them the compiler can no longer count the outstanding memory operations and makes the
-            // next sample's staging wait for vmcnt(0) -- for these stores' acknowledgements -- in every iteration.)
+        for (int c = lane; c < D; c += 64) out[c] = Ts[c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
-                if (i0 < F && l16 < i0 + off) Ts[D + pair_base(i0, itself) + l16] = acc00[r];
-                if (i1 < F) Ts[D + pair_base(i1, itself) + l16] = acc10[r];
-                if (i1 < F && 16 + l16 < i1 + off) Ts[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
-            }
-            const int width = D + pair_base(F, itself);
-            if (lane < 4) Ts[width + lane] = 0.f;   // the row pitch's pad columns (ld_r >= width rounded up to 4)
-            const int W4 = (width + 3) >> 2;
-            constexpr int NS = (D4 + 132 + 63) / 64;                 // covers F = 32 with `itself`; a compile-time count
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int e = min(64 * k + lane, W4 - 1);            // clamped: spare lanes / passes repeat the last word
-                *reinterpret_cast<v4f*>(out + 4 * e) = *reinterpret_cast<const v4f*>(Ts + 4 * e);
-            }
-            // rows 1 .. of T are rewritten by the next interact_stage; its row pitch pad [D, D+4) too (never read)
-        } else {
-            for (int c = lane; c < D; c += 64) out[c] = Ts[c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // accumulator register r of lane l: tile row 4 (l / 16) + r, tile column l % 16
-                const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
-                if (i0 < F && l16 < i0 + off) out[D + pair_base(i0, itself) + l16] = acc00[r];
-                if (i1 < F) out[D + pair_base(i1, itself) + l16] = acc10[r];
-                if (i1 < F && 16 + l16 < i1 + off) out[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            // accumulator register r of lane l: tile row 4 (l / 16) + r, tile column l % 16
+            const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
+            if (i0 < F && l16 < i0 + off) out[D + pair_base(i0, itself) + l16] = acc00[r];
+            if (i1 < F) out[D + pair_base(i1, itself) + l16] = acc10[r];
+            if (i1 < F && 16 + l16 < i1 + off) out[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
         IA_STAMP_AT(3)
     };
-    // The first sample is peeled off the loop so that the loop is only ever entered with the same memory operations in
-    // flight as its own back edge leaves -- the next sample's loads, then this one's output stores: the wait in front of
-    // the staging then counts the loads alone.  (Entered straight from the prefetch, the compiler has to assume the
-    // smaller number and waits for the stores' acknowledgements in every iteration.)
-    one(b);
+    for (; b < B; b += nw) one(b);
+}
+
+// Column-slab forward (the kernel the step runs): the sample's [F, D] block is staged NS slabs of D / NS columns at a time into a
+// slice of 32 x (D / NS + 4) floats; the three accumulator chains run on across the slabs -- the contraction order of
+// k_interact_fwd_p, bit-identical results --; each slab's registers are refilled with the NEXT sample's slab right after they are
+// staged, so a wave's loads, LDS traffic and MFMAs interleave at slab granularity instead of sample granularity.  That, not
+// occupancy, is what pays (tools/interact_ablate.hip, B = 8192, F = 27, D = 128): 22.6 us on ONE workgroup per CU (a wave streams
+// 8 samples) against 29.3 us for whole-row staging on two; with more waves per CU (the slice is 4.6 KB instead of 16.9 KB: up to
+// 20 fit) the kernel gets SLOWER, 24.2 us at 8, 26.6-27.5 us at 12-20.  Rows F .. 31 of a slab are copies of row F - 1 (clamped
+// row index in the load: finite values whose products land in rows / columns >= F of Z, never stored).
+// The output row [dense D | pairs | pad] is put together in a staging row of its own and leaves as whole float4 words: a fixed
+// number of unconditional, fully coalesced stores.  (Storing the accumulators straight from their lanes is a dozen 4-byte stores
+// under lane-dependent conditions; behind them the compiler can no longer count the outstanding memory operations and makes the
+// next sample's staging wait for vmcnt(0) -- for these stores' acknowledgements -- in every iteration.)  The first sample is
+// peeled off the loop so that the loop is only ever entered with the same memory operations in flight as its own back edge
+// leaves -- the next sample's loads, then this one's output stores: the wait in front of the staging then counts the loads alone.
+template <int D4, int NS>
+__global__ void __launch_bounds__(256) k_interact_fwd_s(const float* __restrict__ feat, int64_t B, int F, int itself,
+                                                        float* __restrict__ R, int64_t ld_r) {
+    constexpr int D = 4 * D4, CS = D4 / NS, DS = 4 * CS, PITCH = DS + 4, NR = CS / 2;
+    constexpr int OSW = D + 532;                    // output staging row: D + up to 528 pairs + the pad word
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Ts = smem + wave * (32 * PITCH + OSW);
+    float* Os = Ts + 32 * PITCH;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int off = itself ? 1 : 0;
+    // per register i of a slab: (row, chunk) of this lane's 16 bytes; the source row is clamped to F - 1
+    int soff[NR], doff[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int e = lane + 64 * i, row = e / CS, c = e % CS;
+        soff[i] = min(row, F - 1) * D4 + c;
+        doff[i] = row * PITCH + 4 * c;
+    }
+    v4f nxt[NS][NR];
+    auto prefetch = [&](int s, int64_t bb) __attribute__((always_inline)) {
+        const v4f* src = reinterpret_cast<const v4f*>(feat) + bb * (int64_t)F * D4 + s * CS;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) nxt[s][i] = src[soff[i]];
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) prefetch(s, b);
+    auto one = [&](int64_t b) __attribute__((always_inline)) {
+        const int64_t bn = min(b + nw, B - 1);
+        v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
+        const float* tp = Ts + l16 * PITCH + 4 * g4;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) *reinterpret_cast<v4f*>(Ts + doff[i]) = nxt[s][i];
+            if (lane < CS) *reinterpret_cast<v4f*>(Os + s * DS + 4 * lane) = nxt[s][0];      // row 0: the dense part of the output
+            prefetch(s, bn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 2
+            for (int g = 0; g < DS / 16; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4*>(tp + 16 * g);                  // rows 0..15
+                const float4 a1 = *reinterpret_cast<const float4*>(tp + 16 * PITCH + 16 * g);     // rows 16..31
+                acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, a0.x, acc00, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a0.x, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, a1.x, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, a0.y, acc00, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a0.y, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, a1.y, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, a0.z, acc00, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a0.z, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, a1.z, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, a0.w, acc00, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a0.w, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, a1.w, acc11, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float* out = R + b * ld_r;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
+            if (i0 < F && l16 < i0 + off) Os[D + pair_base(i0, itself) + l16] = acc00[r];
+            if (i1 < F) Os[D + pair_base(i1, itself) + l16] = acc10[r];
+            if (i1 < F && 16 + l16 < i1 + off) Os[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
+        }
+        const int width = D + pair_base(F, itself);
+        if (lane < 4) Os[width + lane] = 0.f;       // the row pitch's pad columns (ld_r >= width rounded up to 4)
+        const int W4 = (width + 3) >> 2;
+        constexpr int NST = (D4 + 132 + 63) / 64;   // covers F = 32 with `itself`; a compile-time count
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = min(64 * k + lane, W4 - 1);
+            *reinterpret_cast<v4f*>(out + 4 * e) = *reinterpret_cast<const v4f*>(Os + 4 * e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    one(b);                 // first sample peeled (above)
     for (b += nw; b < B; b += nw) one(b);
 }
 
-// backward: dR row staged as float4 (needs ld_r % 4 == 0 and a 16-byte aligned dR)
-// STAGED (F > 16): the 32x32 accumulator tile leaves through LDS -- 16 rows at a time into the part of the dR staging
-// row that is dead once the S fragments are built -- as whole float4 words of valid rows only: 4 unconditional, fully
-// coalesced stores per 32-column block instead of 16 four-byte stores under lane-dependent conditions (see the forward
-// kernel: behind conditional stores every iteration waits for the previous sample's store acknowledgements).
-template <int D4, bool STAGED>
+// backward, whole-row staging (F <= 16 or an unaligned dfeat): dR row staged as float4 (needs ld_r % 4 == 0 and a 16-byte
+// aligned dR), the accumulators stored straight from their lanes
+template <int D4>
 __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict__ feat, const float* __restrict__ dR,
                                                         int64_t ld_r, int64_t B, int F, int itself, int x_act,
                                                         float* __restrict__ dfeat) {
@@ -758,7 +821,6 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
     const int lr = lane & 31, lk = lane >> 5;
     float* Ts = smem + wave * (32 * PITCH + GMAX);
     float* Gs = Ts + 32 * PITCH;
-    float* Os = Gs + D;                         // [16][32] output staging (STAGED)
     for (int e = lane; e < 32 * PITCH; e += 64) Ts[e] = 0.f;
     const int FD4 = F * D4;
     const int off = itself ? 1 : 0;
@@ -793,8 +855,6 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
             sreg[m] = v;
         }
         float* out = dfeat + b * F * D;
-        // (STAGED: unrolled, so that the number of stores behind the prefetch loads is a compile-time count)
-#pragma unroll STAGED ? D / 32 : 1
         for (int n0 = 0; n0 < D; n0 += 32) {
             f32x16 acc;
 #pragma unroll
@@ -803,10 +863,109 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
 #pragma unroll
             for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sreg[m], tp[2 * m * PITCH], acc, 0, 0, 0);
             const int col = n0 + lr;
-            if (STAGED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (i < F) {
+                    float v = acc[r];
+                    if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
+                        v += Gs[col];
+                        const float y = Ts[col];
+                        if (x_act == 1) v = y > 0.f ? v : 0.f;
+                        else if (x_act == 2) v = v * ((1.0f - y) * y);
+                    }
+                    out[i * D + col] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (; b < B; b += nw) one(b);
+}
+
+// Column-slab backward (the kernel the step runs at F > 16): dT[:, slab] = (G + G^T) T[:, slab] needs only the slab's columns of
+// T, so the sample's features are staged NS slabs of D / NS columns at a time (slice 32 x (D / NS + 4) floats instead of
+// 32 x (D + 4)), each slab's registers refilled with the next sample's slab as soon as they are staged; the dR row and the S
+// fragments are per sample.  The 32x32 accumulator tile of a 32-column block leaves through LDS -- 16 rows at a time into the
+// part of the dR staging row that is dead once the S fragments are built -- as whole float4 words of valid rows only: 4
+// unconditional, fully coalesced stores per block (see the forward kernel for why).  Same products in the same order as
+// k_interact_bwd_p: bit-identical.  49.1 -> 41.2 us at B = 8192, F = 27, D = 128 (two workgroups per CU; one: 45.6).
+// Needs F > 16, a 16-byte aligned dfeat / dR and ld_r % 4 == 0.
+template <int D4, int NS>
+__global__ void __launch_bounds__(256) k_interact_bwd_s(const float* __restrict__ feat, const float* __restrict__ dR,
+                                                        int64_t ld_r, int64_t B, int F, int itself, int x_act,
+                                                        float* __restrict__ dfeat) {
+    constexpr int D = 4 * D4, CS = D4 / NS, DS = 4 * CS, PITCH = DS + 4, NR = CS / 2;
+    constexpr int GMAX = D + 528;               // dense part + up to 32*33/2 pair gradients
+    constexpr int NG = (GMAX / 4 + 63) / 64;
+    static_assert(DS % 32 == 0, "a slab is a whole number of 32-column MFMA blocks");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    float* Ts = smem + wave * (32 * PITCH + GMAX);
+    float* Gs = Ts + 32 * PITCH;
+    float* Os = Gs + D;                         // [16][32] output staging: the pair part of the dR row, dead once S is built
+    const int off = itself ? 1 : 0;
+    const int npairs = pair_base(F, itself);
+    const int G4 = (D + npairs + 3) / 4;        // float4 words of one dR row (the pad word lies inside the pitch)
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    int soff[NR], doff[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int e = lane + 64 * i, row = e / CS, c = e % CS;
+        soff[i] = min(row, F - 1) * D4 + c;
+        doff[i] = row * PITCH + 4 * c;
+    }
+    v4f nxt[NS][NR], gn[NG];
+    auto prefetch = [&](int s, int64_t bb) __attribute__((always_inline)) {
+        const v4f* src = reinterpret_cast<const v4f*>(feat) + bb * (int64_t)F * D4 + s * CS;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) nxt[s][i] = src[soff[i]];
+    };
+#pragma unroll
+    for (int i = 0; i < NG; ++i) gn[i] = reinterpret_cast<const v4f*>(dR + b * ld_r)[min(lane + 64 * i, G4 - 1)];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) prefetch(s, b);
+    auto one = [&](int64_t b) __attribute__((always_inline)) {
+        const int64_t bn = min(b + nw, B - 1);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) *reinterpret_cast<v4f*>(Gs + 4 * min(lane + 64 * i, GMAX / 4 - 1)) = gn[i];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gn[i] = reinterpret_cast<const v4f*>(dR + bn * ld_r)[min(lane + 64 * i, G4 - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        // A fragments of S = G + G^T: lane holds S[lr][lk + 2m], m = 0..15
+        float sreg[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int j = lk + 2 * m;
+            float v = 0.f;
+            if (lr < F && j < F) {
+                if (j < lr + off) v += Gs[D + pair_base(lr, itself) + j];
+                if (lr < j + off) v += Gs[D + pair_base(j, itself) + lr];
+            }
+            sreg[m] = v;
+        }
+        float* out = dfeat + b * F * D;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) *reinterpret_cast<v4f*>(Ts + doff[i]) = nxt[s][i];
+            prefetch(s, bn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nl = 0; nl < DS; nl += 32) {
+                const int n0 = s * DS + nl;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float* tp = Ts + lk * PITCH + nl + lr;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sreg[m], tp[2 * m * PITCH], acc, 0, 0, 0);
                 {   // row 0 (register 0 of the lanes lk = 0): the dense feature: + direct path, * act'(bottom-MLP output)
-                    float v = acc[0] + Gs[col];
-                    const float y = Ts[col];
+                    float v = acc[0] + Gs[n0 + lr];
+                    const float y = Ts[nl + lr];
                     if (x_act == 1) v = y > 0.f ? v : 0.f;
                     else if (x_act == 2) v = v * ((1.0f - y) * y);
                     acc[0] = lk == 0 ? v : acc[0];
@@ -817,39 +976,20 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
                     for (int rr = 0; rr < 8; ++rr)      // accumulator register 8h + rr: row 16h + (rr&3) + 8 (rr>>2) + 4 lk
                         Os[((rr & 3) + 8 * (rr >> 2) + 4 * lk) * 32 + lr] = acc[8 * h + rr];
                     const int nvalid = min(F - 16 * h, 16) * 8;     // float4 words of valid rows (F > 16: >= 8)
-                    const int first = 0;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const int idx = first + min(64 * k + lane, nvalid - first - 1);     // clamped: spare lanes repeat the last word
+                        const int idx = min(64 * k + lane, nvalid - 1);     // clamped: spare lanes repeat the last word
                         const int row = idx >> 3, c4 = idx & 7;
                         *reinterpret_cast<v4f*>(out + (16 * h + row) * D + n0 + 4 * c4) =
                             *reinterpret_cast<const v4f*>(Os + row * 32 + 4 * c4);
                     }
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (i < F) {
-                        float v = acc[r];
-                        if (i == 0) {       // the dense feature: + direct path, * act'(bottom-MLP output) if asked
-                            v += Gs[col];
-                            const float y = Ts[col];
-                            if (x_act == 1) v = y > 0.f ? v : 0.f;
-                            else if (x_act == 2) v = v * ((1.0f - y) * y);
-                        }
-                        out[i * D + col] = v;
-                    }
-                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
-    if (STAGED) {           // first sample peeled: see k_interact_fwd_p
-        one(b);
-        b += nw;
-    }
-    for (; b < B; b += nw) one(b);
+    one(b);                 // first sample peeled: see k_interact_fwd_s
+    for (b += nw; b < B; b += nw) one(b);
 }
 
 template <typename K>
@@ -867,24 +1007,43 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
     CDLRM_REQUIRE(aligned16(feat) && ld_r >= D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2), "alignment / ld_r");
     if (B == 0) return 0;
     if (D == 32 || D == 64 || D == 128 || D == 256) {
-        const size_t ldsp = (size_t)4 * 32 * (D + 4) * sizeof(float);
         const int width_p = D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2);
-        // whole-float4 output rows: the 32-row staging slice must hold one (F >= 4 does), the row pitch its last word
-        const int vec_out_p = ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width_p + 3) & ~3) && width_p + 4 <= 32 * (D + 4);
+        // whole-float4 output rows: the row pitch holds the last (padded) word
+        const bool vec_out_p = ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width_p + 3) & ~3);
         int64_t gp = cdiv(B, 4);
+        if (vec_out_p) {
+            // column-slab kernel, slabs of 32 columns, ONE workgroup per CU (each wave streams 8 samples at B = 8192).  Measured at
+            // B = 8192, F = 27, D = 128 (tools/interact_ablate.hip): 22.6 us against 29.3 for the whole-row staging kernel at two
+            // workgroups per CU (26.9 at one); 2 / 4 / 8 slabs at one workgroup per CU 23.3 / 22.6 / 23.3, at two 24.7 / 24.2 / 24.3,
+            // at three to five 26.6-27.5 -- the finer-grained pipeline, not occupancy, is what pays
+            const size_t lds_s = (size_t)4 * (32 * 36 + D + 532) * sizeof(float);
+            if (gp > 256) gp = 256;
+            static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
+#define IFWD_S(D4_, A_)                                                                                               \
+    do {                                                                                                              \
+        int rc = interact_set_lds(k_interact_fwd_s<D4_, D4_ / 8>, lds_s, &A_);                                        \
+        if (rc) return rc;                                                                                            \
+        hipLaunchKernelGGL((k_interact_fwd_s<D4_, D4_ / 8>), dim3((unsigned)gp), dim3(256), lds_s, (hipStream_t)stream, feat, B, \
+                           F, itself, R, ld_r);                                                                       \
+    } while (0)
+            if (D == 32) IFWD_S(8, s32);
+            else if (D == 64) IFWD_S(16, s64);
+            else if (D == 128) IFWD_S(32, s128);
+            else IFWD_S(64, s256);
+#undef IFWD_S
+            CDLRM_LAUNCH_CHECK();
+            return 0;
+        }
+        // output rows that cannot leave as float4 words (pitch or alignment): whole-row staging, scalar stores
+        const size_t ldsp = (size_t)4 * 32 * (D + 4) * sizeof(float);
         if (gp > 512) gp = 512;             // 2 workgroups per CU (LDS), each wave streams ~4 samples
-        static size_t a32 = 0, a64 = 0, a128 = 0, a256 = 0, a32v = 0, a64v = 0, a128v = 0, a256v = 0;
+        static size_t a32 = 0, a64 = 0, a128 = 0, a256 = 0;
 #define IFWD(D4_, A_)                                                                                          \
     do {                                                                                                       \
-        int rc = interact_set_lds(k_interact_fwd_p<D4_, false>, ldsp, &A_);                                    \
-        if (!rc) rc = interact_set_lds(k_interact_fwd_p<D4_, true>, ldsp, &A_##v);                             \
+        int rc = interact_set_lds(k_interact_fwd_p<D4_>, ldsp, &A_);                                           \
         if (rc) return rc;                                                                                     \
-        if (vec_out_p)                                                                                         \
-            hipLaunchKernelGGL((k_interact_fwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, B, F, itself, R, ld_r);                                                   \
-        else                                                                                                   \
-            hipLaunchKernelGGL((k_interact_fwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, B, F, itself, R, ld_r);                                                   \
+        hipLaunchKernelGGL((k_interact_fwd_p<D4_>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream,  \
+                           feat, B, F, itself, R, ld_r);                                                       \
     } while (0)
         if (D == 32) IFWD(8, a32);
         else if (D == 64) IFWD(16, a64);
@@ -913,23 +1072,43 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     CDLRM_REQUIRE(aligned16(feat), "alignment");
     if (B == 0) return 0;
     const int npairs = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    if ((D == 32 || D == 64 || D == 128) && ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3)) {
+    const bool vec_in = ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3);
+    if ((D == 32 || D == 64 || D == 128 || D == 256) && vec_in && F > 16 && aligned16(dfeat)) {
+        // column-slab kernel, slabs of 32 columns, two workgroups per CU.  Measured at B = 8192, F = 27, D = 128
+        // (tools/interact_ablate.hip): 41.2 us against 49.1 for the whole-row staging kernel; 4 slabs on 256 / 512 / 768 workgroups
+        // 45.6 / 41.2 / 44.2, 2 slabs 46.7 / 51.8 / 54.2
+        const size_t lds_s = (size_t)4 * (32 * 36 + D + 528) * sizeof(float);
+        int64_t gp = cdiv(B, 4);
+        if (gp > 512) gp = 512;
+        static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
+#define IBWD_S(D4_, A_)                                                                                               \
+    do {                                                                                                              \
+        int rc = interact_set_lds(k_interact_bwd_s<D4_, D4_ / 8>, lds_s, &A_);                                        \
+        if (rc) return rc;                                                                                            \
+        CDLRM_LAUNCH_EV((k_interact_bwd_s<D4_, D4_ / 8>), dim3((unsigned)gp), dim3(256), lds_s, (hipStream_t)stream, feat, dR,   \
+                        ld_r, B, F, itself, x_act, dfeat);                                                            \
+    } while (0)
+        if (D == 32) IBWD_S(8, s32);
+        else if (D == 64) IBWD_S(16, s64);
+        else if (D == 128) IBWD_S(32, s128);
+        else IBWD_S(64, s256);
+#undef IBWD_S
+        CDLRM_LAUNCH_CHECK();
+        CDLRM_FLUSH_STOP_EVENT(stream);
+        return 0;
+    }
+    if ((D == 32 || D == 64 || D == 128) && vec_in) {
+        // F <= 16 (or an unaligned dfeat): whole-row staging, the accumulators stored straight from their lanes
         const size_t ldsp = (size_t)4 * (32 * (D + 4) + D + 528) * sizeof(float);
         int64_t gp = cdiv(B, 4);
         if (gp > 512) gp = 512;
-        static size_t b32 = 0, b64 = 0, b128 = 0, b32s = 0, b64s = 0, b128s = 0;
-        const bool staged = F > 16 && aligned16(dfeat);
+        static size_t b32 = 0, b64 = 0, b128 = 0;
 #define IBWD(D4_, A_)                                                                                          \
     do {                                                                                                       \
-        int rc = interact_set_lds(k_interact_bwd_p<D4_, false>, ldsp, &A_);                                    \
-        if (!rc) rc = interact_set_lds(k_interact_bwd_p<D4_, true>, ldsp, &A_##s);                             \
+        int rc = interact_set_lds(k_interact_bwd_p<D4_>, ldsp, &A_);                                           \
         if (rc) return rc;                                                                                     \
-        if (staged)                                                                                            \
-            CDLRM_LAUNCH_EV((k_interact_bwd_p<D4_, true>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                             \
-        else                                                                                                   \
-            CDLRM_LAUNCH_EV((k_interact_bwd_p<D4_, false>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream, \
-                               feat, dR, ld_r, B, F, itself, x_act, dfeat);                             \
+        CDLRM_LAUNCH_EV((k_interact_bwd_p<D4_>), dim3((unsigned)gp), dim3(256), ldsp, (hipStream_t)stream,     \
+                        feat, dR, ld_r, B, F, itself, x_act, dfeat);                                           \
     } while (0)
         if (D == 32) IBWD(8, b32);
         else if (D == 64) IBWD(16, b64);

@@ -4,10 +4,14 @@
 #include <stdarg.h>
 #include "dense.hip"
 void cdlrm_set_error(const char* fmt, ...) {}
+thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
+thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
 
 int main(int argc, char** argv) {
     int64_t B = 8192; int F = 27, D = 128;
     if (argc > 1) B = atol(argv[1]);
+    if (argc > 2) D = atoi(argv[2]);
+    if (argc > 3) F = atoi(argv[3]);
     const int np = F * (F - 1) / 2, ld = (D + np + 3) / 4 * 4;
     float *feat, *R, *dR, *dfeat;
     hipMalloc(&feat, B * F * D * 4); hipMalloc(&dfeat, B * F * D * 4); hipMalloc(&R, B * ld * 4); hipMalloc(&dR, B * ld * 4);
@@ -28,7 +32,16 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("ABL %d %s %.1f us\n", IA_ABL, which ? "bwd" : "fwd", ms / 30 * 1e3);
+        printf("ABL %d %s %.1f us", IA_ABL, which ? "bwd" : "fwd", ms / 30 * 1e3);
+        {   // FNV-1a of the result's bytes: variants of a kernel must agree bit for bit
+            const size_t nb = which ? (size_t)B * F * D * 4 : (size_t)B * ld * 4;
+            unsigned char* hb = (unsigned char*)malloc(nb);
+            hipMemcpy(hb, which ? (void*)dfeat : (void*)R, nb, hipMemcpyDeviceToHost);
+            unsigned long long hsh = 1469598103934665603ull;
+            for (size_t i = 0; i < nb; ++i) hsh = (hsh ^ hb[i]) * 1099511628211ull;
+            printf("   result hash %016llx\n", hsh);
+            free(hb);
+        }
 #ifdef IA_STAMP
         if (which == 0) {
             long long st[64];
