@@ -1079,7 +1079,9 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         // 45.6 / 41.2 / 44.2, 2 slabs 46.7 / 51.8 / 54.2
         const size_t lds_s = (size_t)4 * (32 * 36 + D + 528) * sizeof(float);
         int64_t gp = cdiv(B, 4);
-        if (gp > 512) gp = 512;
+        // (D = 256: 336 registers per lane, one wave per SIMD -- one workgroup per CU is all that fits: 96.7 us against 102.2)
+        const int64_t gmax = D == 256 ? 256 : 512;
+        if (gp > gmax) gp = gmax;
         static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
 #define IBWD_S(D4_, A_)                                                                                               \
     do {                                                                                                              \
