@@ -246,7 +246,8 @@ def main():
     ev_flags = []                           # per sampled launch: did a window plan run beside it?
     refills = {"commits": 0, "plans": 0, "merges": 0, "first_plan_ms": None, "first_commit_ms": None}
     # the roofline kernel is timed with HIP events ATTACHED TO ITS LAUNCH (cdlrm_ctx_time_next_gather -> hipExtLaunchKernel:
-    # the kernel's own start / stop timestamps, no marker packets on the queue).  A timed launch carries a completion signal
+    # timestamps the runtime takes for the launch, no event records around it; 0.5-2 us above the profiler's End - Start of the
+    # same kernel).  A timed launch carries a completion signal
     # and the queue handles it before the next packet: measured on one box, 1500 steps, sampling EVERY launch costs the step
     # 0.007 ms (0.6473 / 0.6464 against 0.6397 / 0.6401 untimed).  So every SECOND launch of the timed region is sampled (10 of
     # the driver's 20 steps); runs beyond 4096 steps keep every --gather-sample'th

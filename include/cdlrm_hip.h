@@ -465,8 +465,9 @@ void* cdlrm_event_create(int32_t timing);
 int cdlrm_event_destroy(void* event);
 int cdlrm_event_elapsed_us(void* start, void* stop, float* us);
 /* Measurement: the NEXT cdlrm_embbag_fwd on this context leaves its start / stop timestamps in the two (timing) events --
- * attached to the launch itself (hipExtLaunchKernel), no marker packets around it -- so bench.py can price the gather
- * (the roofline kernel) live, per launch, without moving it. */
+ * attached to the launch itself (hipExtLaunchKernel), no event records around it -- so bench.py can price the gather
+ * (the roofline kernel) live, per launch.  A timed launch costs its queue ~7 us (completion signal); the elapsed time reads
+ * 0.5-2 us above the profiler's duration of the same kernel. */
 int cdlrm_ctx_time_next_gather(cdlrm_ctx* ctx, void* start_event, void* stop_event);
 
 #ifdef __cplusplus
