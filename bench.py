@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=-1, help="override the config's global batch (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-sample", type=int, default=8, help="time the gather kernel every k-th step")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="keep the GPU busy this long between the warm-up steps and the timed region (0: off)")
     ap.add_argument("--seed", type=int, default=123)
     return ap.parse_args()
 
@@ -331,6 +333,22 @@ def main():
 
     for j in range(a.warmup):
         run_step(j, False)
+    # Clock pre-warm (outside the timed region, no training state touched).  Set-up leaves the GPU idle for most of a second
+    # (host tables, the first plan's CPU row gather) and the part then needs a few hundred ms of load to reach its clocks: measured
+    # with tools/step_ramp.py, the steps right after set-up run 0.665, 0.651, 0.640, 0.632 ... ms per block of five and reach
+    # 0.61-0.62 after ~35 steps, the MFMA-bound GEMMs 8-10 % slower early than late in one kernel trace.  A run of W = 5 warm-up
+    # and K = 20 timed steps (16 ms) would report that ramp, not the training rate: 0.660-0.671 ms without, 0.631-0.643 with
+    # 300 ms of this loop (40 ms: no effect).  The loop runs the step's own forward GEMM kernel on scratch buffers.
+    if a.prewarm_ms > 0:
+        pw_x = torch.randn(8192, 512, device=dev)
+        pw_w = torch.randn(512, 512, device=dev) * 0.04
+        pw_y = torch.empty(8192, 512, device=dev)
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < a.prewarm_ms:
+            for _ in range(64):
+                _ops.linear_fwd(pw_x, pw_w, None, pw_y, 1)
+            torch.cuda.synchronize()
+        del pw_x, pw_w, pw_y
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -384,6 +402,8 @@ def main():
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "dist_backend": dist.get_backend() if dist.is_initialized() else "none (one process, no collectives)",
                        "final_loss": loss, "setup_s": round(setup_s, 1),
+                       # GPU kept busy (scratch GEMMs, no training state) between the W warm-up steps and the timed region
+                       "gpu_prewarm_ms": a.prewarm_ms,
                        "host_issue_ms_per_step": t_issued / a.steps * 1e3,
                        # launch tapes of the step's control paths: replayed by one library call each (native) or from Python
                        "launch_tapes": {"native": sum(1 for t in eng._tapes.values() if t["native"] is not None),

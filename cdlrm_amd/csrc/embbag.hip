@@ -475,8 +475,13 @@ extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t 
     hipStream_t s = (hipStream_t)stream;
     int lpl = pow2ceil(ctx->ways);
     if (lpl > 16) lpl = 16;
-    int64_t gx = cdiv(n, 256 / lpl);
-    if (gx > 8192) gx = 8192;
+    // ~4096 workgroups over all tables, every lane group walking its share four lookups at a time.  (Until round 3 the grid
+    // had one lane group per lookup -- 213 k workgroups for a c3 chunk, three of the four lookups "in flight" clamped dummies:
+    // 403 us per chunk beside the training step against 133 us now; 2048 / 8192 workgroups 162 / 136 us, eight lookups in
+    // flight 138-142 us, sixteen 159-199 us.)
+    int64_t gx = cdiv(n, (int64_t)(256 / lpl) * 4);
+    const int64_t gcap = 4096 / ctx->T > 0 ? 4096 / ctx->T : 1;
+    if (gx > gcap) gx = gcap;
     dim3 grid((unsigned)gx, (unsigned)ctx->T);
 #define PROBE_CALL(L) hipLaunchKernelGGL((k_probe<L, 4>), grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, wslots, ctx->d_err)
     switch (lpl) {
