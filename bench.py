@@ -10,6 +10,10 @@ A "step" is one pass of the hot path over one batch: tag probe -> cached gather 
 -> top MLP -> BCE -> backward -> fused sparse SGD + dense SGD (+ grad all-reduce and periodic cache-row merge at
 N > 1); the wall time of the timed region includes the look-ahead refills (window scan, insert/evict, host row
 prefetch) that fall into it.  Rank 0 prints ONE JSON line.
+
+Between the W warm-up steps and the timed region the GPU is kept busy for --prewarm-ms (default 300 ms, scratch GEMMs, no
+training state; reported as config.gpu_prewarm_ms): the part needs that long under load to reach its clocks after set-up, and a
+short timed region would otherwise report the ramp.  --prewarm-ms 0 switches it off.
 """
 import argparse
 import json
