@@ -475,21 +475,16 @@ extern "C" int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t 
     hipStream_t s = (hipStream_t)stream;
     int lpl = pow2ceil(ctx->ways);
     if (lpl > 16) lpl = 16;
-    // ~512 workgroups over all tables (two per CU), every lane group walking its share four lookups at a time.  Until round 3
-    // the grid had one lane group per lookup -- 213 k workgroups for a c3 chunk, three of the four lookups "in flight" clamped
-    // dummies, launch-rate-bound: 403 us per chunk beside the training step, which lost 0.34-0.45 ms to it.  On 4096 workgroups
-    // the probe takes 133 us (2048 / 8192: 162 / 136; eight / sixteen lookups in flight: 138-142 / 159-199) -- and, queued behind
-    // the step's weight gradients on the prefetch stream, it then lands on the NEXT step's gather, the roofline kernel, which
-    // takes 60-70 us beside it (one launch in sixteen).  Throttled it shares the bandwidth instead (640 steps, one box):
-    //   workgroups   step (ms)   gather mean / p90 / max (us)
-    //      4096       0.6064        33.4 / 44.6 / 70.8
-    //      1024       0.6068        32.3 / 42.7 / 51.2
-    //       512       0.6131        30.9 / 33.9 / 38.5
-    //       256       0.6227        30.8 / 32.8 / 37.0
-    // (placing the resolve behind the interaction forward instead -- its own stream plus an event -- failed on the runtime's
-    //  stream -> hardware-queue multiplexing: every fifth stream tried shared a queue with the weight-gradient stream.)
+    // ~4096 workgroups over all tables, every lane group walking its share four lookups at a time.  Until round 3 the grid had
+    // one lane group per lookup -- 213 k workgroups for a c3 chunk, three of the four lookups "in flight" clamped dummies,
+    // launch-rate-bound: 403 us per chunk beside the training step, which lost 0.34-0.45 ms to it.  On 4096 workgroups the probe
+    // takes 133 us (2048 / 8192: 162 / 136; eight / sixteen lookups in flight: 138-142 / 159-199).  A probe this fast doubles a
+    // gather it runs beside (60-70 us for that launch) -- which is where it landed while it was queued behind the step's weight
+    // gradients on the prefetch stream (one gather in sixteen; throttled to 512 workgroups: gather mean 33.4 -> 30.9 us, 427 us
+    // per chunk); the long-batch step now issues it right behind its interaction forward (TrainEngine._issue_resolve), beside
+    // the top MLP's GEMMs, which leave HBM idle.
     int64_t gx = cdiv(n, (int64_t)(256 / lpl) * 4);
-    const int64_t gcap = 512 / ctx->T > 0 ? 512 / ctx->T : 1;
+    const int64_t gcap = 4096 / ctx->T > 0 ? 4096 / ctx->T : 1;
     if (gx > gcap) gx = gcap;
     dim3 grid((unsigned)gx, (unsigned)ctx->T);
 #define PROBE_CALL(L) hipLaunchKernelGGL((k_probe<L, 4>), grid, dim3(256), 0, s, ctx->d_tab, ctx->ways, ctx->tags, idx, n, ld_idx, wslots, ctx->d_err)

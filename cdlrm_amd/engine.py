@@ -400,41 +400,70 @@ class WindowResolver:
             engine._bufs[key] = [tuple(torch.empty(T * self.CH * self.B, dtype=torch.int32, device=window_idx.device)
                                        for _ in range(2)) for _ in range(self.RING)]
         self._ring = engine._bufs[key]
+        if ("wres_ev",) not in engine._bufs:        # one persistent event per ring slot (a launch tape keeps its handle in a cell)
+            evs = [S.new_event(engine.dev) for _ in range(self.RING)]
+            if S.is_hip(engine.dev):
+                for e in evs:
+                    e.record(S.current_stream(engine.dev))
+            engine._bufs[("wres_ev",)] = evs
+        self._ring_ev = engine._bufs[("wres_ev",)]
+        self._armed = None          # chunk handed to the engine, to be placed by its next step
+        self._started = False       # the first chunks of a window are issued at once (no step of the window is in flight)
         self.ensure(self.CH + 2)
+        self._started = True
 
-    def ensure(self, upto_batch: int):
-        """Issue the resolve of every chunk that holds a batch < upto_batch (prefetch stream; no host wait)."""
-        eng, ctx = self.eng, self.ctx
+    def _long_batch(self) -> bool:
+        """Long local batches on a HIP device with an engine that can place a resolve inside its step: the gather then runs alone
+        on the training queue (the roofline kernel) and a chunk's resolve is worth placing."""
+        eng = self.eng
+        return (hasattr(eng, "_issue_resolve") and S.is_hip(eng.dev) and not eng._side_gather(self.width))
+
+    def _prepare(self, c: int):
+        ctx = self.ctx
+        self.chunks.pop(c - self.RING, None)
+        b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
+        cols = self.idx[:, b0 * self.B:b1 * self.B]
+        w = int(cols.shape[1])
+        ring_ws, ring_src = self._ring[c % self.RING]
+        ws, wsrc = ring_ws[:ctx.T * w].view(ctx.T, w), ring_src[:ctx.T * w].view(ctx.T, w)
+        ev = self._ring_ev[c % self.RING]
+        self.chunks[c] = (ws, wsrc, ev)
+        return dict(cols=cols, lbs=self.lbs, ws=ws, wsrc=wsrc, ev=ev, B=self.B, first=(c == 0))
+
+    def ensure(self, upto_batch: int, urgent: bool = False):
+        """Issue the resolve of every chunk that holds a batch < upto_batch (prefetch stream; no host wait).  Called after every
+        step.  At long batches a chunk that falls due is handed to the engine, whose NEXT step issues it behind its interaction
+        forward (TrainEngine._issue_resolve); urgent (batch() needs the chunk now), the first chunks of a window, short batches
+        and engines without that hook: at once."""
+        eng = self.eng
+        if self._armed is not None:
+            if eng._pending_resolve is None:
+                self._armed = None                      # the step issued since has placed it
+            elif urgent and self._armed * self.CH < int(upto_batch):
+                self._armed = None
+                eng.flush_pending_resolve()             # needed before a step could place it
         nchunks = -(-self.nb // self.CH)
         want = min(nchunks, -(-min(int(upto_batch), self.nb) // self.CH))
-        while self.done < want:
+        while self.done < want and self._armed is None:
             c = self.done
             if c >= self.RING and self.maxj < (c - 2) * self.CH + 1:
                 break               # the slot's previous chunk may still have takes to issue: a later ensure() / batch() issues it
-            self.chunks.pop(c - self.RING, None)
-            b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
-            cols = self.idx[:, b0 * self.B:b1 * self.B]
-            w = int(cols.shape[1])
-            ring_ws, ring_src = self._ring[c % self.RING]
-            ws, wsrc = ring_ws[:ctx.T * w].view(ctx.T, w), ring_src[:ctx.T * w].view(ctx.T, w)
-            pst = eng.pref
-            if self.done == 0:
-                pst.wait_stream(S.current_stream(eng.dev))      # the commit (tags, victims) is on the main stream
-            # the slot's previous chunk (this window's c - 3, or a chunk of the previous window): its takes are all issued,
-            # on the side stream (chained / in-line takes) or on this very stream (two-phase takes: in order)
-            pst.wait_stream(eng.side)
-            with S.on_stream(pst):
-                ops.window_resolve(ctx, cols, self.lbs, ws, wsrc, stream=pst, batch_len=self.B)
-                ev = S.new_event(eng.dev)
-                ev.record(pst)
-            self.chunks[c] = (ws, wsrc, ev)
             self.done += 1
+            pr = self._prepare(c)
+            if not urgent and c > 0 and self._started and self._long_batch() and eng._pending_resolve is None:
+                eng._pending_resolve, eng.mark_next = pr, True
+                self._armed = c
+                break               # one chunk per step
+            if hasattr(eng, "_issue_resolve"):
+                eng._issue_resolve(pr, lambda fn, *a: fn(*a), S.current_stream(eng.dev), placed=False)
+            else:                   # (host-logic tests: a bare engine stand-in)
+                ops.window_resolve(self.ctx, pr["cols"], self.lbs, pr["ws"], pr["wsrc"], stream=eng.pref, batch_len=self.B)
 
     def batch(self, j: int):
         """(wslots view, wsrc view, ready event) of this rank's lookups of batch j of the window."""
         c = j // self.CH
         self.maxj = max(self.maxj, j)
-        self.ensure(j + 1)
+        self.ensure(j + 1, urgent=True)
         ws, wsrc, ev = self.chunks[c]
         col = (j - c * self.CH) * self.B + self.col0
         if c >= 2 and (c - 2) in self.chunks:       # chunks far behind the training position are not needed any more
@@ -492,7 +521,7 @@ class TrainEngine:
         self._emb_done = None
         ne = lambda: S.new_event(self.dev)
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
-                            emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne())
+                            emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne(), fwd_mark=ne(), res_slot=ne())
         if S.is_hip(self.dev):
             # torch creates the HIP event at the first record: give every engine event its handle now (a launch tape stores
             # handles; a wait recorded before the event's first real record would otherwise push that tape back to Python)
@@ -539,6 +568,13 @@ class TrainEngine:
         self.fold_top_wait = True               # short batches: the wait for the deferred top-MLP update rides on the side stream
         self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
         self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
+        # WindowResolver hands the NEXT step a look-ahead chunk to resolve (`_pending_resolve`, taken when `mark_next` is set): the
+        # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
+        # stream --, so the resolve (random 128-B tag reads) runs beside the top MLP's GEMMs, which leave HBM idle, instead of
+        # behind the weight gradients at the end of the step, where it lands on the next step's gather (the roofline kernel)
+        self.mark_next = False
+        self._mark_this = False
+        self._pending_resolve = None
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
     def _flatten_params(self):
@@ -580,6 +616,29 @@ class TrainEngine:
             l.bias.grad = self.gb[l]
             off_b += m
         self.r_width = kp[top0]
+
+    def _issue_resolve(self, pr, rec, main, placed: bool):
+        """One look-ahead chunk's resolve on the prefetch stream (WindowResolver prepares `pr`).  placed: from inside a step,
+        behind its interaction forward (an event recorded on the training queue: one marker packet per chunk, i.e. per 16 steps)."""
+        pst, ev = self.pref, self._events
+        if placed:
+            rec(ev["fwd_mark"].record, main)
+            rec(pst.wait_event, ev["fwd_mark"])
+        elif pr["first"]:
+            pst.wait_stream(main)               # the commit (tags, victims) is on the main stream
+        # the ring slot's previous chunk (this window's c - 3, or a chunk of the previous window): its takes are all issued, on
+        # the side stream (chained / in-line takes) or on this very stream (two-phase takes: in order)
+        rec(ev["res_slot"].record, self.side)
+        rec(pst.wait_event, ev["res_slot"])
+        ops.window_resolve(self.ctx, pr["cols"], pr["lbs"], pr["ws"], pr["wsrc"], stream=pst, batch_len=pr["B"])
+        ops.event_record(pr["ev"], pst)
+
+    def flush_pending_resolve(self):
+        """Issue a handed-over chunk at once (its batches are needed before a step could place it)."""
+        pr, self._pending_resolve = self._pending_resolve, None
+        self.mark_next = False
+        if pr is not None:
+            self._issue_resolve(pr, lambda fn, *a: fn(*a), S.current_stream(self.dev), placed=False)
 
     def _side_gather(self, B: int) -> bool:
         """Short local batches run the gather on the side stream (see _fwd_bwd)."""
@@ -742,6 +801,8 @@ class TrainEngine:
         Returns the device loss buffer (element 0 = the loss, 1 = correct predictions, 2 = loss * batch)."""
         B, n = X.shape[0], lS_i.shape[1]
         self.loss_sync = bool(loss_sync) or not self.fused_head
+        self._mark_this = bool(self.mark_next and self._pending_resolve is not None and lS_o is None)
+        self.mark_next = False
         self._res, self._next_res = res, (next_res if next_idx is not None else None)
         if lS_o is not None:
             assert lS_o.shape[1] in (B, B + 1) and (not self.multi or lS_o.shape[1] == B)
@@ -770,6 +831,8 @@ class TrainEngine:
             sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
             sgd_done = self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
+        if self._mark_this:
+            self._pending_resolve = None        # issued by this step
         # ---- dense gradient exchange + SGD ----
         if self.multi and self.defer_top:
             # two exchanges, issued in the same order on every rank: the top MLP's (its weight gradients were launched
@@ -938,6 +1001,8 @@ class TrainEngine:
             rec(main.wait_event, ev["top_updated"])
         if not self.cat:
             ops.interact_fwd(feat, self.itself, R)
+        if self._mark_this:
+            self._issue_resolve(self._pending_resolve, rec, main, placed=True)
         cur = R
         top_acts = [R]
         fused_head = self.fused_head
@@ -1158,7 +1223,9 @@ class TrainEngine:
                next_idx.stride(0) if nxt else 0,
                (self.iter & 1) if (self.ctx.aux_phases < 2 or self._chain(B, next_idx, None)) else 0,
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
-               self._gslot is not None, self.loss_sync, self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait,
+               self._gslot is not None, self.loss_sync,
+               (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
+               self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
@@ -1183,6 +1250,10 @@ class TrainEngine:
                 cells["nwsrc"] = C.c_void_p(self._next_res[1].data_ptr())
             if self._gslot is not None:
                 cells["g0"], cells["g1"] = C.c_void_p(self._gslot[0].handle), C.c_void_p(self._gslot[1].handle)
+            if self._mark_this:             # the placed resolve's chunk: index columns, ring slot, the slot's event
+                pr = self._pending_resolve
+                cells["rcols"], cells["rws"] = C.c_void_p(pr["cols"].data_ptr()), C.c_void_p(pr["ws"].data_ptr())
+                cells["rwsrc"], cells["rev"] = C.c_void_p(pr["wsrc"].data_ptr()), C.c_void_p(int(pr["ev"].cuda_event))
             by_value = {c.value: c for c in cells.values()}
             if len(by_value) != len(cells):
                 return not self.multi      # aliased inputs: stay on the untaped path
@@ -1222,6 +1293,10 @@ class TrainEngine:
             cells["nwsrc"].value = self._next_res[1].data_ptr()
         if "g0" in cells:
             cells["g0"].value, cells["g1"].value = self._gslot[0].handle, self._gslot[1].handle
+        if "rcols" in cells:
+            pr = self._pending_resolve
+            cells["rcols"].value, cells["rws"].value = pr["cols"].data_ptr(), pr["ws"].data_ptr()
+            cells["rwsrc"].value, cells["rev"].value = pr["wsrc"].data_ptr(), int(pr["ev"].cuda_event)
         bufs = self._buffers(B)
         (bufs["wgrad_split"][0] if bufs["wgrad_split"] is not None else bufs["wgrad"]).set_x(0, X)
         if tape["native"] is not None:

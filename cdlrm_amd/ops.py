@@ -166,6 +166,13 @@ def event_attach_next(event: "torch.cuda.Event", stream):
     check(_lib.lib().cdlrm_event_attach_next(int(h), stream.cuda_stream))
 
 
+def event_record(event: "torch.cuda.Event", stream):
+    """event.record(stream) as a library call (the handle is an argument a launch tape can keep in a cell)."""
+    h = event.cuda_event
+    assert h, "record the event once through torch first (it creates the HIP event lazily)"
+    check(_lib.lib().cdlrm_event_record(int(h), stream.cuda_stream))
+
+
 def time_next_gather(ctx: CacheCtx, start: TimingEvent, stop: TimingEvent):
     """The next embbag_fwd on this context leaves its own start / stop timestamps in the two events (attached to the
     launch: nothing is added to the queue)."""

@@ -282,7 +282,72 @@ def test_window_resolver_ring_never_recycles_a_live_chunk(monkeypatch, CH, nb, s
             assert issued[c][0] == issued[c % 3][0]     # ... and it is the ring slot, not a new allocation
         seen_issue = len(issued)
     assert len(issued) == -(-nb // CH)
-    assert len(eng._bufs) == 1
+    assert set(eng._bufs) == {("wres", CH * B), ("wres_ev",)}      # one ring of buffers, one ring of events: nothing per chunk
+
+
+def test_window_resolver_hands_due_chunks_to_the_next_step(monkeypatch):
+    """Long batches: a chunk that falls due is handed to the engine (`_pending_resolve` + `mark_next`) and issued by the NEXT
+    step behind its interaction forward, one chunk per step; the first chunks of a window and a chunk whose batches are
+    asked for before a step could place it are issued at once.  Host-side protocol with an engine stand-in (no GPU)."""
+    import cdlrm_amd.engine as engine
+    S = engine.S
+    monkeypatch.setattr(S, "is_hip", lambda dev: True)
+    monkeypatch.setattr(S, "new_event", lambda dev, timing=False: S._NullEvent())
+    monkeypatch.setattr(S, "current_stream", lambda dev: S._NullStream())
+    log = []
+
+    class Ctx:
+        T = 2
+
+    class Eng:
+        ctx, world, rank, dev = Ctx(), 1, 0, torch.device("cpu")
+        pref = side = S._NullStream()
+
+        def __init__(self):
+            self._bufs, self._pending_resolve, self.mark_next = {}, None, False
+
+        def _side_gather(self, B):
+            return False
+
+        def _issue_resolve(self, pr, rec, main, placed):
+            log.append(("placed" if placed else "now", pr["cols"].data_ptr()))
+
+        def flush_pending_resolve(self):
+            pr, self._pending_resolve, self.mark_next = self._pending_resolve, None, False
+            self._issue_resolve(pr, None, None, placed=False)
+
+        def step(self):                     # what TrainEngine.step does with the hand-over
+            if self.mark_next and self._pending_resolve is not None:
+                self._issue_resolve(self._pending_resolve, None, None, placed=True)
+                self._pending_resolve = None
+            self.mark_next = False
+
+    B, CH, nb = 8, 4, 40
+    win = torch.zeros(2, nb * B, dtype=torch.int64)
+    first_col = lambda c: win[:, c * CH * B:].data_ptr()
+    eng = Eng()
+    rs = engine.WindowResolver(eng, win, B, chunk=CH)
+    assert log == [("now", first_col(0)), ("now", first_col(1))]        # window start: at once
+    for j in range(nb - 1):
+        before = len(log)
+        r0, r1 = rs.batch(j), rs.batch(j + 1)
+        assert len(log) == before, "nothing is issued while the batches of resolved chunks are handed out"
+        eng.step()
+        placed = log[before:]
+        assert len(placed) <= 1 and all(kind == "placed" for kind, _ in placed)
+        rs.ensure(j + rs.CH + 2)
+        assert len(log) == before + len(placed), "a due chunk waits for the next step"
+        assert r0[0].shape == r1[0].shape == (2, B)
+    assert [p for _, p in log] == [first_col(c) for c in range(nb // CH)]
+    assert sum(kind == "placed" for kind, _ in log) == nb // CH - 2
+    # a chunk asked for before any step ran: flushed at once
+    log.clear()
+    eng2 = Eng()
+    rs2 = engine.WindowResolver(eng2, win, B, chunk=CH)
+    rs2.ensure(3 * CH)                      # chunk 2 falls due: handed over
+    assert eng2._pending_resolve is not None and len(log) == 2
+    rs2.batch(2 * CH)                       # ... and needed now
+    assert eng2._pending_resolve is None and log[-1] == ("now", first_col(2))
 
 
 def test_tape_registry_matches_the_ctypes_prototypes(built_lib):
