@@ -408,6 +408,9 @@ class WindowResolver:
             engine._bufs[("wres_ev",)] = evs
         self._ring_ev = engine._bufs[("wres_ev",)]
         self._armed = None          # chunk handed to the engine, to be placed by its next step
+        if getattr(engine, "_pending_resolve", None) is not None:
+            # a chunk of the window this one replaces that no step has placed: its ring slot belongs to this window now
+            engine._pending_resolve, engine.mark_next = None, False
         self._started = False       # the first chunks of a window are issued at once (no step of the window is in flight)
         self.ensure(self.CH + 2)
         self._started = True
