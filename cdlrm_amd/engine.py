@@ -634,7 +634,10 @@ class TrainEngine:
         rec(ev["res_slot"].record, self.side)
         rec(pst.wait_event, ev["res_slot"])
         ops.window_resolve(self.ctx, pr["cols"], pr["lbs"], pr["ws"], pr["wsrc"], stream=pst, batch_len=pr["B"])
-        ops.event_record(pr["ev"], pst)
+        if S.is_hip(self.dev):
+            ops.event_record(pr["ev"], pst)       # (a library call: on a launch tape the slot's event handle is a cell)
+        else:
+            pr["ev"].record(pst)
 
     def flush_pending_resolve(self):
         """Issue a handed-over chunk at once (its batches are needed before a step could place it)."""
