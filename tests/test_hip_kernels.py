@@ -523,7 +523,10 @@ def test_fused_activation_backward_chain(ops, M):
 
 @pytest.mark.parametrize("B,F,D,itself,pad", [(3000, 27, 128, 0, 1), (2049, 9, 32, 1, 3), (700, 32, 64, 0, 0),
                                                (5000, 27, 128, 1, 2), (33, 27, 256, 0, 1), (257, 4, 16, 0, 0),
-                                               (1, 27, 128, 0, 1)])
+                                               (1, 27, 128, 0, 1),
+                                               # slab kernels with several samples per wave at the other widths; a row pitch
+                                               # that is no multiple of 4 (whole-row forward, generic backward)
+                                               (2100, 27, 256, 1, 3), (4100, 20, 32, 0, 2), (300, 27, 128, 0, 0)])
 def test_interaction_kernels_vs_torch(ops, B, F, D, itself, pad):
     """Pairwise-dot interaction forward/backward (software-pipelined kernels for D = 32/64/128/256, generic otherwise)
     against torch autograd on the oracle's interact_features; R/dR with a padded row pitch as the engine uses."""
