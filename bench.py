@@ -181,16 +181,29 @@ def pct(xs, q):
 
 def main():
     a = parse()
+    from cdlrm_amd import launch
+    if a.gpus > 1 and not launch.under_launcher():
+        # `python bench.py --gpus N` as typed: this process -- before its first HIP call -- starts the N ranks as children
+        # (one process per GPU under torch.distributed.run, what the reference's mp.spawn does, main_no_ddp.py:638-643),
+        # rank 0 prints the JSON line on the inherited stdout, and the children's return code is this process's
+        raise SystemExit(launch.spawn_ranks(a.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if world != a.gpus:
+        raise SystemExit("ERROR: --gpus %d does not match the launcher's WORLD_SIZE %d" % (a.gpus, world))
     # development: CDLRM_BENCH_EMULATE=1 runs the N ranks on ONE GPU with gloo collectives (RCCL cannot place two ranks
     # on a device) -- exercises the whole multi-rank path on a 1-GPU box; its numbers mean nothing
-    emulate = os.environ.get("CDLRM_BENCH_EMULATE", "0") == "1"
+    from cdlrm_amd import _lib
+    try:
+        _lib.require_gpu("bench.py")
+    except _lib.CdlrmLibraryError as e:
+        raise SystemExit("ERROR: " + str(e))
+    emulate = launch.emulated()
     if emulate:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit("ERROR: --gpus %d, but this node has %d GPUs (one process per GPU)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -199,6 +212,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    launch.check_world(a.gpus)      # an --gpus N line is only ever printed by N ranks
 
     def barrier():
         if world > 1:
@@ -220,7 +234,12 @@ def main():
     # compete for CUs the critical path goes first (c3: 0.685 -> 0.673 ms); the side work has slack until the next step
     torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 
-    total_steps = a.warmup + a.steps
+    # With a clock pre-warm the line also carries what the same steps cost WITHOUT it: a bounded pass of cold steps (at most 50,
+    # timed with its own barriers, reported as config.ms_per_step_before_prewarm) runs between the warm-up and the pre-warm.
+    # It is extra warm-up as far as the timed region is concerned: the K timed steps follow the pre-warm, exactly K of them.
+    cold_steps = min(a.steps, 50) if a.prewarm_ms > 0 else 0
+    t_start = a.warmup + cold_steps
+    total_steps = t_start + a.steps
     # The synthetic index stream is the input: generate it BEFORE the timed region (windows of L batches, int64
     # [T, L*B] each = 5.1 GB at c3) so that the timed steps see inputs already resident in HBM, as a real loader
     # thread would leave them.  Beyond the memory budget the windows are generated on the fly (inside the timing).
@@ -263,7 +282,7 @@ def main():
     # the events exist before the timed region starts; their handles are cells of the engine's launch tape
     from cdlrm_amd import ops as _ops
     ev_pool = {j: (_ops.TimingEvent(), _ops.TimingEvent())
-               for j in range(a.warmup, total_steps) if a.gather_sample > 0 and j % sample_every == 0}
+               for j in range(t_start, total_steps) if a.gather_sample > 0 and j % sample_every == 0}
     warm_pair = (_ops.TimingEvent(), _ops.TimingEvent())
 
     def begin_window(w, timed):
@@ -284,8 +303,11 @@ def main():
             refills["first_commit_ms"] = (time.perf_counter() - t_c) * 1e3
         if timed:
             refills["commits"] += 1
-        if pipe.breakdown is not None:      # where this window's plan spent its time (first window: planned stand-alone)
-            refills["breakdown_first" if "breakdown_first" not in refills else "breakdown_last"] = dict(pipe.breakdown)
+        # where this window's plan spent its time (first window: planned stand-alone); resolved after the timed region -- reading
+        # the DMA timing events waits for them
+        bd = pipe.breakdown_deferred()
+        if bd is not None:
+            refills["breakdown_first" if "breakdown_first" not in refills else "breakdown_last"] = bd
         state["win"], state["next"], state["w"] = state["next"], None, w
         # window-resident probe: the window's lookups are resolved against the new tags once, in chunks ahead of the
         # training position (streamed windows: per chunk, when the chunk is loaded)
@@ -337,6 +359,16 @@ def main():
 
     for j in range(a.warmup):
         run_step(j, False)
+    cold_ms = None
+    if cold_steps:
+        torch.cuda.synchronize()
+        barrier()
+        t_c0 = time.perf_counter()
+        for j in range(a.warmup, t_start):
+            run_step(j, False)
+        torch.cuda.synchronize()
+        barrier()
+        cold_ms = (time.perf_counter() - t_c0) / cold_steps * 1e3
     # Clock pre-warm (outside the timed region, no training state touched).  Set-up leaves the GPU idle for most of a second
     # (host tables, the first plan's CPU row gather) and the part then needs a few hundred ms of load to reach its clocks: measured
     # with tools/step_ramp.py, the steps right after set-up run 0.665, 0.651, 0.640, 0.632 ... ms per block of five and reach
@@ -357,7 +389,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for j in range(a.warmup, total_steps):
+    for j in range(t_start, total_steps):
         run_step(j, True)
     t_issued = time.perf_counter() - t0        # host time to ISSUE the steps (== dt when the host is the bottleneck)
     torch.cuda.synchronize()
@@ -408,6 +440,11 @@ def main():
                        "final_loss": loss, "setup_s": round(setup_s, 1),
                        # GPU kept busy (scratch GEMMs, no training state) between the W warm-up steps and the timed region
                        "gpu_prewarm_ms": a.prewarm_ms,
+                       # the same step right after the warm-up, BEFORE the pre-warm (rank 0's clock over a bounded pass of
+                       # untimed extra steps; null with --prewarm-ms 0, where the headline itself is that number)
+                       "ms_per_step_before_prewarm": cold_ms, "steps_before_prewarm": cold_steps,
+                       # hardware queues the HIP runtime of this process may use (the step schedule is tuned for 4)
+                       "gpu_max_hw_queues": _lib.hw_queues(),
                        "host_issue_ms_per_step": t_issued / a.steps * 1e3,
                        # launch tapes of the step's control paths: replayed by one library call each (native) or from Python
                        "launch_tapes": {"native": sum(1 for t in eng._tapes.values() if t["native"] is not None),
@@ -424,10 +461,10 @@ def main():
                                        # the stand-alone plan itemised (ms): GPU half (window scan, tag probe, way choice,
                                        # victim list), list copies to the host, first-touch allocation of the pinned staging
                                        # (first window only), CPU-thread row gather, DMA copies; `rows` = list lengths
-                                       "plan_breakdown_ms": refills.get("breakdown_first"),
+                                       "plan_breakdown_ms": pipe.resolve_breakdown(refills.get("breakdown_first")),
                                        # ... and of the last plan that ran in the background of the timed steps (steady state:
                                        # staging already pinned; its GPU half shares the device with the training step)
-                                       "plan_breakdown_ms_background": refills.get("breakdown_last"),
+                                       "plan_breakdown_ms_background": pipe.resolve_breakdown(refills.get("breakdown_last")),
                                        "commit_ms": refills["first_commit_ms"],
                                        "commit_ms_per_step_amortised": (refills["first_commit_ms"] / L)
                                        if refills["first_commit_ms"] is not None else None}},

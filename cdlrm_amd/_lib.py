@@ -112,6 +112,10 @@ PROTOTYPES = {
     "cdlrm_tape_add": (C.c_int, [vp, vp, c_i32, vp, vp, c_i32, vp]),
     "cdlrm_tape_cells": (vp, [vp]),
     "cdlrm_tape_length": (c_i64, [vp]),
+    "cdlrm_tape_stream_arg": (c_i32, [vp]),
+    "cdlrm_tape_probe": (C.c_int, [c_f32, c_i64, c_f32, c_i32, vp, c_i64, c_f32, c_i32, c_i64, c_i64, vp, c_i32, c_f32, c_i64]),
+    "cdlrm_tape_probe_log": (C.c_int, [c_i64, c_i64]),
+    "cdlrm_tape_probe_log_take": (c_i64, [vp, c_i64]),
     "cdlrm_tape_replay": (C.c_int, [vp]),
     "cdlrm_tape_set_lanes": (C.c_int, [vp, vp, vp, c_i64]),
     "cdlrm_tape_selftest": (C.c_int, []),
@@ -206,6 +210,42 @@ def lib():
     return _proxy
 
 
+def require_gpu(what: str = "cdlrm_amd") -> None:
+    """The cached training path has no CPU fallback: say so, instead of a torch traceback from the first device call."""
+    import torch
+    if not torch.cuda.is_available():
+        raise CdlrmLibraryError(
+            "%s needs a HIP device (MI355X / gfx950) and found none: cdlrm_amd has no CPU fallback for the cached training "
+            "path -- every compute entry point is a hand-written HIP kernel behind csrc/libcdlrm_hip.so" % what)
+
+
+HW_QUEUES_TUNED = 4
+
+
+def hw_queues() -> int:
+    """GPU_MAX_HW_QUEUES as the HIP runtime of this process read it (its default is 4)."""
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", str(HW_QUEUES_TUNED)))
+    except ValueError:
+        return -1
+
+
+_warned_queues = False
+
+
+def warn_hw_queues() -> None:
+    """The training step's five streams are scheduled for the runtime's default of 4 hardware queues per process (with 6 or
+    8 the c3 step measured 1.39-1.42 ms instead of 0.79).  bench.py and the CLI pin the variable before
+    HIP starts; a caller that imports cdlrm_amd with another value gets a warning, once."""
+    global _warned_queues
+    if not _warned_queues and hw_queues() != HW_QUEUES_TUNED:
+        _warned_queues = True
+        import warnings
+        warnings.warn("GPU_MAX_HW_QUEUES=%s: cdlrm_amd's step schedule is tuned for %d hardware queues per process (set "
+                      "GPU_MAX_HW_QUEUES=%d before the first HIP call)"
+                      % (os.environ.get("GPU_MAX_HW_QUEUES"), HW_QUEUES_TUNED, HW_QUEUES_TUNED), RuntimeWarning, stacklevel=3)
+
+
 class TapeUnsupported(Exception):
     """A recorded call the native tape cannot hold (the engine then replays that step's tape from Python)."""
 
@@ -236,6 +276,7 @@ class NativeTape:
         L = raw()
         order = list(cells.values())
         index = {id(c): i for i, c in enumerate(order)}
+        self._cell_ids = set(index)
         self._cells_py = order
         self._keep = []                          # torch events created for wait_stream: must outlive the tape
         h = L.cdlrm_tape_create(len(order))
@@ -279,17 +320,31 @@ class NativeTape:
     def _set_lanes(self, L, ops, main_stream: int, max_lanes: int) -> int:
         """Split the recorded ops by stream and order the lanes on every event both of them touch."""
         names = [getattr(fn, "__name__", "") for fn, _ in ops]
-        val = lambda a: (a.value or 0) if isinstance(a, C._SimpleCData) else (0 if a is None else a)
+
+        def val(a, what):
+            # Lanes and cross-lane dependencies are fixed at build time.  A STREAM that is patched per replay (a cell) would be
+            # laned by whatever handle it held when the step was recorded: refused.  An EVENT cell (the resolver's ring-slot
+            # event) is keyed by the cell itself and accepted only if every op that names it ends up in ONE lane, where program
+            # order orders its touches (checked below).
+            if isinstance(a, C.c_void_p) and id(a) in self._cell_ids:
+                if what == "stream":
+                    raise TapeUnsupported("a stream argument that is a per-step cell cannot be assigned to a lane")
+                return ("cell", id(a))
+            return int((a.value or 0) if isinstance(a, C._SimpleCData) else (0 if a is None else a))
+
         streams, events = [], []
         for (fn, args), name in zip(ops, names):
+            # where the stream sits in the parameter list is the library's knowledge (csrc/tape.hip: tape_registry), not a guess
+            pos = int(L.cdlrm_tape_stream_arg(C.cast(fn, C.c_void_p)))
+            if pos == -2:
+                raise TapeUnsupported("%s is not a registered tape entry point" % name)
+            streams.append(val(args[pos], "stream") if pos >= 0 else None)     # (None: the call issues nothing itself)
             if name == "cdlrm_stream_wait_event":
-                streams.append(int(val(args[0]))); events.append(int(val(args[1])))
+                events.append(val(args[1], "event"))
             elif name in ("cdlrm_event_record", "cdlrm_event_attach_next"):
-                streams.append(int(val(args[1]))); events.append(int(val(args[0])))
-            elif name == "cdlrm_ctx_time_next_gather":      # no stream of its own: it arms the NEXT gather launch
-                streams.append(None); events.append(None)
+                events.append(val(args[0], "event"))
             else:
-                streams.append(int(val(args[-1]))); events.append(None)     # kernel entry points: the stream is the last argument
+                events.append(None)
         lane_of = {main_stream: 0}
         for st in streams:                      # lanes in order of appearance; the last lane takes every further stream
             if st is not None and st not in lane_of:
@@ -305,6 +360,8 @@ class NativeTape:
             e = events[k]
             if e is None:
                 continue
+            if isinstance(e, tuple) and e in last and lane[last[e]] != lane[k]:
+                raise TapeUnsupported("an event that is a per-step cell is touched from two lanes")
             if e in last and lane[last[e]] != lane[k]:
                 dep[k] = last[e]
             last[e] = k

@@ -80,27 +80,44 @@ void cdlrm_set_error(const char* fmt, ...);
 // the kernel it is meant to follow, the same event completes with that kernel and costs the queue nothing.  The pending
 // event is per host thread (the thread that issues the launch); a launch site that can carry it takes it with
 // cdlrm_take_stop_event, an entry point that could not place it records it the ordinary way before it returns.
-extern thread_local hipEvent_t cdlrm_pending_stop_event;
-extern thread_local hipStream_t cdlrm_pending_stop_stream;
+// Only the two entry points the engine attaches events to (cdlrm_linear_bwd, cdlrm_interact_bwd) open a CdlrmStopScope; a
+// launch site takes the pending event only inside such a scope, and the scope's destructor -- i.e. EVERY exit path of the
+// entry point: B == 0, a failed requirement, a failed launch -- records whatever is still pending, so an event can neither be
+// dropped nor ride on a later, unrelated GEMM of the thread (cdlrm_linear_fwd / cdlrm_mlp_wgrad share the launch sites).
+#define CDLRM_HIDDEN __attribute__((visibility("hidden")))
+extern CDLRM_HIDDEN thread_local hipEvent_t cdlrm_pending_stop_event;
+extern CDLRM_HIDDEN thread_local hipStream_t cdlrm_pending_stop_stream;
+extern CDLRM_HIDDEN thread_local int cdlrm_stop_scope_depth;
 static inline hipEvent_t cdlrm_take_stop_event(hipStream_t s) {
     hipEvent_t e = cdlrm_pending_stop_event;
-    if (e && cdlrm_pending_stop_stream == s) {
+    if (e && cdlrm_stop_scope_depth > 0 && cdlrm_pending_stop_stream == s) {
         cdlrm_pending_stop_event = nullptr;
         return e;
     }
     return nullptr;
 }
+struct CdlrmStopScope {
+    hipEvent_t held = nullptr;
+    hipStream_t held_stream = nullptr;
+    CdlrmStopScope() { ++cdlrm_stop_scope_depth; }
+    // a call with several launches: keep the event away from them, it is recorded behind the last one (on exit)
+    void hold(hipStream_t s) {
+        held = cdlrm_take_stop_event(s);
+        held_stream = s;
+    }
+    ~CdlrmStopScope() {
+        if (held) (void)hipEventRecord(held, held_stream);
+        if (--cdlrm_stop_scope_depth == 0 && cdlrm_pending_stop_event) {      // no launch carried it
+            (void)hipEventRecord(cdlrm_pending_stop_event, cdlrm_pending_stop_stream);
+            cdlrm_pending_stop_event = nullptr;
+        }
+    }
+};
 #define CDLRM_LAUNCH_EV(kernel, grid, block, lds, stream, ...)                                                     \
     do {                                                                                                           \
         hipEvent_t se__ = cdlrm_take_stop_event(stream);                                                           \
         if (se__) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, se__, 0, __VA_ARGS__);          \
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                    \
-    } while (0)
-// an entry point's last word: an event its launches could not carry is recorded behind them
-#define CDLRM_FLUSH_STOP_EVENT(stream)                                                                             \
-    do {                                                                                                           \
-        hipEvent_t se__ = cdlrm_take_stop_event((hipStream_t)(stream));                                            \
-        if (se__) CDLRM_HIP_CHECK(hipEventRecord(se__, (hipStream_t)(stream)));                                    \
     } while (0)
 // hipGetLastError() is sticky per host thread: an error some OTHER caller of the runtime left behind (the host
 // framework probes pointers and events with calls that are allowed to fail) would be reported by our next launch

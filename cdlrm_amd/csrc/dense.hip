@@ -210,6 +210,7 @@ extern "C" uint64_t cdlrm_mlp_wgrad_work_bytes(int32_t n_layers, int64_t M, cons
 extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, const float* Y, int64_t ld_y, float* dY,
                                 int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db, int64_t M, int32_t N,
                                 int32_t K, int32_t act, int32_t x_act, void* work, void* stream) {
+    CdlrmStopScope stop_scope;          // (first: every exit below flushes an attached completion event)
     CDLRM_REQUIRE(X && W && dY && work && M >= 1 && N >= 1 && K >= 1, "bad argument");
     CDLRM_REQUIRE(dW || !db, "db without dW (the bias gradient is a by-product of the weight-gradient GEMM)");
     CDLRM_REQUIRE(act == 0 || Y, "activation backward needs Y");
@@ -218,7 +219,7 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
     hipStream_t s = (hipStream_t)stream;
     // a completion event waiting for this call (cdlrm_event_attach_next) rides on the dgrad GEMM when that is the call's only
     // launch (the training step's use); with several launches it is recorded behind the last one
-    hipEvent_t held = (act != 0 || dW || !dX) ? cdlrm_take_stop_event(s) : nullptr;
+    if (act != 0 || dW || !dX) stop_scope.hold(s);
     const int splits = wgrad_splits(M, N, K);
     float* slabs = (float*)work;
     float* cs = (float*)((char*)work + ((((uint64_t)splits * N * K * 4) + 255) & ~(uint64_t)255));
@@ -259,9 +260,7 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
         }
     }
     CDLRM_LAUNCH_CHECK();
-    if (held) CDLRM_HIP_CHECK(hipEventRecord(held, s));
-    CDLRM_FLUSH_STOP_EVENT(s);          // (a GEMM path without the plumbing)
-    return 0;
+    return 0;                           // (stop_scope records an event no launch carried)
 }
 
 // Weight (and bias) gradients of SEVERAL layers at once, from the pre-activation gradients dZ[i] that the dgrad chain
@@ -1068,6 +1067,7 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
 
 extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F, int32_t D,
                                   int32_t itself, int32_t x_act, float* dfeat, void* stream) {
+    CdlrmStopScope stop_scope;          // (first: every exit below flushes an attached completion event)
     CDLRM_REQUIRE(feat && dR && dfeat && F >= 1 && F <= 32 && D >= 4 && D % 4 == 0 && D <= 512, "unsupported shape");
     CDLRM_REQUIRE(aligned16(feat), "alignment");
     if (B == 0) return 0;
@@ -1096,7 +1096,6 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         else IBWD_S(64, s256);
 #undef IBWD_S
         CDLRM_LAUNCH_CHECK();
-        CDLRM_FLUSH_STOP_EVENT(stream);
         return 0;
     }
     if ((D == 32 || D == 64 || D == 128) && vec_in) {
@@ -1117,7 +1116,6 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         else IBWD(32, b128);
 #undef IBWD
         CDLRM_LAUNCH_CHECK();
-        CDLRM_FLUSH_STOP_EVENT(stream);
         return 0;
     }
     const size_t lds = (size_t)4 * (32 * (D + 1) + 32 + ((npairs + 3) & ~3)) * sizeof(float);
@@ -1132,7 +1130,6 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     hipLaunchKernelGGL(k_interact_bwd, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, feat, dR, ld_r, B, F, D,
                        itself, x_act, dfeat);
     CDLRM_LAUNCH_CHECK();
-    CDLRM_FLUSH_STOP_EVENT(stream);
     return 0;
 }
 

@@ -59,6 +59,7 @@ struct TapeEntry {
     tape_invoke_fn invoke;
     int32_t n_int, n_flt;
     const char* name;
+    int32_t stream_arg;     // position (in the full parameter list) of the hipStream_t the call issues on; -1: none
 };
 
 template <typename R, typename... A>
@@ -67,14 +68,32 @@ static TapeEntry tape_entry(R (*f)(A...), const char* name) {
     constexpr int n_flt = (0 + ... + (std::is_floating_point<A>::value ? 1 : 0));
     constexpr int n_int = (int)sizeof...(A) - n_flt;
     static_assert(n_int <= TAPE_MAX_INT && n_flt <= TAPE_MAX_FLT, "too many arguments for a tape call");
-    return TapeEntry{reinterpret_cast<void*>(f), &tape_invoke<R, A...>, n_int, n_flt, name};
+    return TapeEntry{reinterpret_cast<void*>(f), &tape_invoke<R, A...>, n_int, n_flt, name, -1};
+}
+// the library's convention: a launching entry point takes its stream as the LAST parameter (void*)
+template <typename... A> struct tape_last_is_ptr : std::false_type {};
+template <typename A0> struct tape_last_is_ptr<A0> : std::is_same<A0, void*> {};
+template <typename A0, typename... A> struct tape_last_is_ptr<A0, A...> : tape_last_is_ptr<A...> {};
+template <typename R, typename... A>
+static TapeEntry tape_entry_s(R (*f)(A...), const char* name) {
+    static_assert(tape_last_is_ptr<A...>::value, "a launching entry point ends on its stream (void*)");
+    TapeEntry e = tape_entry(f, name);
+    e.stream_arg = (int32_t)sizeof...(A) - 1;
+    return e;
+}
+template <typename R, typename... A>
+static TapeEntry tape_entry_at(R (*f)(A...), const char* name, int32_t stream_arg) {
+    TapeEntry e = tape_entry(f, name);
+    e.stream_arg = stream_arg;
+    return e;
 }
 
 extern "C" int cdlrm_tape_probe(float f0, int64_t a0, float f1, int32_t a1, void* a2, int64_t a3, float f2, int32_t a4,
                                 int64_t a5, int64_t a6, void* a7, int32_t a8, float f3, int64_t a9);
 extern "C" int cdlrm_tape_probe_log(int64_t tag, int64_t spin);
 
-#define TAPE_FN(f) tape_entry(&f, #f)
+#define TAPE_FN(f) tape_entry_s(&f, #f)                 /* issues on the stream its last parameter names */
+#define TAPE_FN_AT(f, pos) tape_entry_at(&f, #f, pos)   /* stream at that parameter position; -1: the call issues nothing */
 // every entry point a recorded training / evaluation step can issue (engine.py: _fwd_bwd, step, evaluate)
 static const std::vector<TapeEntry>& tape_registry() {
     static const std::vector<TapeEntry> reg = {
@@ -83,12 +102,15 @@ static const std::vector<TapeEntry>& tape_registry() {
         TAPE_FN(cdlrm_mark_rows), TAPE_FN(cdlrm_interact_fwd), TAPE_FN(cdlrm_interact_bwd), TAPE_FN(cdlrm_linear_fwd),
         TAPE_FN(cdlrm_linear_bwd), TAPE_FN(cdlrm_mlp_wgrad), TAPE_FN(cdlrm_mlp_wgrad_sgd), TAPE_FN(cdlrm_bce_fwd_bwd),
         TAPE_FN(cdlrm_loss_fwd_bwd), TAPE_FN(cdlrm_head_fwd_bwd), TAPE_FN(cdlrm_head_finish), TAPE_FN(cdlrm_act_bwd),
-        TAPE_FN(cdlrm_sgd_step), TAPE_FN(cdlrm_sgd_step2), TAPE_FN(cdlrm_scale_div), TAPE_FN(cdlrm_ctx_time_next_gather),
-        TAPE_FN(cdlrm_event_record), TAPE_FN(cdlrm_stream_wait_event), TAPE_FN(cdlrm_event_attach_next), TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather),
-        TAPE_FN(cdlrm_agg_scatter), TAPE_FN(cdlrm_tape_probe), TAPE_FN(cdlrm_tape_probe_log),
+        TAPE_FN(cdlrm_sgd_step), TAPE_FN(cdlrm_sgd_step2), TAPE_FN(cdlrm_scale_div),
+        TAPE_FN_AT(cdlrm_ctx_time_next_gather, -1),      // arms the NEXT gather launch: no stream of its own
+        TAPE_FN_AT(cdlrm_event_record, 1), TAPE_FN_AT(cdlrm_stream_wait_event, 0), TAPE_FN_AT(cdlrm_event_attach_next, 1),
+        TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather), TAPE_FN(cdlrm_agg_scatter),
+        TAPE_FN_AT(cdlrm_tape_probe, -1), TAPE_FN_AT(cdlrm_tape_probe_log, -1),
     };
     return reg;
 }
+#undef TAPE_FN_AT
 #undef TAPE_FN
 
 struct TapeOp {
@@ -157,6 +179,13 @@ extern "C" int64_t* cdlrm_tape_cells(cdlrm_tape* t) { return t ? t->cells.data()
 
 extern "C" int64_t cdlrm_tape_length(cdlrm_tape* t) { return t ? (int64_t)t->ops.size() : -1; }
 
+// position of the stream parameter of a registered entry point (-1: the call issues nothing itself, -2: not registered)
+extern "C" int32_t cdlrm_tape_stream_arg(void* fn) {
+    for (const TapeEntry& e : tape_registry())
+        if (e.fn == fn) return e.stream_arg;
+    return -2;
+}
+
 // ---- multi-lane replay -------------------------------------------------------------------------------------------------
 // At a per-rank batch of 1024 a step is ~45 runtime calls of ~4.5 us of HOST time each: the thread that issues them, not
 // the GPU, sets the step time (0.20 ms of issue against ~0.17 ms of dependent GPU work).  A tape can therefore be split by
@@ -208,9 +237,12 @@ struct TapeHelper {
                 // going to sleep: announce it, THEN look for a job once more (sequentially consistent on both sides: the
                 // submitter publishes the job, THEN looks at `sleeping` -- one of the two always sees the other; the bounded
                 // wait is a second line of defence, not the mechanism)
+                // An idle helper stays asleep: it re-checks for a job every 5 ms (the second line of defence) WITHOUT going back
+                // to the spin phase -- a process that replayed a multi-lane tape once would otherwise keep up to three threads
+                // spinning ~25 % of a core each through evaluate(), save and the CPU baseline.  Only a job restarts the spin.
                 std::unique_lock<std::mutex> lk(m);
                 sleeping.store(1, std::memory_order_seq_cst);
-                if (!job.load(std::memory_order_seq_cst)) cv.wait_for(lk, std::chrono::milliseconds(5));
+                while (!job.load(std::memory_order_seq_cst)) cv.wait_for(lk, std::chrono::milliseconds(5));
                 sleeping.store(0, std::memory_order_seq_cst);
                 idle = 0;
                 continue;
@@ -298,8 +330,9 @@ extern "C" int cdlrm_event_record(void* event, void* stream) {
     return 0;
 }
 
-thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
-thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
+CDLRM_HIDDEN thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
+CDLRM_HIDDEN thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
+CDLRM_HIDDEN thread_local int cdlrm_stop_scope_depth = 0;
 
 // `event` completes with the NEXT kernel this thread launches on `stream` through cdlrm_linear_bwd or cdlrm_interact_bwd
 // (attached to the launch as its stop event: no marker packet on the queue); where that call cannot attach it -- a kernel

@@ -129,8 +129,27 @@ class WindowPipeline:
         # where the last host-gather plan's time went (ms, host clock of the plan thread; `dma` from events at commit()):
         # the GPU half (window scan, tag probe, way choice, victim list), list copies to the host, first-touch allocation of
         # pinned staging (first window only, or when a list outgrows it), the CPU threads' row gather, the DMA copies
-        self.breakdown = None
+        self._breakdown = None
         self._bd = None
+
+    @property
+    def breakdown(self):
+        """Itemised cost of the last committed host-gather plan (None before the first).  Reading it waits for that plan's
+        DMA copies (instrumentation: commit() itself never blocks the host for it)."""
+        return self.resolve_breakdown(self._breakdown)
+
+    def breakdown_deferred(self):
+        """The same record WITHOUT waiting for anything: hand it to resolve_breakdown() later (bench.py: after the timed region)."""
+        return self._breakdown
+
+    @staticmethod
+    def resolve_breakdown(bd):
+        if bd is not None and "_dma_events" in bd:
+            evs = bd.pop("_dma_events")
+            if evs and isinstance(evs[0][0], torch.cuda.Event):
+                evs[-1][1].synchronize()
+                bd["dma"] = float(sum(a.elapsed_time(b) for a, b in evs))
+        return bd
 
     def _pinned(self, key, shape, dtype):
         t = self._pin.get(key)
@@ -305,14 +324,9 @@ class WindowPipeline:
         assert self.planned is not None, "plan_window() first"
         main.wait_event(self.planned)
         if self._bd is not None:
-            # the DMA copies' own duration (timing events around them on the plan stream; they have completed or are about
-            # to: this wait belongs to the refill either way)
-            bd, self._bd = self._bd, None
-            evs = bd.pop("_dma_events")
-            if evs and S.is_hip(self.dev):
-                evs[-1][1].synchronize()
-                bd["dma"] = float(sum(a.elapsed_time(b) for a, b in evs))
-            self.breakdown = bd
+            # (the DMA copies' own duration is read from their timing events when `breakdown` is QUERIED, not here: a commit
+            #  keeps the host free to issue the next steps -- on a late plan the wait above is the GPU's, not the host's)
+            self._breakdown, self._bd = self._bd, None
         # sharded fetch: every rank holds its slice of each list in place; one in-place all-gather per list (RCCL over
         # xGMI) completes them.  Issued here, on the main thread and stream, at the same point of the step sequence on
         # every rank, so it orders with the per-step gradient exchanges on the same communicator.

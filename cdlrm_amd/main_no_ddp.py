@@ -9,9 +9,10 @@
     load_caches_and_broadcast         :309-321
     Run                               :324-502  per-GPU trainer
 
-Launch: one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m cdlrm_amd.main_no_ddp ...`) or a
-single process for --world-size 1.  The reference's mp.spawn + Manager queues are replaced by torchrun + in-process
-threads/streams; tensors never cross a process boundary.
+Launch: `python -m cdlrm_amd.main_no_ddp <reference flags> --world-size=N` starts its N trainer processes itself, one per
+GPU (cdlrm_amd/launch.py: the reference's mp.spawn, main_no_ddp.py:638-643, as a torch.distributed.run child started before
+the first HIP call); under an external `torchrun` it is one of the ranks.  The reference's Manager queues are replaced by
+in-process threads/streams; tensors never cross a process boundary.
 """
 from __future__ import annotations
 
@@ -342,13 +343,18 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
     torch.manual_seed(args.numpy_rand_seed)
     np.set_printoptions(precision=args.print_precision)
     torch.set_printoptions(precision=args.print_precision)
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
+    # `rank` is the device index AND the distributed rank (main_no_ddp.py:324-344); `args.device_index` (set by main() when
+    # ranks are emulated on one GPU) separates the two
+    dev_index = int(getattr(args, "device_index", rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     world = args.world_size
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if world > 1 and dist.get_world_size() != world:
+        sys.exit("ERROR: --world-size=%d but torch.distributed reports %d ranks" % (world, dist.get_world_size()))
     local_batch_size = math.ceil(args.mini_batch_size / world)
     # the trainer's queue outranks the engine's side queues (see bench.py)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
@@ -589,12 +595,20 @@ def main(argv=None):
     # step measured 1.39-1.42 ms instead of 0.79): pin the default before the first HIP call, as bench.py does.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     args = ProcessArgs(argv)
+    from . import launch
+    if args.world_size > 1 and not launch.under_launcher():
+        # the reference's `mp.spawn(Run, nprocs=args.world_size)` (main_no_ddp.py:638-643): this process -- before its first
+        # HIP call -- starts one trainer process per GPU as children and exits with their return code
+        sys.exit(launch.spawn_ranks(args.world_size, sys.argv[1:] if argv is None else list(argv),
+                                    module="cdlrm_amd.main_no_ddp", port=launch.free_port() if launch.emulated() else
+                                    args.master_port))
     np.random.seed(args.numpy_rand_seed)
     torch.manual_seed(args.numpy_rand_seed)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if "WORLD_SIZE" in os.environ:
-        args.world_size = int(os.environ["WORLD_SIZE"])
+    if launch.under_launcher() and int(os.environ["WORLD_SIZE"]) != args.world_size:
+        sys.exit("ERROR: --world-size=%d does not match the launcher's WORLD_SIZE %s"
+                 % (args.world_size, os.environ["WORLD_SIZE"]))
     if rank != local_rank:
         # `Run(rank, ...)` keeps the reference's contract -- ONE integer that is both the device index and the
         # distributed rank (main_no_ddp.py:324-344, single node, MASTER_ADDR=localhost) -- and the host tables are one
@@ -644,12 +658,28 @@ def main(argv=None):
         # row, so neither trick has cached semantics: the operators are available stand-alone
         # (cdlrm_amd.tricks, Embedding_Table_Group(qr_flag= / md_flag=)).
         sys.exit("ERROR: --md-flag / --qr-flag tables cannot feed the embedding cache (stand-alone operators only)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from . import _lib
+    try:
+        _lib.require_gpu("cdlrm_amd.main_no_ddp")
+    except _lib.CdlrmLibraryError as e:
+        sys.exit("ERROR: " + str(e))
+    # development: CDLRM_BENCH_EMULATE=1 places every rank on device 0 with gloo collectives (tests on a one-GPU box)
+    emulate = launch.emulated() and args.world_size > 1
+    dev_index = 0 if emulate else local_rank
+    if not emulate and args.world_size > torch.cuda.device_count():
+        sys.exit("ERROR: --world-size=%d, but this node has %d GPUs (one trainer process per GPU)"
+                 % (args.world_size, torch.cuda.device_count()))
+    args.device_index = dev_index
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if args.world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
-        dist.init_process_group("nccl", rank=rank, world_size=args.world_size)
+        if emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=args.world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=args.world_size, device_id=dev)
+    launch.check_world(args.world_size)
     from . import synth
     from .hostmem import make_host_tables
     emb_tables = make_host_tables(ln_emb, m_spa, device=dev, seed=args.numpy_rand_seed, rank=rank, world=args.world_size,

@@ -32,6 +32,8 @@ class CacheCtx:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("cdlrm_amd: a HIP device is required (no CPU fallback)")
+        _lib.require_gpu("cdlrm_amd.ops.CacheCtx")
+        _lib.warn_hw_queues()
         self.rows = [self.ways * p + self.aux * self.aux_phases for p in self.cache_sets]
         self.row_base, self.tag_base, self.set_base = [0], [0], [0]
         for k in range(self.T):

@@ -440,6 +440,9 @@ int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int64_t* iargs,
                    const float* fargs);
 int64_t* cdlrm_tape_cells(cdlrm_tape* t);
 int64_t cdlrm_tape_length(cdlrm_tape* t);
+/* position, in fn's parameter list, of the stream the call issues on (the library's convention is "last parameter"; the
+ * event / stream calls below differ); -1: the call issues nothing itself; -2: fn is not a registered tape entry point */
+int32_t cdlrm_tape_stream_arg(void* fn);
 int cdlrm_tape_replay(cdlrm_tape* t);      /* first non-zero return code of a replayed call, else 0 */
 /* Multi-lane replay: at short per-rank batches the HOST thread that issues a step's ~45 runtime calls, not the GPU, sets the
  * step time.  lane[k] = 1 .. 3 hands op k to that helper thread of the process (one per side queue), lane[k] = 0 stays with
@@ -448,6 +451,13 @@ int cdlrm_tape_replay(cdlrm_tape* t);      /* first non-zero return code of a re
  * n = cdlrm_tape_length. */
 int cdlrm_tape_set_lanes(cdlrm_tape* t, const int32_t* lane, const int32_t* dep, int64_t n);
 int cdlrm_tape_selftest(void);
+/* Self-test hooks (no GPU involved; used by cdlrm_tape_selftest and tests/test_host_logic.py): a call with interleaved
+ * float / int32 / pointer / int64 parameters that adds its arguments up, and a logging call (spins `spin` iterations, then
+ * appends `tag` to a process-wide log that cdlrm_tape_probe_log_take drains; returns the number of entries logged). */
+int cdlrm_tape_probe(float f0, int64_t a0, float f1, int32_t a1, void* a2, int64_t a3, float f2, int32_t a4, int64_t a5,
+                     int64_t a6, void* a7, int32_t a8, float f3, int64_t a9);
+int cdlrm_tape_probe_log(int64_t tag, int64_t spin);
+int64_t cdlrm_tape_probe_log_take(int64_t* out, int64_t cap);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
 int cdlrm_event_record(void* event, void* stream);
 int cdlrm_stream_wait_event(void* stream, void* event);
