@@ -85,13 +85,19 @@ void cdlrm_set_error(const char* fmt, ...);
 // entry point: B == 0, a failed requirement, a failed launch -- records whatever is still pending, so an event can neither be
 // dropped nor ride on a later, unrelated GEMM of the thread (cdlrm_linear_fwd / cdlrm_mlp_wgrad share the launch sites).
 #define CDLRM_HIDDEN __attribute__((visibility("hidden")))
-extern CDLRM_HIDDEN thread_local hipEvent_t cdlrm_pending_stop_event;
-extern CDLRM_HIDDEN thread_local hipStream_t cdlrm_pending_stop_stream;
-extern CDLRM_HIDDEN thread_local int cdlrm_stop_scope_depth;
+// per host thread (the thread that issues the launch); lives in tape.hip behind a hidden accessor, so the library exports
+// nothing but the entry points include/cdlrm_hip.h declares
+struct CdlrmStopState {
+    hipEvent_t event;
+    hipStream_t stream;
+    int depth;
+};
+CDLRM_HIDDEN CdlrmStopState* cdlrm_stop_state();
 static inline hipEvent_t cdlrm_take_stop_event(hipStream_t s) {
-    hipEvent_t e = cdlrm_pending_stop_event;
-    if (e && cdlrm_stop_scope_depth > 0 && cdlrm_pending_stop_stream == s) {
-        cdlrm_pending_stop_event = nullptr;
+    CdlrmStopState* st = cdlrm_stop_state();
+    hipEvent_t e = st->event;
+    if (e && st->depth > 0 && st->stream == s) {
+        st->event = nullptr;
         return e;
     }
     return nullptr;
@@ -99,17 +105,18 @@ static inline hipEvent_t cdlrm_take_stop_event(hipStream_t s) {
 struct CdlrmStopScope {
     hipEvent_t held = nullptr;
     hipStream_t held_stream = nullptr;
-    CdlrmStopScope() { ++cdlrm_stop_scope_depth; }
+    CdlrmStopScope() { ++cdlrm_stop_state()->depth; }
     // a call with several launches: keep the event away from them, it is recorded behind the last one (on exit)
     void hold(hipStream_t s) {
         held = cdlrm_take_stop_event(s);
         held_stream = s;
     }
     ~CdlrmStopScope() {
+        CdlrmStopState* st = cdlrm_stop_state();
         if (held) (void)hipEventRecord(held, held_stream);
-        if (--cdlrm_stop_scope_depth == 0 && cdlrm_pending_stop_event) {      // no launch carried it
-            (void)hipEventRecord(cdlrm_pending_stop_event, cdlrm_pending_stop_stream);
-            cdlrm_pending_stop_event = nullptr;
+        if (--st->depth == 0 && st->event) {      // no launch carried it
+            (void)hipEventRecord(st->event, st->stream);
+            st->event = nullptr;
         }
     }
 };

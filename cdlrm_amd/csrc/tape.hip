@@ -330,9 +330,10 @@ extern "C" int cdlrm_event_record(void* event, void* stream) {
     return 0;
 }
 
-CDLRM_HIDDEN thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
-CDLRM_HIDDEN thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
-CDLRM_HIDDEN thread_local int cdlrm_stop_scope_depth = 0;
+CdlrmStopState* cdlrm_stop_state() {
+    static thread_local CdlrmStopState st{nullptr, nullptr, 0};
+    return &st;
+}
 
 // `event` completes with the NEXT kernel this thread launches on `stream` through cdlrm_linear_bwd or cdlrm_interact_bwd
 // (attached to the launch as its stop event: no marker packet on the queue); where that call cannot attach it -- a kernel
@@ -340,10 +341,14 @@ CDLRM_HIDDEN thread_local int cdlrm_stop_scope_depth = 0;
 // guarantees as cdlrm_event_record issued right behind that call.
 extern "C" int cdlrm_event_attach_next(void* event, void* stream) {
     CDLRM_REQUIRE(event, "null event");
-    if (cdlrm_pending_stop_event)       // (never the case in the training step: one attach per consuming call)
-        CDLRM_HIP_CHECK(hipEventRecord(cdlrm_pending_stop_event, cdlrm_pending_stop_stream));
-    cdlrm_pending_stop_event = (hipEvent_t)event;
-    cdlrm_pending_stop_stream = (hipStream_t)stream;
+    CdlrmStopState* st = cdlrm_stop_state();
+    if (st->event) {      // (never the case in the training step: one attach per consuming call)
+        hipEvent_t old = st->event;
+        st->event = nullptr;
+        CDLRM_HIP_CHECK(hipEventRecord(old, st->stream));
+    }
+    st->event = (hipEvent_t)event;
+    st->stream = (hipStream_t)stream;
     return 0;
 }
 

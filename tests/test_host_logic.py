@@ -422,3 +422,13 @@ def test_two_lane_tape_replay_orders_the_lanes(built_lib):
     assert L.cdlrm_tape_set_lanes(tape2._h, (C.c_int32 * n)(*lane2), bad, n) != 0
     same = (C.c_int32 * n)(*([-1, -1, 1] + [-1] * (n - 3)))     # op 2 (lane 0) on op 1 (lane 0)
     assert L.cdlrm_tape_set_lanes(tape2._h, (C.c_int32 * n)(*lane2), same, n) != 0
+
+
+def test_event_consumers_reject_bad_arguments_through_their_scope_guard(built_lib):
+    """cdlrm_linear_bwd / cdlrm_interact_bwd open the scope that flushes an attached completion event on EVERY exit path; the
+    argument-check exits are reachable without a GPU (no launch happens) and must return the error code, not crash."""
+    from cdlrm_amd import _lib
+    L = _lib.raw()
+    assert L.cdlrm_interact_bwd(None, None, 0, 0, 1, 4, 0, 0, None, None) == -22
+    assert b"cdlrm_interact_bwd" in L.cdlrm_last_error()
+    assert L.cdlrm_linear_bwd(None, 0, None, None, 0, None, 0, None, 0, None, None, 0, 0, 0, 0, 0, None, None) == -22
