@@ -61,11 +61,82 @@ __global__ void __launch_bounds__(256) k_linear_smallk(const float* __restrict__
     }
 }
 
+// The same layer with the WEIGHTS in registers (round 4): a lane owns 4 output columns and keeps their 4 x K weights, a wave
+// walks rows -- the row's K inputs are wave-uniform (scalar loads), so a row costs 4 K fused multiply-adds per lane and one
+// 1 KB store per wave, and nothing is staged through LDS.  Same arithmetic per output as k_linear_smallk (k ascending from
+// 0, bias added last): bit-identical.  The LDS-tiled version above spent its 13 us at M = 8192 on tile set-up (a 32-row tile
+// is 53 k multiply-adds behind two index-division loops and a barrier); this one is bound by the 16.8 MB it writes.
+template <int K_>
+__global__ void __launch_bounds__(256) k_linear_smallk_rows(const float* __restrict__ X, int64_t ld_x,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, int64_t ld_y, int64_t M, int N, int rows_per_wg,
+                                                            int act) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ncg = N >> 8;                                   // column groups of 256 (N % 256 == 0)
+    const int cgp = (int)(blockIdx.x % (unsigned)ncg);
+    const int64_t r0 = (int64_t)(blockIdx.x / (unsigned)ncg) * rows_per_wg;
+    const int n = cgp * 256 + lane * 4;
+    float w[4][K_];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < K_; ++k) w[j][k] = W[(int64_t)(n + j) * K_ + k];
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = *reinterpret_cast<const float4*>(bias + n);
+    int64_t r1 = r0 + rows_per_wg;
+    if (r1 > M) r1 = M;
+    float xn[K_];                                              // the next row's inputs, fetched one row ahead
+    {
+        const int64_t rf = r0 + wave < M ? r0 + wave : M - 1;
+        const float* __restrict__ xr = X + rf * ld_x;          // wave-uniform address: scalar loads
+#pragma unroll
+        for (int k = 0; k < K_; ++k) xn[k] = xr[k];
+    }
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+        float x[K_];
+#pragma unroll
+        for (int k = 0; k < K_; ++k) x[k] = xn[k];
+        {
+            const int64_t rn = r + 4 < M ? r + 4 : M - 1;
+            const float* __restrict__ xr = X + rn * ld_x;
+#pragma unroll
+            for (int k = 0; k < K_; ++k) xn[k] = xr[k];
+        }
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < K_; ++k) a = fmaf(x[k], w[j][k], a);
+            v[j] = a;
+        }
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (act == 1) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            else if (act == 2) v[j] = 1.0f / (1.0f + expf(-v[j]));
+        }
+        *reinterpret_cast<float4*>(Y + r * ld_y + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y, int64_t ld_y,
                                 int64_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     CDLRM_REQUIRE(X && W && Y && M >= 0 && N >= 1 && K >= 1 && ld_x >= K && ld_y >= N, "bad argument");
     if (M == 0) return 0;
     CDLRM_CLEAR_STALE();
+    if (K == 13 && N % 256 == 0 && ld_y % 4 == 0 && aligned16(Y) && (!bias || aligned16(bias)) && M >= 256) {
+        // rows per workgroup: ~512-1024 workgroups at the c3 batch, whole waves of rows at any batch
+        const int rpw = M >= 32768 ? 128 : 32;
+        const int64_t blocks = cdiv(M, rpw) * (N >> 8);
+        if (blocks <= 0x7fffffff) {
+            hipLaunchKernelGGL((k_linear_smallk_rows<13>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, ld_x, W,
+                               bias, Y, ld_y, M, (int)N, rpw, (int)act);
+            CDLRM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (K <= SK_KMAX && N % 4 == 0 && ld_y % 4 == 0 && aligned16(Y) && cdiv(M, 32) <= 65535) {
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 32));
         hipLaunchKernelGGL(k_linear_smallk, grid, dim3(256), 0, (hipStream_t)stream, X, ld_x, W, bias, Y, ld_y, M, (int)N,
@@ -122,6 +193,34 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
             const float g = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
             outB[e] = g;
             if (pB) pB[e] = fmaf(-lr, g, pB[e]);
+        }
+        return;
+    }
+    if ((countA & 3) == 0 && ((((uintptr_t)partA | (uintptr_t)outA | (uintptr_t)pA) & 15) == 0)) {
+        // 16-byte version (round 4): a thread owns four consecutive elements, eight slabs in flight; per element the same
+        // additions in the same order as the scalar loop below (slab 0, 1, 2, ...): bit-identical
+        const int64_t n4 = countA >> 2;
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(partA);
+        for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gxa * blockDim.x) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 8 <= splitsA; z += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p4[(int64_t)(z + u) * n4 + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+            for (; z < splitsA; ++z) {
+                const float4 v = p4[(int64_t)z * n4 + e];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            reinterpret_cast<float4*>(outA)[e] = s;
+            if (pA) {
+                float4 q = reinterpret_cast<float4*>(pA)[e];
+                q.x = fmaf(-lr, s.x, q.x); q.y = fmaf(-lr, s.y, q.y); q.z = fmaf(-lr, s.z, q.z); q.w = fmaf(-lr, s.w, q.w);
+                reinterpret_cast<float4*>(pA)[e] = q;
+            }
         }
         return;
     }
@@ -261,6 +360,107 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
     }
     CDLRM_LAUNCH_CHECK();
     return 0;                           // (stop_scope records an event no launch carried)
+}
+
+// ---- thin weight gradients (round 4) --------------------------------------------------------------------------------
+// dW[n][k] = sum_m dZ[m][n] X[m][k] where ONE side has at most 16 columns: the bottom MLP's first layer (X is 13 wide) and the
+// output layer (dZ is 1 wide).  An MFMA tile would be 60-97 % padding there (the LDS-free MFMA kernel took 27.9 us on the
+// training queue and 10.8 us beside it at M = 8192, for 16.8 / 8.4 MB of operand); this is a reduction over the batch on the
+// vector ALU: lanes <-> columns of the WIDE operand (coalesced 256-byte row reads), the thin operand's row is wave-uniform
+// (scalar loads), a wave walks every fourth row of its slab with four rows in flight, the workgroup's four waves are summed
+// through LDS in wave order -- fixed order, no atomics.  Writes the split-M slab layout the grouped reduction expects
+// (slab z at out + z * slab_stride, row-major [N, K]; column sums of dZ at colsum + z * N).
+// THIN_X: the thin side is X (lanes <-> n, the layer's outputs); else the thin side is dZ (lanes <-> k, the layer's inputs).
+template <int NT, bool THIN_X>
+__global__ void __launch_bounds__(256) k_wgrad_thin(const float* __restrict__ wide, int64_t ld_w, int NW,
+                                                    const float* __restrict__ thin, int64_t ld_t, int64_t M, int64_t rows_per_slab,
+                                                    float* __restrict__ out, int64_t slab_stride, float* __restrict__ colsum,
+                                                    int N, int K) {
+    __shared__ float red[4][NT + 1][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = blockIdx.x * 64 + lane;
+    const int colc = col < NW ? col : NW - 1;
+    const int z = blockIdx.y;
+    const int64_t r0 = (int64_t)z * rows_per_slab;
+    int64_t r1 = r0 + rows_per_slab;
+    if (r1 > M) r1 = M;
+    float acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) acc[k] = 0.f;
+    float side = 0.f;           // THIN_X: column sum of the wide operand (dZ); else unused
+    float tsum[NT];             // !THIN_X: column sums of the thin operand (dZ), the same in every lane
+#pragma unroll
+    for (int k = 0; k < NT; ++k) tsum[k] = 0.f;
+    for (int64_t r = r0 + wave; r < r1; r += 16) {
+        float v[4];
+        float t[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {       // four rows in flight; rows past the slab's end are read clamped and weighted 0
+            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
+            v[u] = wide[rr * ld_w + colc];
+            const float* __restrict__ tr = thin + rr * ld_t;        // wave-uniform: scalar loads
+#pragma unroll
+            for (int k = 0; k < NT; ++k) t[u][k] = tr[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = r + 4 * u < r1;
+            const float vv = live ? v[u] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) acc[k] = fmaf(vv, t[u][k], acc[k]);
+            if (THIN_X) side += vv;
+            else {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) tsum[k] += live ? t[u][k] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) red[wave][k][lane] = acc[k];
+    float extra = side;
+    if (!THIN_X) {              // lane k < NT parks the thin column sum k (every lane holds all of them)
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            if (lane == k) extra = tsum[k];
+    }
+    red[wave][NT][lane] = extra;
+    __syncthreads();
+    if (wave != 0) return;
+    float* __restrict__ o = out + (int64_t)z * slab_stride;
+    if (col < NW) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const float g = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
+            if (THIN_X) o[(int64_t)col * K + k] = g;          // dW[n = col][k]
+            else o[(int64_t)k * K + col] = g;                 // dW[n = k][k' = col]
+        }
+    }
+    if (colsum) {
+        const float g = ((red[0][NT][lane] + red[1][NT][lane]) + red[2][NT][lane]) + red[3][NT][lane];
+        if (THIN_X) {
+            if (col < NW) colsum[(int64_t)z * N + col] = g;
+        } else if (blockIdx.x == 0 && lane < NT) {
+            colsum[(int64_t)z * N + lane] = g;
+        }
+    }
+}
+
+// the thin kernel for one layer's split-M weight gradient, if the layer has a thin side it covers; false: not taken
+static bool launch_wgrad_thin(const float* dZ, int64_t ld_dz, const float* X, int64_t ld_x, int64_t M, int N, int K,
+                              int64_t rows_per_slab, int zs, float* out, float* colsum, hipStream_t s) {
+    if (zs < 1 || zs > 65535) return false;
+    if (K == 13 && N >= 64) {
+        hipLaunchKernelGGL((k_wgrad_thin<13, true>), dim3((unsigned)cdiv(N, 64), (unsigned)zs), dim3(256), 0, s, dZ, ld_dz, N, X,
+                           ld_x, M, rows_per_slab, out, (int64_t)N * K, colsum, N, K);
+        return true;
+    }
+    if (N == 1 && K >= 64) {
+        hipLaunchKernelGGL((k_wgrad_thin<1, false>), dim3((unsigned)cdiv(K, 64), (unsigned)zs), dim3(256), 0, s, X, ld_x, K, dZ,
+                           ld_dz, M, rows_per_slab, out, (int64_t)N * K, colsum, N, K);
+        return true;
+    }
+    return false;
 }
 
 // Weight (and bias) gradients of SEVERAL layers at once, from the pre-activation gradients dZ[i] that the dgrad chain
@@ -434,6 +634,7 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
             if (P_w) stepped[i] = 1;
             jobs.push_back(r);
         }
+        if (launch_wgrad_thin(dZ[i], ld_dz[i], X[i], ld_x[i], M, N[i], K[i], g.kchunk, zs, g.C, g.colsum, s)) continue;
         int rc = launch_gemm<false, false>(g, zs, s);
         if (rc) return rc;
     }

@@ -23,6 +23,9 @@
 #include "gemm.h"
 
 #define G2_BK 32
+#ifndef G2_PRIO
+#define G2_PRIO 0       // experiment (tools/gemm2_bench.hip): wave priority of the first-dispatched half of the grid
+#endif
 #ifndef G2_ABL
 #define G2_ABL 0        // diagnostic builds: 1 no DMA in the loop, 2 no barrier in the loop, 4 pieces behind every 2nd MFMA
 #endif
@@ -319,6 +322,10 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
     const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
     const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned wgid = xcd_remap(orig, nwg);
+#if G2_PRIO
+    // experiment: the first half of the grid (dispatched first: one workgroup per CU) outranks the second half, its CU-mates
+    if (orig < (nwg >> 1)) __builtin_amdgcn_s_setprio(G2_PRIO);
+#endif
     gemm2_tile_body<A_KC, B_KC, TM, TN>(g, wgid % gridDim.x, (wgid / gridDim.x) % gridDim.y,
                                         wgid / (gridDim.x * gridDim.y), lds);
 }

@@ -187,11 +187,16 @@ __global__ void __launch_bounds__(WIN_THREADS) k_kept_flags(const TableDesc* __r
 
 // off_out[k] = number of entries of the ascending list `list[0..count)` that are < bound[k], k = 0..T
 __global__ void k_offsets_from_sorted(const int32_t* __restrict__ list, const int64_t* __restrict__ d_count, int64_t cap,
-                                      const int64_t* __restrict__ bound, int T, int64_t* __restrict__ off_out) {
+                                      const int64_t* __restrict__ bound, int T, int64_t* __restrict__ off_out,
+                                      int64_t* __restrict__ total_out = nullptr) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > T) return;
     const int64_t cnt = min(*d_count, cap);
-    if (k == T) { off_out[T] = cnt; return; }
+    if (k == T) {
+        off_out[T] = cnt;
+        if (total_out) *total_out = *d_count;       // the length the list would have without the cap
+        return;
+    }
     int64_t lo = 0, hi = cnt;
     const int64_t b = bound[k];
     while (lo < hi) {
@@ -650,7 +655,7 @@ static int plan_victims_impl(cdlrm_ctx* ctx, const cdlrm_plan* plan, const cdlrm
                              ctx->d_small + 2, 1 | 2, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_offsets_from_sorted, dim3(cdiv(ctx->T + 1, 64)), dim3(64), 0, s, v->pos, ctx->d_small + 2, v->cap,
-                       plan->uniq_off, ctx->T, v->off);
+                       plan->uniq_off, ctx->T, v->off, v->off + ctx->T + 1);
     CDLRM_REQUIRE(ctx->T <= 1024, "more than 1024 tables");
     if (fetch) {
         const int D4 = ctx->D / 4;

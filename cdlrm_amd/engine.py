@@ -100,8 +100,17 @@ class WindowPipeline:
         self.write_back = bool(write_back)
         self.ctx = cache_group.ctx
         self.plan = ops.WindowPlan(self.ctx, max_window, cap_uniq, cap_win)
+        # Each of the two victim buffers starts at <= 8 GiB and GROWS when a window's plan lists more non-cached indices than it
+        # holds (host-gather plans: the count is on the host before any row moves), up to a fifth of the device's memory per
+        # buffer: a Zipf window at c3 leaves 9-10 M victims (5 GB), a UNIFORM one 76 M (39 GB) -- cut at 8 GiB, four of five
+        # misses of every step read the host table over PCIe inside the step (0.90 instead of 0.70 ms/step).  288 GB of HBM are
+        # there to be used; what does not fit even then is still served from the host table, as the reference serves all of it.
+        self.victim_limit = 0
         if victim_rows is None:
             victim_rows = min(self.plan.cap_uniq, (8 << 30) // (4 * self.ctx.D))
+            if S.is_hip(cache_group.weight.device):
+                total = torch.cuda.get_device_properties(cache_group.weight.device).total_memory
+                self.victim_limit = min(self.plan.cap_uniq, int(total * 0.2) // (4 * self.ctx.D))
         self.victims = [ops.Victims(self.ctx, victim_rows) for _ in range(2)] if victim_rows > 0 else None
         self._vnext = 0
         self.dev = cache_group.weight.device
@@ -241,8 +250,21 @@ class WindowPipeline:
                     t0 = _time.perf_counter()
                     voff = vic.off.cpu().tolist()
                     bd["lists_to_host"] += (_time.perf_counter() - t0) * 1e3
+                    need = voff[T + 1]               # what the window has; voff[T] = what the buffer holds of it
+                    if need > vic.cap and self.victim_limit > vic.cap:
+                        # more victims than this buffer holds: a larger one (this is the buffer of the window being planned:
+                        # nothing reads it yet), and the list again
+                        t0 = _time.perf_counter()
+                        side.synchronize()
+                        self.victims[self._vnext] = vic = None
+                        vic = self.victims[self._vnext] = ops.Victims(
+                            self.ctx, min(self.victim_limit, int(need * 1.1) + 4096))
+                        plan.victims(vic, stream=side, list_only=True)
+                        voff = vic.off.cpu().tolist()
+                        bd["victims_regrown_ms"] = (_time.perf_counter() - t0) * 1e3
+                    bd["victims_in_window"], bd["victim_capacity"] = int(voff[T + 1]), int(vic.cap)
                     V = min(voff[T], vic.cap)
-                    voff = [min(o, V) for o in voff]
+                    voff = [min(o, V) for o in voff[:T + 1]]
                     self._fetch_list("vic", vic.idx, voff, V, vic.rows, D)
                 bd["host_total"] = (_time.perf_counter() - t_launch) * 1e3
                 if isinstance(window_idx, torch.Tensor) and window_idx.is_cuda:

@@ -338,7 +338,7 @@ class Victims:
         self.cap = max(1, int(cap))
         self.pos = torch.empty(self.cap, dtype=torch.int32, device=dev)
         self.idx = torch.zeros(self.cap, dtype=torch.int64, device=dev)
-        self.off = torch.zeros(ctx.T + 1, dtype=torch.int64, device=dev)
+        self.off = torch.zeros(ctx.T + 2, dtype=torch.int64, device=dev)     # [T + 1] offsets + the un-capped list length
         self.rows = torch.empty((self.cap, ctx.D), dtype=torch.float32, device=dev)
         self.c = _VictimsStruct(self.pos.data_ptr(), self.idx.data_ptr(), self.off.data_ptr(), self.rows.data_ptr(),
                                 self.cap)

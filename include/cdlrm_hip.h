@@ -229,7 +229,8 @@ int cdlrm_plan_writeback(cdlrm_ctx* ctx, const cdlrm_plan* plan, float* const* d
 typedef struct {
     int32_t* pos;            /* [cap] positions into plan->uniq, ascending                                   */
     int64_t* idx;            /* [cap] the indices, ascending per table                                       */
-    int64_t* off;            /* [T+1] start of table k                                                       */
+    int64_t* off;            /* [T+2] start of table k; off[T] = entries listed (<= cap); off[T+1] = entries the    */
+                             /*       window HAS (> cap: the list was cut -- a caller may come back with a larger one) */
     float*   rows;           /* [cap, D] their host rows                                                     */
     int64_t  cap;
 } cdlrm_victims;

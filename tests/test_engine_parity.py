@@ -260,7 +260,7 @@ def test_host_gather_plan_equals_device_fetch(golden):
             torch.cuda.synchronize()
             vic = pipe.victims[pipe._vnext ^ 1]
             voff = vic.off.cpu().tolist()
-            nv = voff[-1]
+            nv = voff[-2]               # off[T]: entries listed (off[T + 1]: what the window has, before the cap)
             snaps.append((cg.tags.cpu().clone(), [cg.emb_l[k].weight[: int(g["ways"]) * cg.cache_sizes[k]].cpu().clone()
                                                   for k in range(len(cg.cache_sizes))], voff,
                           vic.idx[:nv].cpu().clone(), vic.rows[:nv].cpu().clone(),

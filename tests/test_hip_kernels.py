@@ -102,7 +102,7 @@ def test_window_resolve_take_equals_probe(ops, with_victims):
         pipe.wait_writeback()
     torch.cuda.synchronize()
     if with_victims:
-        nv = int(pipe.victims[pipe._vnext ^ 1].off.cpu()[-1])
+        nv = int(pipe.victims[pipe._vnext ^ 1].off.cpu()[-2])       # off[T]: entries listed (off[T + 1]: before the cap)
         assert 0 < nv, "the fixture must produce victims"
     # lookups: the window's own batches plus ids the window never saw (host fallback)
     look = win.clone()
@@ -281,7 +281,7 @@ def test_window_victims_serve_misses_from_hbm(ops, golden, cap_mode):
         torch.cuda.synchronize(); st.ctx.check()
         off = vic.off.cpu().tolist()
         flat = torch.cat(expect)[:cap]
-        assert off[T] == min(total, cap)
+        assert off[T] == min(total, cap) and off[T + 1] == total       # listed / what the window has (a cut list says so)
         assert torch.equal(vic.idx[:off[T]].cpu(), flat)
         lo = 0
         for k in range(T):      # per-table boundaries of the (possibly cut) list
@@ -1019,3 +1019,28 @@ def test_synthetic_index_stream_device_vs_host(ops, alpha):
     if alpha > 0:       # skew: the hottest id of the big table takes far more than its uniform share
         big = dev_s.window(0, 50)[0]
         assert int(torch.bincount(big % 1000003).max()) > 50 * big.numel() / 1000003
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_smallk_rows_kernel_equals_the_tiled_one(ops, act):
+    """The 13-wide first layer on the weights-in-registers kernel (M >= 256, N % 256 == 0) computes every output with the
+    tiled kernel's arithmetic (k ascending from 0, bias last): the same rows through the tiled kernel (a batch below 256)
+    are bit-identical; a ragged batch and a row pitch wider than N included."""
+    rng = np.random.RandomState(7 + act)
+    M, N, K = 8192 + 37, 512, 13
+    X = torch.from_numpy(rng.randn(M, K).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rng.randn(N, K) / 3.6).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.randn(N).astype(np.float32)).to(DEV)
+    Yb = torch.full((M, N + 8), 7.0, device=DEV)
+    Y = Yb[:, :N]
+    ops.linear_fwd(X, W, b, Y, act)
+    assert bool((Yb[:, N:] == 7.0).all())
+    for lo in (0, 4000, M - 200):
+        Yt = torch.empty(200, N, device=DEV)
+        ops.linear_fwd(X[lo:lo + 200], W, b, Yt, act)          # 200 rows: the tiled kernel
+        assert torch.equal(Yt, Y[lo:lo + 200].contiguous()), lo
+    Yn = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(X, W, None, Yn, act)                         # no bias
+    pre = X.cpu().double() @ W.cpu().double().t()
+    ref = {0: pre, 1: torch.relu(pre), 2: torch.sigmoid(pre)}[act]
+    np.testing.assert_allclose(Yn.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)

@@ -212,7 +212,7 @@ def _shard_worker(rank, world, port, host_shared, ret):
                 pipe.wait_writeback()           # barrier: rank 0's evictions are in the host tables before the next plan
                 torch.cuda.synchronize()
                 vic = pipe.victims[pipe._vnext ^ 1]
-                nv = int(vic.off.cpu()[-1])
+                nv = int(vic.off.cpu()[-2])           # off[T]: entries listed
                 snaps.append((cg.tags.cpu().clone(), cg.weight.cpu().clone(), nv, vic.idx[:nv].cpu().clone(),
                               vic.rows[:nv].cpu().clone()))
             cg.ctx.check()
@@ -353,3 +353,143 @@ def test_plan_in_flight_while_rows_merge_every_step():
         assert "error" not in payload, payload["error"]
     for p in procs:
         p.join(timeout=60)
+
+
+# ---- config c5 at world > 1: lbs = 8192 per rank, streamed windows, a resolver per chunk, the long-batch schedule ----------
+C5 = dict(cap=30000, D=128, ways=16, cache=500, B=16384, L=4, C=2, nwin=2, agg=3, seed=31, alpha=1.05, lr=0.8, lr_emb=0.8,
+          bot=[13, 512, 256, 128], top=[512, 512, 256, 1])
+
+
+def _c5_data():
+    """Indices / dense features / targets of the capped c5 shape, from the CPU restatement of the synthetic stream (the ranks
+    and the oracle must see the same integers: the device generator may differ from it in a last place of a float64 pow)."""
+    sys.path.insert(0, ROOT)
+    from cdlrm_amd.synth import CriteoSynth, TERABYTE_COUNTS
+    ln_emb = [min(n, C5["cap"]) for n in TERABYTE_COUNTS]
+    syn = CriteoSynth(ln_emb, 13, C5["B"], seed=C5["seed"], alpha=C5["alpha"], device="cpu")
+    wins = [syn.window(w, C5["L"]) for w in range(C5["nwin"])]
+    dense = [syn.dense(j) for j in range(C5["L"] * C5["nwin"])]
+    return ln_emb, wins, dense
+
+
+def _c5_worker(rank, world, port, host_shared, ret):
+    import faulthandler
+    faulthandler.dump_traceback_later(400, exit=True)
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        import cdlrm_amd.engine as engine
+        import cdlrm_amd.model_no_ddp as M
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = "cuda:0"
+        torch.cuda.set_device(0)
+        ln_emb_l, wins, dense = _c5_data()
+        ln_emb = np.array(ln_emb_l)
+        D, B, L, C = C5["D"], C5["B"], C5["L"], C5["C"]
+        lbs = B // world
+        nf = len(ln_emb) + 1
+        ln_top = np.array([D + nf * (nf - 1) // 2] + C5["top"])
+        eg = M.Embedding_Table_Group(D, ln_emb, init="empty_meta")
+        for k in range(len(ln_emb)):
+            eg.emb_l[k].weight.data = host_shared[k]
+        eg.register_shared()
+        np.random.seed(C5["seed"])
+        torch.manual_seed(C5["seed"])
+        cg = M.Embedding_Table_Cache_Group(D, ln_emb, C5["cache"], B, C5["ways"]).to(dev)
+        dl = M.DLRM_Net(np.array(C5["bot"]), ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
+        eng = engine.TrainEngine(cg, dl, eg, lr=C5["lr"], lr_embeds=C5["lr_emb"], world_size=world, rank=rank,
+                                 table_agg_freq=C5["agg"], table_agg_op="mean", defer_top_update=True)
+        eng.agg_chunk_rows = 4096           # the touched-row merge in several chunks on the exchange stream
+        assert not eng._side_gather(lbs), "lbs = 8192: the long-batch schedule (gather alone on the training queue)"
+        pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+        losses, j = [], 0
+        for w, win in enumerate(wins):
+            win_d = win.to(dev)
+            eng.sync_touched_to_rank0()
+            torch.manual_seed(5000 + w * L)
+            # the window reaches the plan as a STREAM of chunks of C batches (cdlrm_window_unique_add / _finish)
+            pipe.plan_window(lambda: (win_d[:, c * C * B:(c + 1) * C * B].contiguous() for c in range(L // C)))
+            pipe.commit()
+            pipe.wait_writeback()
+            rs = chunk = None
+            for jj in range(L):
+                c, jc = divmod(jj, C)
+                if jc == 0:         # a resolver per chunk, as bench.py runs streamed windows
+                    chunk = win_d[:, c * C * B:(c + 1) * C * B].contiguous()
+                    rs = engine.WindowResolver(eng, chunk, B, chunk=1)
+                col = jc * B + rank * lbs
+                idx = chunk[:, col:col + lbs]
+                nxt = chunk[:, col + B:col + B + lbs] if jc + 1 < C else None
+                X, T = dense[j]
+                loss = eng.step(X[rank * lbs:(rank + 1) * lbs].to(dev), idx, T[rank * lbs:(rank + 1) * lbs].to(dev), j=jj,
+                                next_idx=nxt, res=rs.batch(jc), next_res=rs.batch(jc + 1) if nxt is not None else None)
+                rs.ensure(jc + rs.CH + 2)
+                losses.append(float(loss[0]))
+                j += 1
+        eng.finish()
+        cg.ctx.check()
+        lin = M._linears(dl.top_l)
+        ret.put((rank, dict(losses=np.array(losses), occ=[o.cpu().numpy() for o in cg.occupancy_tables],
+                            top_w=[l.weight.data.cpu().numpy() for l in lin])))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        ret.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+def test_c5_flow_two_ranks_vs_oracle():
+    """BASELINE configs[4] at world > 1 on its own code path: a local batch of 8192 per rank (the long-batch schedule: gather
+    alone on the training queue, chained take, resolve placed inside the step), the window streamed into the plan in chunks, a
+    window-resident resolver per chunk, the touched-row merge in chunks on the exchange stream, deferred top-MLP update --
+    26 capped Terabyte tables, D = 128, 16-way, the c3 / c5 MLPs -- against the oracle's 2-rank emulation: per-rank loss of every
+    iteration 1e-5, shared tag state bit-exact, replicated weights."""
+    from oracle import cdlrm_oracle as O
+    world = 2
+    ln_emb, wins, dense = _c5_data()
+    D, B, L = C5["D"], C5["B"], C5["L"]
+    nf = len(ln_emb) + 1
+    ln_top = np.array([D + nf * (nf - 1) // 2] + C5["top"])
+    torch.set_num_threads(16)
+    np.random.seed(C5["seed"])
+    host0 = O.init_host_tables(ln_emb, D)
+    host = [h.clone().share_memory_() for h in host0]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, 29861, host, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    # the oracle runs while the ranks train
+    tr = O.OracleTrainer(ln_emb, D, np.array(C5["bot"]), ln_top, cache_size=C5["cache"], num_ways=C5["ways"],
+                         mini_batch_size=B, world_size=world, lr=C5["lr"], lr_embeds=C5["lr_emb"], lookahead=L,
+                         table_agg_freq=C5["agg"], table_agg_op="mean", seed=C5["seed"], host_tables=host0)
+    lS_o = torch.arange(B // world).repeat(len(ln_emb), 1)
+    j = 0
+    for w, win in enumerate(wins):
+        torch.manual_seed(5000 + w * L)
+        tr.refill(win)
+        for jj in range(L):
+            X, T = dense[j]
+            tr.step(jj, X, lS_o, win[:, jj * B:(jj + 1) * B], T)
+            j += 1
+    got = {}
+    for _ in range(world):
+        r, payload = ret.get(timeout=500)
+        assert "error" not in payload, payload["error"]
+        got[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], np.array([l[r] for l in tr.losses]), rtol=1e-5)
+        for k in range(len(ln_emb)):
+            assert np.array_equal(got[r]["occ"][k], tr.occ[k].numpy()), (r, k)
+        for i in range(len(got[r]["top_w"])):
+            # (eight steps at lr = 0.8 on 8192-sample gradients: weights of magnitude ~0.05 agree to ~1e-5 absolute)
+            np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=2e-4, atol=5e-5)
+            assert np.array_equal(got[r]["top_w"][i], got[0]["top_w"][i])
+    for k in range(len(ln_emb)):
+        np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=1e-6)

@@ -182,6 +182,23 @@ def main():
         byt = B * (2 * F * D * 4 + (D + npairs) * 4)
         print("interact_bwd         %8.1f us   %7.1f GB/s" % (us, byt / us / 1e3))
 
+    if want("thin"):
+        # the layers with a thin side: 13-wide input (forward on the vector ALU, weights in registers), and the weight gradients
+        # of the 13-wide and the 1-wide layer (vector-ALU reductions over the batch + the grouped slab reduction)
+        X = torch.randn(B, 13, device=DEV)
+        W = torch.randn(512, 13, device=DEV) / 3.6
+        b = torch.randn(512, device=DEV)
+        Y = torch.empty(B, 512, device=DEV)
+        us = timeit(lambda: ops.linear_fwd(X, W, b, Y, 1))
+        print("linear 13->512 fwd     %8.1f us   %7.1f GB/s written" % (us, B * 512 * 4 / us / 1e3))
+        for (N, K) in ((512, 13), (1, 256), (256, 512)):
+            Xs = [torch.randn(B, K, device=DEV)]
+            dZs = [torch.randn(B, N, device=DEV)]
+            dWs, dbs = [torch.empty(N, K, device=DEV)], [torch.empty(N, device=DEV)]
+            plan = ops.WgradPlan(Xs, dZs, dWs, dbs, ops.mlp_wgrad_work(B, [N], [K], DEV))
+            us = timeit(lambda: ops.mlp_wgrad(plan))
+            print("wgrad %4d x %4d (+ slab reduction) %8.1f us   %7.1f GB/s of operands" % (N, K, us, B * (N + K) * 4 / us / 1e3))
+
     if want("gemm"):
         layers = [(13, 512, 1), (512, 256, 1), (256, 128, 1), (D + 351, 512, 1), (512, 512, 1), (512, 256, 1), (256, 1, 2)]
         tot_f = tot_b = 0.0

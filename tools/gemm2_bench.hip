@@ -16,8 +16,10 @@ static int g_extra_lds = 0;      // development: extra dynamic LDS per workgroup
 #include "gemm_glds.h"
 
 void cdlrm_set_error(const char* fmt, ...) {}
-thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
-thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
+CdlrmStopState* cdlrm_stop_state() {
+    static thread_local CdlrmStopState st{nullptr, nullptr, 0};
+    return &st;
+}
 
 static int g_data_mode = 1;      // 0 zeros, 1 uniform [-1, 1), 2 ReLU-like (half of the values zero)
 static float* dev_rand(size_t n, unsigned seed) {

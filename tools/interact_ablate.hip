@@ -4,8 +4,10 @@
 #include <stdarg.h>
 #include "dense.hip"
 void cdlrm_set_error(const char* fmt, ...) {}
-thread_local hipEvent_t cdlrm_pending_stop_event = nullptr;
-thread_local hipStream_t cdlrm_pending_stop_stream = nullptr;
+CdlrmStopState* cdlrm_stop_state() {
+    static thread_local CdlrmStopState st{nullptr, nullptr, 0};
+    return &st;
+}
 
 int main(int argc, char** argv) {
     int64_t B = 8192; int F = 27, D = 128;
