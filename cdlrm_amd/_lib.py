@@ -47,6 +47,7 @@ class Victims(C.Structure):
 # name -> (restype, argtypes); every symbol include/cdlrm_hip.h declares
 PROTOTYPES = {
     "cdlrm_abi_version": (C.c_int, []),
+    "cdlrm_debug_set": (C.c_int, [c_i32, c_i32]),
     "cdlrm_last_error": (C.c_char_p, []),
     "cdlrm_ctx_create": (C.c_int, [C.POINTER(Geometry), C.POINTER(vp)]),
     "cdlrm_ctx_destroy": (C.c_int, [vp]),
@@ -119,6 +120,7 @@ PROTOTYPES = {
     "cdlrm_tape_replay": (C.c_int, [vp]),
     "cdlrm_tape_set_lanes": (C.c_int, [vp, vp, vp, c_i64]),
     "cdlrm_tape_selftest": (C.c_int, []),
+    "cdlrm_delay_us": (C.c_int, [c_f32, vp]),
     "cdlrm_event_record": (C.c_int, [vp, vp]),
     "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
     "cdlrm_event_attach_next": (C.c_int, [vp, vp]),

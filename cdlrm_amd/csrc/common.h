@@ -73,7 +73,13 @@ void cdlrm_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+#define CDLRM_HIDDEN_DATA __attribute__((visibility("hidden")))
 #define CDLRM_LAUNCH_CHECK() CDLRM_HIP_CHECK(hipGetLastError())
+
+// Development switches (cdlrm_debug_set, tools/ab_step.py --attr debug:<key>): A/B a kernel path against the one it replaced
+// on ONE box in ONE process -- box-to-box spread is larger than most single-kernel gains.  All zero in production.
+//   0: 13-wide forward on the LDS-tiled kernel   2: scalar slab reduction
+extern CDLRM_HIDDEN_DATA int g_cdlrm_debug[8];
 
 // Completion events attached to a launch (cdlrm_event_attach_next).  An event RECORDED on the training queue is a marker
 // packet of its own and leaves a 6-8 us bubble there; handed to hipExtLaunchKernel as the stop event of

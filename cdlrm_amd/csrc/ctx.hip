@@ -15,6 +15,12 @@ void cdlrm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int g_cdlrm_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int cdlrm_debug_set(int32_t key, int32_t value) {
+    CDLRM_REQUIRE(key >= 0 && key < 8, "key: 0 .. 7");
+    g_cdlrm_debug[key] = value;
+    return 0;
+}
 extern "C" int cdlrm_abi_version(void) { return CDLRM_ABI_VERSION; }
 extern "C" const char* cdlrm_last_error(void) { return g_err; }
 

@@ -126,9 +126,12 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
     CDLRM_REQUIRE(X && W && Y && M >= 0 && N >= 1 && K >= 1 && ld_x >= K && ld_y >= N, "bad argument");
     if (M == 0) return 0;
     CDLRM_CLEAR_STALE();
-    if (K == 13 && N % 256 == 0 && ld_y % 4 == 0 && aligned16(Y) && (!bias || aligned16(bias)) && M >= 256) {
-        // rows per workgroup: ~512-1024 workgroups at the c3 batch, whole waves of rows at any batch
-        const int rpw = M >= 32768 ? 128 : 32;
+    if (K == 13 && N % 256 == 0 && ld_y % 4 == 0 && aligned16(Y) && (!bias || aligned16(bias)) && M >= 256 &&
+        !g_cdlrm_debug[0]) {
+        // Rows per workgroup: ~512-1024 workgroups at the c3 batch; short batches get 8 rows per workgroup -- a wave's 52
+        // weight loads are then amortised over two rows only, but 32 rows left 64 workgroups for 256 CUs at M = 1024 and the
+        // kernel took 10.3 us in the per-rank step, against 6.6 for the LDS-tiled one.
+        const int rpw = M >= 32768 ? 128 : M >= 4096 ? 32 : 8;
         const int64_t blocks = cdiv(M, rpw) * (N >> 8);
         if (blocks <= 0x7fffffff) {
             hipLaunchKernelGGL((k_linear_smallk_rows<13>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, ld_x, W,
@@ -178,7 +181,7 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
                                                   float* __restrict__ outA, int gxa, const float* __restrict__ partB,
                                                   int64_t countB, int splitsB, float* __restrict__ outB,
                                                   float (*red)[64], float* __restrict__ pA = nullptr,
-                                                  float* __restrict__ pB = nullptr, float lr = 0.f) {
+                                                  float* __restrict__ pB = nullptr, float lr = 0.f, int novec = 0) {
     if (bid >= gxa) {
         // part B (bias gradient): few elements, many partials -> 4 lanes per element, each summing every 4th
         // partial, combined in a fixed order through LDS
@@ -196,7 +199,7 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
         }
         return;
     }
-    if ((countA & 3) == 0 && ((((uintptr_t)partA | (uintptr_t)outA | (uintptr_t)pA) & 15) == 0)) {
+    if (!novec && (countA & 3) == 0 && ((((uintptr_t)partA | (uintptr_t)outA | (uintptr_t)pA) & 15) == 0)) {
         // 16-byte version (round 4): a thread owns four consecutive elements, eight slabs in flight; per element the same
         // additions in the same order as the scalar loop below (slab 0, 1, 2, ...): bit-identical
         const int64_t n4 = countA >> 2;
@@ -252,6 +255,7 @@ struct ReduceJob {
     const float* partB; int64_t countB; float* outB;
     int splits;
     float* pA; float* pB; float lr;         // fused SGD step (NULL: none)
+    int novec;                              // development: the scalar loop (g_cdlrm_debug[2])
 };
 struct ReduceGroup {
     int n;
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup grp) {
         if (q < grp.n && blockIdx.x >= grp.first[q]) p = q;
     const ReduceJob& r = grp.j[p];
     reduce_slabs_body((int)(blockIdx.x - grp.first[p]), r.partA, r.countA, r.splits, r.outA, r.gxa, r.partB, r.countB,
-                      r.splits, r.outB, red, r.pA, r.pB, r.lr);
+                      r.splits, r.outB, red, r.pA, r.pB, r.lr, r.novec);
 }
 
 // Weight-gradient contraction (over the batch) is cut into slabs when the batch is long: small batches go to the
@@ -362,107 +366,13 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
     return 0;                           // (stop_scope records an event no launch carried)
 }
 
-// ---- thin weight gradients (round 4) --------------------------------------------------------------------------------
-// dW[n][k] = sum_m dZ[m][n] X[m][k] where ONE side has at most 16 columns: the bottom MLP's first layer (X is 13 wide) and the
-// output layer (dZ is 1 wide).  An MFMA tile would be 60-97 % padding there (the LDS-free MFMA kernel took 27.9 us on the
-// training queue and 10.8 us beside it at M = 8192, for 16.8 / 8.4 MB of operand); this is a reduction over the batch on the
-// vector ALU: lanes <-> columns of the WIDE operand (coalesced 256-byte row reads), the thin operand's row is wave-uniform
-// (scalar loads), a wave walks every fourth row of its slab with four rows in flight, the workgroup's four waves are summed
-// through LDS in wave order -- fixed order, no atomics.  Writes the split-M slab layout the grouped reduction expects
-// (slab z at out + z * slab_stride, row-major [N, K]; column sums of dZ at colsum + z * N).
-// THIN_X: the thin side is X (lanes <-> n, the layer's outputs); else the thin side is dZ (lanes <-> k, the layer's inputs).
-template <int NT, bool THIN_X>
-__global__ void __launch_bounds__(256) k_wgrad_thin(const float* __restrict__ wide, int64_t ld_w, int NW,
-                                                    const float* __restrict__ thin, int64_t ld_t, int64_t M, int64_t rows_per_slab,
-                                                    float* __restrict__ out, int64_t slab_stride, float* __restrict__ colsum,
-                                                    int N, int K) {
-    __shared__ float red[4][NT + 1][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = blockIdx.x * 64 + lane;
-    const int colc = col < NW ? col : NW - 1;
-    const int z = blockIdx.y;
-    const int64_t r0 = (int64_t)z * rows_per_slab;
-    int64_t r1 = r0 + rows_per_slab;
-    if (r1 > M) r1 = M;
-    float acc[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) acc[k] = 0.f;
-    float side = 0.f;           // THIN_X: column sum of the wide operand (dZ); else unused
-    float tsum[NT];             // !THIN_X: column sums of the thin operand (dZ), the same in every lane
-#pragma unroll
-    for (int k = 0; k < NT; ++k) tsum[k] = 0.f;
-    for (int64_t r = r0 + wave; r < r1; r += 16) {
-        float v[4];
-        float t[4][NT];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {       // four rows in flight; rows past the slab's end are read clamped and weighted 0
-            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
-            v[u] = wide[rr * ld_w + colc];
-            const float* __restrict__ tr = thin + rr * ld_t;        // wave-uniform: scalar loads
-#pragma unroll
-            for (int k = 0; k < NT; ++k) t[u][k] = tr[k];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool live = r + 4 * u < r1;
-            const float vv = live ? v[u] : 0.f;
-#pragma unroll
-            for (int k = 0; k < NT; ++k) acc[k] = fmaf(vv, t[u][k], acc[k]);
-            if (THIN_X) side += vv;
-            else {
-#pragma unroll
-                for (int k = 0; k < NT; ++k) tsum[k] += live ? t[u][k] : 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NT; ++k) red[wave][k][lane] = acc[k];
-    float extra = side;
-    if (!THIN_X) {              // lane k < NT parks the thin column sum k (every lane holds all of them)
-#pragma unroll
-        for (int k = 0; k < NT; ++k)
-            if (lane == k) extra = tsum[k];
-    }
-    red[wave][NT][lane] = extra;
-    __syncthreads();
-    if (wave != 0) return;
-    float* __restrict__ o = out + (int64_t)z * slab_stride;
-    if (col < NW) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const float g = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
-            if (THIN_X) o[(int64_t)col * K + k] = g;          // dW[n = col][k]
-            else o[(int64_t)k * K + col] = g;                 // dW[n = k][k' = col]
-        }
-    }
-    if (colsum) {
-        const float g = ((red[0][NT][lane] + red[1][NT][lane]) + red[2][NT][lane]) + red[3][NT][lane];
-        if (THIN_X) {
-            if (col < NW) colsum[(int64_t)z * N + col] = g;
-        } else if (blockIdx.x == 0 && lane < NT) {
-            colsum[(int64_t)z * N + lane] = g;
-        }
-    }
-}
-
-// the thin kernel for one layer's split-M weight gradient, if the layer has a thin side it covers; false: not taken
-static bool launch_wgrad_thin(const float* dZ, int64_t ld_dz, const float* X, int64_t ld_x, int64_t M, int N, int K,
-                              int64_t rows_per_slab, int zs, float* out, float* colsum, hipStream_t s) {
-    if (zs < 1 || zs > 65535) return false;
-    if (K == 13 && N >= 64) {
-        hipLaunchKernelGGL((k_wgrad_thin<13, true>), dim3((unsigned)cdiv(N, 64), (unsigned)zs), dim3(256), 0, s, dZ, ld_dz, N, X,
-                           ld_x, M, rows_per_slab, out, (int64_t)N * K, colsum, N, K);
-        return true;
-    }
-    if (N == 1 && K >= 64) {
-        hipLaunchKernelGGL((k_wgrad_thin<1, false>), dim3((unsigned)cdiv(K, 64), (unsigned)zs), dim3(256), 0, s, X, ld_x, K, dZ,
-                           ld_dz, M, rows_per_slab, out, (int64_t)N * K, colsum, N, K);
-        return true;
-    }
-    return false;
-}
-
+// (Round 4 built the two layers with a thin side -- the 13-wide first layer and the 1-wide output layer -- as vector-ALU
+//  reductions over the batch: lanes <-> columns of the wide operand, the thin operand's rows staged in LDS and read back as
+//  broadcasts, sixteen rows in flight per wave, the four waves of a workgroup summed through LDS in a fixed order, into the same
+//  split-M slabs.  Parity-green, 12.5 / 11.4 us stand-alone with their reductions at M = 8192 -- and a TIE in the step against
+//  the LDS-free MFMA kernel they were to replace: 0.6125 against 0.6113 ms (13-wide), 0.6148 against 0.6146 (1-wide), same box,
+//  same process, tools/ab_step.py.  Where these launches sit -- the end of the backward, three queues deep -- a kernel's
+//  duration is set by what runs beside it (30 us in the trace for either version), not by its own instruction mix.  Removed.)
 // Weight (and bias) gradients of SEVERAL layers at once, from the pre-activation gradients dZ[i] that the dgrad chain
 // left behind (cdlrm_linear_bwd with dW = NULL): dW[i] = dZ[i]^T X[i], db[i] = column sums of dZ[i].
 // Small batches: all layers in one grouped launch of the LDS-free kernel (no slabs, no reduction); long batches: the
@@ -551,6 +461,7 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
             r.gxa = (int)gxa;
             r.partB = cs; r.countB = db[li] ? N[li] : 0; r.outB = db[li];
             r.splits = zs;
+            r.novec = g_cdlrm_debug[2];
             r.pA = P_w ? P_w[li] : nullptr; r.pB = (P_w && P_b && db[li]) ? P_b[li] : nullptr; r.lr = lr;
             if (P_w) stepped[li] = 1;
             jobs.push_back(r);
@@ -630,11 +541,11 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
             r.gxa = (int)gxa;
             r.partB = cs; r.countB = db[i] ? N[i] : 0; r.outB = db[i];
             r.splits = zs;
+            r.novec = g_cdlrm_debug[2];
             r.pA = P_w ? P_w[i] : nullptr; r.pB = (P_w && P_b && db[i]) ? P_b[i] : nullptr; r.lr = lr;
             if (P_w) stepped[i] = 1;
             jobs.push_back(r);
         }
-        if (launch_wgrad_thin(dZ[i], ld_dz[i], X[i], ld_x[i], M, N[i], K[i], g.kchunk, zs, g.C, g.colsum, s)) continue;
         int rc = launch_gemm<false, false>(g, zs, s);
         if (rc) return rc;
     }

@@ -290,12 +290,23 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
                                                   float4* __restrict__ weight, const uint64_t* __restrict__ keys,
                                                   int64_t n, float lr, const float4* __restrict__ partials,
                                                   int64_t pstride, const int64_t* __restrict__ longlist,
-                                                  const int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
+                                                  int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
                                                   int64_t aux_total, const int32_t* __restrict__ runend) {
     const int c = threadIdx.x % LPR;
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
     const int cnt = *longcount;
+    // The list counter lives in the context (zero at creation) and is left zero by the LAST workgroup of this kernel to
+    // finish -- every workgroup has read it by then --, so no clearing launch sits in front of the next backward (a 4-byte
+    // hipMemsetAsync is a 5.4 us kernel of its own on the queue).  longcount[2] counts the workgroups that are through.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int through = atomicAdd(longcount + 2, 1);
+        if (through == (int)gridDim.x - 1) {
+            atomicExch(longcount, 0);
+            atomicExch(longcount + 2, 0);
+        }
+    }
     for (int li = blockIdx.x * gpb + gid; li < cnt; li += gridDim.x * gpb) {
         const int64_t e = longlist[li];
         const int t = (int)(e >> 40);
@@ -456,7 +467,7 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     const int gpb = 256 / lpr;
     BwdWork w = carve(work, T, n, ctx->D);
     const uint64_t* cur = sorted_in_B(n) ? w.keysB : w.keysA;
-    CDLRM_HIP_CHECK(hipMemsetAsync(w.longcount, 0, sizeof(int32_t), s));
+    w.longcount = reinterpret_cast<int32_t*>(ctx->d_small + 16);       // self-resetting (k_bwd_long), zero since ctx creation
     int64_t gx = cdiv(n, gpb);
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)T);

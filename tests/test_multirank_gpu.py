@@ -491,5 +491,5 @@ def test_c5_flow_two_ranks_vs_oracle():
             # (eight steps at lr = 0.8 on 8192-sample gradients: weights of magnitude ~0.05 agree to ~1e-5 absolute)
             np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=2e-4, atol=5e-5)
             assert np.array_equal(got[r]["top_w"][i], got[0]["top_w"][i])
-    for k in range(len(ln_emb)):
-        np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=1e-6)
+    for k in range(len(ln_emb)):        # (evicted rows carry eight steps of lr = 0.8 updates in another summation order)
+        np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=2e-5)

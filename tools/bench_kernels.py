@@ -184,7 +184,7 @@ def main():
 
     if want("thin"):
         # the layers with a thin side: 13-wide input (forward on the vector ALU, weights in registers), and the weight gradients
-        # of the 13-wide and the 1-wide layer (vector-ALU reductions over the batch + the grouped slab reduction)
+        # of the 13-wide and the 1-wide layer (LDS-free MFMA kernel + the grouped slab reduction)
         X = torch.randn(B, 13, device=DEV)
         W = torch.randn(512, 13, device=DEV) / 3.6
         b = torch.randn(512, device=DEV)

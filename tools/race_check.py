@@ -23,6 +23,8 @@ VARIANTS = {
     "one lane": {"tape_lanes": 1},
     "recorded events": {"attach_events": False},
     "wait on the training queue": {"fold_top_wait": False},
+    "early take (next batch's take + sort at the head of the step)": {"early_take": True},
+    "unchained take (round-1 schedule)": {"chain_take": False},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
 }
@@ -55,8 +57,10 @@ def run(a, knobs, host):
         eng.finish()
     torch.cuda.synchronize()
     cg.ctx.check()
-    out = (float(eng._buffers(B)["loss"][0]), eng.param_flat.clone(), cg.weight.data.sum(dtype=torch.float64).item(),
-           cg.tags.clone(), eng.stat_acc.clone())
+    # (cache rows only: which aux region a batch's miss rows pass through differs between the take schedules)
+    rows = sum(cg.emb_l[k].weight.data[: cg.num_ways * cg.cache_sizes[k]].sum(dtype=torch.float64).item()
+               for k in range(len(cg.cache_sizes)))
+    out = (float(eng._buffers(B)["loss"][0]), eng.param_flat.clone(), rows, cg.tags.clone(), eng.stat_acc.clone())
     del wl, eng, pipe, syn, cg
     torch.cuda.empty_cache()
     return out
