@@ -120,7 +120,6 @@ PROTOTYPES = {
     "cdlrm_tape_replay": (C.c_int, [vp]),
     "cdlrm_tape_set_lanes": (C.c_int, [vp, vp, vp, c_i64]),
     "cdlrm_tape_selftest": (C.c_int, []),
-    "cdlrm_delay_us": (C.c_int, [c_f32, vp]),
     "cdlrm_event_record": (C.c_int, [vp, vp]),
     "cdlrm_stream_wait_event": (C.c_int, [vp, vp]),
     "cdlrm_event_attach_next": (C.c_int, [vp, vp]),

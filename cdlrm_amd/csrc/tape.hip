@@ -91,7 +91,6 @@ static TapeEntry tape_entry_at(R (*f)(A...), const char* name, int32_t stream_ar
 extern "C" int cdlrm_tape_probe(float f0, int64_t a0, float f1, int32_t a1, void* a2, int64_t a3, float f2, int32_t a4,
                                 int64_t a5, int64_t a6, void* a7, int32_t a8, float f3, int64_t a9);
 extern "C" int cdlrm_tape_probe_log(int64_t tag, int64_t spin);
-extern "C" int cdlrm_delay_us(float us, void* stream);
 
 #define TAPE_FN(f) tape_entry_s(&f, #f)                 /* issues on the stream its last parameter names */
 #define TAPE_FN_AT(f, pos) tape_entry_at(&f, #f, pos)   /* stream at that parameter position; -1: the call issues nothing */
@@ -106,7 +105,7 @@ static const std::vector<TapeEntry>& tape_registry() {
         TAPE_FN(cdlrm_sgd_step), TAPE_FN(cdlrm_sgd_step2), TAPE_FN(cdlrm_scale_div),
         TAPE_FN_AT(cdlrm_ctx_time_next_gather, -1),      // arms the NEXT gather launch: no stream of its own
         TAPE_FN_AT(cdlrm_event_record, 1), TAPE_FN_AT(cdlrm_stream_wait_event, 0), TAPE_FN_AT(cdlrm_event_attach_next, 1),
-        TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather), TAPE_FN(cdlrm_agg_scatter), TAPE_FN(cdlrm_delay_us),
+        TAPE_FN(cdlrm_agg_compact), TAPE_FN(cdlrm_agg_gather), TAPE_FN(cdlrm_agg_scatter),
         TAPE_FN_AT(cdlrm_tape_probe, -1), TAPE_FN_AT(cdlrm_tape_probe_log, -1),
     };
     return reg;
@@ -321,30 +320,6 @@ extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
     if (rc0) return rc0;
     for (int l = 1; l < t->lanes; ++l)
         if (t->rc[l]) { cdlrm_set_error("%s", t->err[l]); return t->rc[l]; }
-    return 0;
-}
-
-// A timed gap on a stream: one wave that sleeps until `us` microseconds of the constant-rate clock have passed (bounded: it
-// ends after at most 4 M sleep rounds whatever the clock says).  The training step uses it to start work of the NEXT batch on a
-// side queue a fixed time after the step begins -- behind the roofline kernel at the head of the training queue -- without an
-// event on that queue (an event record or a completion signal there costs the step 6-8 us; this costs it nothing).
-__global__ void __launch_bounds__(64) k_delay(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();
-    for (int i = 0; i < (1 << 22); ++i) {
-        if (wall_clock64() - t0 >= ticks) break;
-        __builtin_amdgcn_s_sleep(16);
-    }
-}
-extern "C" int cdlrm_delay_us(float us, void* stream) {
-    CDLRM_REQUIRE(us >= 0.f && us <= 1e6f, "0 .. 1 s");
-    if (us == 0.f) return 0;
-    int rate_khz = 100000;                  // the constant clock's rate (100 MHz on this part)
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
-    if (rate_khz <= 0) rate_khz = 100000;
-    const unsigned long long ticks = (unsigned long long)((double)us * 1e-3 * (double)rate_khz);
-    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
-    CDLRM_LAUNCH_CHECK();
     return 0;
 }
 

@@ -606,13 +606,6 @@ class TrainEngine:
         self.attach_events = True
         self.fold_top_wait = True               # short batches: the wait for the deferred top-MLP update rides on the side stream
         self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
-        # ... or AHEAD of it (round 4): the chained take + slot sort of batch j + 1 (~100 us on the side queue at the END of
-        # step j, where three queues compete) move to the HEAD of step j, where the side queues idle under the top MLP's GEMMs:
-        # into the OTHER aux region, a second sort scratch, started a fixed time after the step begins (cdlrm_delay_us: behind
-        # the gather, the roofline kernel, without an event on the training queue).  The one event the next gather waits for
-        # is still recorded behind this step's embedding update.
-        self.early_take = False
-        self.early_take_delay_us = None         # None: the gather's expected duration at ~6.3 TB/s + 4 us
         self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
         # WindowResolver hands the NEXT step a look-ahead chunk to resolve (`_pending_resolve`, taken when `mark_next` is set): the
         # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
@@ -782,14 +775,8 @@ class TrainEngine:
                                torch.empty(self.T, dtype=i32, device=self.dev))
         return self._bufs[key]
 
-    def _sort_parity(self) -> bool:
-        """The slot sort's scratch alternates by step (early-take schedule on a cache group with two aux regions)."""
-        return bool(self.early_take) and self.ctx.aux_phases >= 2
-
-    def _emb_work(self, n, parity: int = 0):
-        """Scratch of the embedding backward (sorted keys, chunk partials).  parity: the early-take schedule sorts the NEXT
-        batch's slot ids while this batch's backward still reads its own sorted keys -- two buffers, by step parity."""
-        key = ("emb", n, int(parity))
+    def _emb_work(self, n):
+        key = ("emb", n)
         if key not in self._bufs:
             self._bufs[key] = ops.embbag_bwd_work(self.ctx, n, self.dev)
         return self._bufs[key]
@@ -859,8 +846,6 @@ class TrainEngine:
         self._mark_this = bool(self.mark_next and self._pending_resolve is not None and lS_o is None)
         self.mark_next = False
         self._res, self._next_res = res, (next_res if next_idx is not None else None)
-        if self._pref is not None and self._pref.get("prepared") and self._pref.get("parity", False) != self._sort_parity():
-            self._pref = None       # the schedule knob changed between two steps: this batch is taken (and sorted) again in line
         if lS_o is not None:
             assert lS_o.shape[1] in (B, B + 1) and (not self.multi or lS_o.shape[1] == B)
         if j is None:
@@ -963,7 +948,6 @@ class TrainEngine:
         # deferred top-MLP update -- is all the next step's gather waits for: the main queue carries one wait per step
         # instead of three (probe, top update, embedding update) plus a record, each a 6-8 us bubble (measured).
         chain = self._chain(B, next_idx, lS_o)
-        early = chain and self.early_take and two_phase
         if chain:
             two_phase = False
         if self.defer_top and self.cat:
@@ -987,19 +971,6 @@ class TrainEngine:
             probed = ev["probed_inline"]
             rec(probed.record, side)
         n_bags = B if lS_o is None else lS_o.shape[1]
-        early_res = None
-        if early:
-            # the NEXT batch's take + slot sort, at the head of this step on the side stream (in order behind the previous
-            # step's embedding update, which freed the other aux region), held back until the gather has run
-            ph = 1 - self._phase
-            which = 2 + (self.iter & 1)
-            early_res = self._probe_bufs(n, which)
-            dl = self.early_take_delay_us
-            if dl is None:
-                dl = n * self.T * (8 * D + 16) / 6.3e6 + 4.0
-            ops.delay_us(dl, stream=side)
-            ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], early_res[0], aux_phase=ph, stream=side)
-            ops.embbag_bwd_prepare(ctx, early_res[0], self._emb_work(n, (self.iter + 1) & 1), stream=side)
 
         def gather(st):
             if self._gslot is not None:         # bench.py: the roofline kernel's own start / stop timestamps
@@ -1060,7 +1031,7 @@ class TrainEngine:
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=ph,
                               res=(res[0], res[1], res[2], evp))
         # the backward's sort of the slot ids needs nothing but the probe result: run it on the side, under the MLPs
-        emb_work = self._emb_work(n, (self.iter & 1) if self._sort_parity() else 0)
+        emb_work = self._emb_work(n)
         if not side_gather:
             rec(side.wait_event, probed)
         if not prepared:        # (a chained take sorted this batch's slots right behind itself, in the previous step)
@@ -1174,27 +1145,22 @@ class TrainEngine:
         if next_idx is not None and not two_phase:
             # single aux region: the next batch's fill can only follow this batch's embedding update
             which = 2 + (self.iter & 1)
-            next_phase = 0
-            if early:
-                res, next_phase = early_res, 1 - self._phase      # taken and sorted at the head of this step
-            elif self._next_res is not None:
+            if self._next_res is not None:
                 res = self._probe_bufs(n, which)
                 ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=0, stream=side)
             else:
                 res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
-            if chain and not early:
+            if chain:
                 # ... and the sort of the next batch's slot ids for ITS backward: here it ends well before the step does; issued
                 # by the next step it ran late enough to share HBM with that step's gather (the roofline kernel)
-                ops.embbag_bwd_prepare(ctx, res[0], self._emb_work(n, ((self.iter + 1) & 1) if self._sort_parity() else 0),
-                                       stream=side)
+                ops.embbag_bwd_prepare(ctx, res[0], emb_work, stream=side)
             chained_top = chain and self.defer_top and not self.multi and split is not None
             if chained_top:
                 rec(side.wait_event, ev["top_updated"])     # recorded above, behind this step's top-MLP SGD
             evp = ev["probed"][which]
             rec(evp.record, side)
-            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=next_phase,
-                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain,
-                              parity=self._sort_parity())
+            self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
+                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain)
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
@@ -1301,7 +1267,7 @@ class TrainEngine:
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
-               self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.early_take,
+               self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
@@ -1353,7 +1319,7 @@ class TrainEngine:
                     self.tape_fallbacks.append(str(e))      # this control path replays from Python (bench.py reports it)
             self._tapes[key] = dict(prog=prog, cells=cells, phase=self._phase, native=native,
                                     pref=None if post is None else (post["phase"], post["res"], post.get("chained_top", False),
-                                                                    post.get("prepared", False), post.get("parity", False)))
+                                                                    post.get("prepared", False)))
             return not self.multi
         cells = tape["cells"]
         cells["X"].value = X.data_ptr()
@@ -1390,7 +1356,7 @@ class TrainEngine:
         self._pref = None
         if tape["pref"] is not None:
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1],
-                              chained_top=tape["pref"][2], prepared=tape["pref"][3], parity=tape["pref"][4])
+                              chained_top=tape["pref"][2], prepared=tape["pref"][3])
         return not self.multi
 
     def table_aggregate(self):

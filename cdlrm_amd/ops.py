@@ -553,11 +553,6 @@ def sgd_step2(param: torch.Tensor, grad: torch.Tensor, off0: int, n0: int, off1:
                                      stream_ptr(stream)))
 
 
-def delay_us(us: float, stream=None):
-    """A timed gap on `stream` (one sleeping wave): see cdlrm_delay_us."""
-    check(_lib.lib().cdlrm_delay_us(float(us), stream_ptr(stream)))
-
-
 def scale_div(x: torch.Tensor, divisor: float, stream=None):
     assert x.is_contiguous()
     check(_lib.lib().cdlrm_scale_div(x.data_ptr(), x.numel(), float(divisor), stream_ptr(stream)))

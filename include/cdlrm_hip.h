@@ -465,9 +465,6 @@ int64_t cdlrm_tape_probe_log_take(int64_t* out, int64_t cap);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
 int cdlrm_event_record(void* event, void* stream);
 int cdlrm_stream_wait_event(void* stream, void* event);
-/* A timed gap on `stream`: one wave sleeps until `us` microseconds have passed (bounded).  The step starts the next batch's
- * take on a side queue this long after it begins -- behind the roofline kernel -- without an event on the training queue. */
-int cdlrm_delay_us(float us, void* stream);
 /* `event` completes with the next kernel the calling thread launches on `stream` through cdlrm_linear_bwd or
  * cdlrm_interact_bwd -- attached to that launch as its stop event instead of recorded behind it: a record is a marker packet
  * and a 6-8 us bubble on the training queue, an attached event is free.  If the call cannot attach it (several launches, a

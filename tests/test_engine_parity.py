@@ -110,16 +110,11 @@ def test_loss_trajectory_and_tag_state(golden, name, pipelined, aux_phases, reso
         np.testing.assert_allclose(l.weight.data.cpu().numpy(), g[f"top_w{i}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,defer,chunk,delay,early", [
-    ("train_small", True, 2, False, False), ("train_small", False, 2, False, False), ("train_c1", True, 2, False, False),
-    ("train_stream", True, 2, False, False),
-    # the host far ahead of a slow side stream, a ring slot recycled every 3 steps
-    ("train_c1", True, 1, True, False), ("train_c1", False, 2, True, False),
-    # early take (round 4): the next batch's take + slot sort at the HEAD of the step, into the other aux region and a second
-    # sort scratch, behind a timed gap instead of an event
-    ("train_small", True, 2, False, True), ("train_c1", True, 2, False, True), ("train_stream", False, 2, False, True),
-    ("train_c1", True, 1, True, True)])
-def test_chained_take_long_batch_path(golden, name, defer, chunk, delay, early):
+@pytest.mark.parametrize("name,defer,chunk,delay", [("train_small", True, 2, False), ("train_small", False, 2, False),
+                                                    ("train_c1", True, 2, False), ("train_stream", True, 2, False),
+                                                    # the host far ahead of a slow side stream, a ring slot recycled every 3 steps
+                                                    ("train_c1", True, 1, True), ("train_c1", False, 2, True)])
+def test_chained_take_long_batch_path(golden, name, defer, chunk, delay):
     """The long-batch schedule (gather alone on the main stream, B >= gather_alone_min) on the window-resident probe: the
     next batch's take follows the embedding update on the side stream and the next gather waits for ONE event recorded
     behind it (and behind the deferred top-MLP update).  Forced here at the goldens' small batches; same trajectory,
@@ -134,12 +129,10 @@ def test_chained_take_long_batch_path(golden, name, defer, chunk, delay, early):
                       table_agg_op=eng0.agg_op, defer_top_update=defer)
     eng.gather_alone_min = 1
     assert eng.chain_take
-    eng.early_take = early
     L = int(g["L"])
     batches = make_batches(g)
     dev_idx = [b[1].to(DEV) for b in batches]
     losses, chained = [], 0
-    phases = set()
     for j, (X, lS_i, Tt) in enumerate(batches):
         if j % L == 0:
             win = torch.cat([b[1] for b in batches[j:j + L]], dim=1).to(DEV)
@@ -156,15 +149,12 @@ def test_chained_take_long_batch_path(golden, name, defer, chunk, delay, early):
         loss = eng.step(X.to(DEV), dev_idx[j], Tt.to(DEV), j=j, next_idx=nxt, res=rs.batch(j % L),
                         next_res=rs.batch(j % L + 1) if nxt is not None else None)
         chained += int(eng._pref is not None and bool(eng._pref.get("chained_top")) == (defer and eng.world == 1))
-        if eng._pref is not None:
-            phases.add(eng._pref["phase"])
         rs.ensure(j % L + rs.CH + 2)
         losses.append(loss[0:1].clone())
     eng.finish()
     losses = [float(x) for x in losses]
     cg.ctx.check()
     assert chained >= len(batches) - len(batches) // L - 1
-    assert phases == ({0, 1} if early else {0}), "early takes alternate between the two aux regions"
     np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-5)
     occ = cg.occupancy_tables
     for k in range(len(g["ln_emb"])):

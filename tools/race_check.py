@@ -23,7 +23,6 @@ VARIANTS = {
     "one lane": {"tape_lanes": 1},
     "recorded events": {"attach_events": False},
     "wait on the training queue": {"fold_top_wait": False},
-    "early take (next batch's take + sort at the head of the step)": {"early_take": True},
     "unchained take (round-1 schedule)": {"chain_take": False},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
