@@ -85,6 +85,8 @@ PROTOTYPES = {
     "cdlrm_agg_compact": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, vp]),
     "cdlrm_agg_gather": (C.c_int, [vp, vp, vp, c_f32, vp, c_i64, c_i64, vp]),
     "cdlrm_agg_scatter": (C.c_int, [vp, vp, vp, vp, c_i64, c_i64, vp]),
+    "cdlrm_agg_mark_tier": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, vp, vp]),
+    "cdlrm_agg_split": (C.c_int, [vp, vp, c_i64, vp, c_i32, vp, vp, vp]),
     "cdlrm_interact_fwd": (C.c_int, [vp, c_i64, c_i32, c_i32, c_i32, vp, c_i64, vp]),
     "cdlrm_interact_bwd": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp]),
     "cdlrm_linear_fwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp]),

@@ -775,6 +775,122 @@ extern "C" int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int6
 }
 
 // ---------------------------------------------------------------------------------------------
+// Deadlines for the touched-row merge (round 4).  The merge of step j has to be applied to a row before the first step after
+// j that USES the row on any rank -- not before step j + 1 as a whole.  The look-ahead window says which rows the next batches
+// use (their slot ids are resolved already: cdlrm_window_resolve), so the rows of a merge are classed by the first batch that
+// needs them and exchanged in that order, most of them in the background of the following steps (engine.MergePump).
+//   cdlrm_agg_mark_tier : tier[row] = value for every cache slot a [T, n] view of resolved slot ids names (aux slots skipped);
+//                         the engine calls it class by class from the LATEST deadline to the earliest, so the earliest wins
+//   cdlrm_agg_split     : stable counting sort of the merge's sorted row list by tier byte: rows grouped by class, ascending
+//                         inside a class -- the same list on every rank -- and the class offsets
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mark_tier(const TableDesc* __restrict__ tab, int ways, const int32_t* __restrict__ slots,
+                                                   int64_t n, int64_t ld, uint8_t value, uint8_t* __restrict__ tier) {
+    const int t = blockIdx.y;
+    const int64_t rb = tab[t].row_base, first_aux = tab[t].P * ways;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = slots[(int64_t)t * ld + i];
+        if (s >= 0 && s < first_aux) tier[rb + s] = value;
+    }
+}
+
+extern "C" int cdlrm_agg_mark_tier(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, int64_t ld, int32_t value, uint8_t* tier,
+                                   void* stream) {
+    CDLRM_REQUIRE(ctx && slots && tier && ld >= n && value >= 0 && value <= 255, "bad argument");
+    if (n == 0) return 0;
+    int64_t gx = cdiv(n, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_mark_tier, dim3((unsigned)gx, (unsigned)ctx->T), dim3(256), 0, (hipStream_t)stream, ctx->d_tab, ctx->ways,
+                       slots, n, ld, (uint8_t)value, tier);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+#define SPLIT_PER_BLOCK 1024      // elements per block: 256 threads x 4 consecutive elements
+#define SPLIT_MAX_CLASSES 8
+// per block and class: how many of the block's elements fall into the class; layout class-major [C][nblocks], so that ONE
+// exclusive scan over the whole array yields every (class, block) group's place in the stable counting sort
+__global__ void __launch_bounds__(256) k_split_hist(const int64_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ tier,
+                                                    int C, int64_t nblocks, int64_t* __restrict__ hist) {
+    __shared__ int cnt[SPLIT_MAX_CLASSES];
+    if (threadIdx.x < SPLIT_MAX_CLASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SPLIT_PER_BLOCK + threadIdx.x * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) {
+            int c = tier[rows[base + i]];
+            c = c < C ? c : C - 1;
+            atomicAdd(&cnt[c], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < C) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_split_scatter(const int64_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ tier,
+                                                       int C, int64_t nblocks, const int64_t* __restrict__ scanned,
+                                                       int64_t* __restrict__ rows_out) {
+    __shared__ int smem[32];
+    const int64_t base = (int64_t)blockIdx.x * SPLIT_PER_BLOCK + threadIdx.x * 4;
+    int cls[4];
+    int64_t r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cls[i] = -1;
+        r[i] = 0;
+        if (base + i < n) {
+            r[i] = rows[base + i];
+            const int c = tier[r[i]];
+            cls[i] = c < C ? c : C - 1;
+        }
+    }
+    for (int c = 0; c < C; ++c) {           // (block-uniform trip count: the scans synchronise)
+        int mine = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine += cls[i] == c;
+        int total;
+        int pos = block_excl_scan(mine, smem, &total);
+        const int64_t at = scanned[(int64_t)c * nblocks + blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (cls[i] == c) rows_out[at + pos++] = r[i];
+    }
+}
+
+__global__ void k_split_offsets(const int64_t* __restrict__ scanned, const int64_t* __restrict__ total, int C, int64_t nblocks,
+                                int64_t* __restrict__ class_off) {
+    const int c = threadIdx.x;
+    if (c < C) class_off[c] = scanned[(int64_t)c * nblocks];
+    if (c == C) class_off[C] = *total;
+}
+
+extern "C" int cdlrm_agg_split(cdlrm_ctx* ctx, const int64_t* rows, int64_t count, const uint8_t* tier, int32_t n_classes,
+                               int64_t* rows_out, int64_t* class_off, void* stream) {
+    CDLRM_REQUIRE(ctx && rows && tier && rows_out && class_off && count >= 0, "null argument");
+    CDLRM_REQUIRE(n_classes >= 1 && n_classes <= SPLIT_MAX_CLASSES, "1 .. 8 classes");
+    hipStream_t s = (hipStream_t)stream;
+    if (count == 0) {
+        CDLRM_HIP_CHECK(hipMemsetAsync(class_off, 0, sizeof(int64_t) * (n_classes + 1), s));
+        return 0;
+    }
+    const int64_t nblocks = cdiv(count, SPLIT_PER_BLOCK);
+    // the merge path's own scan scratch (the plan stream may be compacting with ctx->d_scan): [C][nblocks] counts + the total
+    int rc = cdlrm_scan_reserve_agg(ctx, (int64_t)n_classes * nblocks + 2);
+    if (rc) return rc;
+    int64_t* hist = ctx->d_scan_agg;
+    int64_t* total = ctx->d_scan_agg + (int64_t)n_classes * nblocks;
+    hipLaunchKernelGGL(k_split_hist, dim3((unsigned)nblocks), dim3(256), 0, s, rows, count, tier, (int)n_classes, nblocks, hist);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, hist, (int64_t)n_classes * nblocks, total);
+    hipLaunchKernelGGL(k_split_scatter, dim3((unsigned)nblocks), dim3(256), 0, s, rows, count, tier, (int)n_classes, nblocks,
+                       (const int64_t*)hist, rows_out);
+    hipLaunchKernelGGL(k_split_offsets, dim3(1), dim3(64), 0, s, (const int64_t*)hist, (const int64_t*)total, (int)n_classes,
+                       nblocks, class_off);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small generic helpers of the drop-in surface
 // ---------------------------------------------------------------------------------------------
 // dst[index[i], :] = rows[i, :]  or  (dst + rows) / 2   (Prefetcher.eviction_manager, cache_manager.py:57-62)

@@ -507,7 +507,27 @@ class WindowResolver:
         col = (j - c * self.CH) * self.B + self.col0
         if c >= 2 and (c - 2) in self.chunks:       # chunks far behind the training position are not needed any more
             del self.chunks[c - 2]
-        return ws[:, col:col + self.width], wsrc[:, col:col + self.width], ev
+        # (4th entry: where this batch sits in which window -- the engine's row merge looks AHEAD from there, lookahead())
+        return ws[:, col:col + self.width], wsrc[:, col:col + self.width], ev, (self, j)
+
+    def lookahead(self, j: int, kmax: int):
+        """[(k, slot ids of GLOBAL batch j + k -- every rank's lookups --, ready event)] for k = 1, 2, ... while the batch
+        belongs to this window and its chunk's resolve has been issued (at most kmax): the rows the next steps will use."""
+        out = []
+        eng = self.eng
+        for k in range(1, int(kmax) + 1):
+            b = j + k
+            if b >= self.nb:
+                break
+            c = b // self.CH
+            if c >= self.done or c not in self.chunks:
+                break
+            if self._armed is not None and c >= self._armed and getattr(eng, "_pending_resolve", None) is not None:
+                break               # handed to the engine, not yet issued
+            ws, _, ev = self.chunks[c]
+            col = (b - c * self.CH) * self.B
+            out.append((k, ws[:, col:col + self.B], ev))
+        return out
 
 
 class TrainEngine:
@@ -555,12 +575,19 @@ class TrainEngine:
         # rows per chunk of the touched-row merge (32 MB at D = 128: large enough for xGMI bandwidth, small enough that
         # the gather of chunk i+1 hides under the reduction of chunk i)
         self.agg_chunk_rows = 1 << 16
+        # The merge of step j is due, row by row, before the first later step that USES the row (on any rank) -- the look-ahead
+        # window knows those steps --, so only the rows the very next batch needs are exchanged at step j; the others follow in
+        # deadline order over the next steps, `merge_budget_rows` per step beyond what the next step needs (MergePump below).
+        self.lazy_merge = True
+        self.merge_budget_rows = 2 << 16
+        self._pump = None
         self._pref = None
         self._phase = 0                             # aux region of the batch being trained
         self._emb_done = None
         ne = lambda: S.new_event(self.dev)
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
-                            emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne(), fwd_mark=ne(), res_slot=ne())
+                            emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne(), fwd_mark=ne(), res_slot=ne(),
+                            tier_marked=ne())
         if S.is_hip(self.dev):
             # torch creates the HIP event at the first record: give every engine event its handle now (a launch tape stores
             # handles; a wait recorded before the event's first real record would otherwise push that tape back to Python)
@@ -669,6 +696,9 @@ class TrainEngine:
         # the side stream (chained / in-line takes) or on this very stream (two-phase takes: in order)
         rec(ev["res_slot"].record, self.side)
         rec(pst.wait_event, ev["res_slot"])
+        if self.multi:
+            # ... and the row merge's deadline pass (main stream, _pump_start) has read the slot ids it wanted from it
+            rec(pst.wait_event, ev["tier_marked"])
         ops.window_resolve(self.ctx, pr["cols"], pr["lbs"], pr["ws"], pr["wsrc"], stream=pst, batch_len=pr["B"])
         if S.is_hip(self.dev):
             ops.event_record(pr["ev"], pst)       # (a library call: on a launch tape the slot's event handle is a cell)
@@ -790,6 +820,7 @@ class TrainEngine:
         if not self.multi:
             return
         ctx = self.ctx
+        self._pump_finish()         # the refill that follows reads and evicts cache rows: the last merge lands first
         self._agg_alloc()
         self._agg_flags.copy_(self.cg.touched)
         dist.all_reduce(self._agg_flags, op=dist.ReduceOp.MAX, group=self.pg)
@@ -863,6 +894,8 @@ class TrainEngine:
         else:
             self._gslot = (ops.TimingEvent(), ops.TimingEvent())
             gather_events.append(self._gslot)
+        if self._pump is not None:
+            self._pump_wait()       # rows of an earlier merge that THIS step uses have landed
         if res is not None:
             # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
             self.side.wait_event(res[2])
@@ -922,6 +955,8 @@ class TrainEngine:
             self.table_aggregate()
             # the next step's gather may run on the side stream: it has to see the merged rows
             self.side.wait_stream(S.current_stream(self.dev))
+        elif self._pump is not None:
+            self._pump_advance()    # the rows the NEXT step needs, and this step's share of the rest
         self.iter += 1
         return self._buffers(B)["loss"]
 
@@ -1241,6 +1276,7 @@ class TrainEngine:
             S.current_stream(self.dev).wait_event(self._events["top_updated"])
         if self._emb_done is not None:          # a pipelined short-batch step leaves the embedding update un-joined
             S.current_stream(self.dev).wait_event(self._emb_done)
+        self._pump_finish()                     # rows of the last merge that are still on their way
 
     def prediction(self, B: int) -> torch.Tensor:
         """Z of the last step at batch size B as DLRM_Net.forward returns it (clamped under --loss-threshold)."""
@@ -1359,6 +1395,117 @@ class TrainEngine:
                               chained_top=tape["pref"][2], prepared=tape["pref"][3])
         return not self.multi
 
+    # ---- the touched-row merge in deadline order ----------------------------------------------------------------------
+    # broadcast_and_aggregate (main_no_ddp.py:250-292) replaces every row any rank touched since the last merge by its mean
+    # (max, sum) over the ranks, at step j, before step j + 1 runs.  What step j + 1 can observe of that is the rows IT uses;
+    # a row nobody uses before step j + d may be merged any time before step j + d -- it does not change in between on any
+    # rank.  The window's resolved slot ids (WindowResolver.lookahead: every rank's lookups of the next batches) say which
+    # rows the next K steps use: the merge's row list is sorted by the first batch that needs a row (classes: batch 1, 2, 3-4,
+    # 5-8, 9-16, 17-32, later = "cold", due at batch K + 1) and exchanged in that order on the exchange stream -- gather, all-
+    # reduce, scatter per chunk -- a few chunks per step, while the training steps run; a step waits for the chunk that holds
+    # the last row it needs.  At c3 (100 steps x 8192 lookups x 26 tables, Zipf 1.05: 1.86 M rows, 0.95 GB) the next batch
+    # needs 2.3 % of the merge's rows, the next 16 batches 13 %.  Same values as the merge in one piece: every rank builds the
+    # same list from the same flags and the same window, and a row's gather reads what the one-piece merge would have read.
+    MERGE_CLASS_FIRST = (1, 2, 3, 5, 9, 17)     # first batch (after the merge step) of each deadline class; then: cold
+
+    def _pump_start(self, U, buf, scale, rop) -> bool:
+        pos = self._res[3] if (self._res is not None and len(self._res) > 3) else None
+        if pos is None:
+            return False
+        rs, j = pos
+        la = rs.lookahead(j, 32)
+        if not la:
+            return False            # nothing known about the next batch (end of the window): the merge in one piece
+        ctx, main = self.ctx, S.current_stream(self.dev)
+        first = self.MERGE_CLASS_FIRST
+        C = len(first) + 1
+        K = la[-1][0]
+        if ("agg_tier",) not in self._bufs:
+            self._bufs[("agg_tier",)] = (torch.empty(ctx.total_rows, dtype=torch.uint8, device=self.dev),
+                                         torch.empty(ctx.total_rows, dtype=torch.int64, device=self.dev),
+                                         torch.zeros(C + 1, dtype=torch.int64, device=self.dev),
+                                         S.pinned(torch.zeros(C + 1, dtype=torch.int64), self.dev))
+        tier, rows_sorted, off_dev, off_host = self._bufs[("agg_tier",)]
+        tier.fill_(C - 1)
+        seen = set()
+        for k, ws, ev in la:
+            if id(ev) not in seen:
+                main.wait_event(ev)
+                seen.add(id(ev))
+        for c in reversed(range(C - 1)):        # latest deadline first: the earliest class that names a row wins
+            hi = first[c + 1] if c + 1 < len(first) else 33
+            for k, ws, ev in la:
+                if first[c] <= k < hi:
+                    ops.agg_mark_tier(ctx, ws, c, tier)
+        ops.agg_split(ctx, self.agg_rows, U, tier, C, rows_sorted, off_dev)
+        self._events["tier_marked"].record(main)
+        off_host.copy_(off_dev, non_blocking=True)
+        self._agg_counted.record(main)
+        self._agg_counted.synchronize()
+        off = [int(x) for x in off_host.tolist()]
+        ready = S.new_event(self.dev)
+        ready.record(main)
+        self._pump = dict(rows=rows_sorted, U=U, buf=buf, scale=scale, rop=rop, off=off, K=K, step0=self.iter, issued=0,
+                          waited=0, chunks=[], ready=ready)
+        self._pump_advance()
+        return True
+
+    def _pump_need(self, d: int) -> int:
+        """Rows of the pending merge that have to have landed before the d-th step after it."""
+        p = self._pump
+        if d > p["K"]:
+            return p["U"]
+        need = 0
+        for c, f in enumerate(self.MERGE_CLASS_FIRST):
+            if f <= d:
+                need = p["off"][c + 1]
+        return need
+
+    def _pump_issue(self, lo: int, hi: int):
+        p, ctx, comm = self._pump, self.ctx, self.comm
+        with S.on_stream(comm):
+            if not p["chunks"]:
+                comm.wait_event(p["ready"])
+            ops.agg_gather(ctx, p["rows"][lo:], self.agg_count, p["scale"], p["buf"][lo:hi], hi - lo, first=lo)
+            dist.all_reduce(p["buf"][lo:hi], op=p["rop"], group=self.pg)
+            ops.agg_scatter(ctx, p["rows"][lo:], self.agg_count, p["buf"][lo:hi], hi - lo, first=lo)
+            ev = S.new_event(self.dev)
+            ev.record(comm)
+        p["chunks"].append((hi, ev))
+        p["issued"] = hi
+
+    def _pump_advance(self, everything: bool = False):
+        """Issue the chunks the NEXT step needs, plus `merge_budget_rows` of the rest (everything: all of it)."""
+        p = self._pump
+        if p is None:
+            return
+        d_next = self.iter + 1 - p["step0"]
+        target = p["U"] if everything else max(self._pump_need(d_next), min(p["U"], p["issued"] + int(self.merge_budget_rows)))
+        ch = max(1, int(self.agg_chunk_rows))
+        while p["issued"] < target:
+            self._pump_issue(p["issued"], min(target, p["issued"] + ch))
+
+    def _pump_wait(self, everything: bool = False):
+        """The training (and the side) stream wait for the chunk that holds the last row this step needs."""
+        p = self._pump
+        need = p["U"] if everything else self._pump_need(self.iter - p["step0"])
+        if need > p["waited"]:
+            assert p["issued"] >= need, "merge rows this step needs were never issued"
+            for hi, ev in p["chunks"]:
+                if hi >= need:
+                    S.current_stream(self.dev).wait_event(ev)
+                    self.side.wait_event(ev)
+                    p["waited"] = hi
+                    break
+        if p["waited"] >= p["U"]:
+            self._pump = None
+
+    def _pump_finish(self):
+        if self._pump is not None:
+            self._pump_advance(everything=True)
+            self._pump_wait(everything=True)
+            self._pump = None
+
     def table_aggregate(self):
         """broadcast_and_aggregate (main_no_ddp.py:250-292): average the rows any rank touched since the last
         merge.  Slot ids are global, so the union of touched rows is an all-reduce(MAX) of the flag bytes (the reference
@@ -1371,6 +1518,7 @@ class TrainEngine:
             touched.zero_()
             return
         main = S.current_stream(self.dev)
+        self._pump_finish()         # (a merge period shorter than the look-ahead: the previous merge's rows land first)
         dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=self.pg)
         self._agg_alloc()
         U = self._agg_list(touched)                   # consumes (clears) the flags
@@ -1385,6 +1533,8 @@ class TrainEngine:
             scale, rop = 1.0, dist.ReduceOp.MAX
         else:
             raise ValueError(self.agg_op)
+        if self.lazy_merge and self.comm is not None and self._pump_start(U, buf, scale, rop):
+            return
         ch = self.agg_chunk_rows
         nch = (U + ch - 1) // ch
         if nch == 1 or self.comm is None or not S.is_hip(self.dev):

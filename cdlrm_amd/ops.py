@@ -386,6 +386,23 @@ def agg_scatter(ctx: CacheCtx, rows: torch.Tensor, count: torch.Tensor, buf: tor
                                        int(first), stream_ptr(stream)))
 
 
+def agg_mark_tier(ctx: CacheCtx, slots: torch.Tensor, value: int, tier: torch.Tensor, stream=None):
+    """tier[row] = value for every cache slot the [T, n] view of resolved slot ids names (cdlrm_agg_mark_tier)."""
+    assert slots.dtype == torch.int32 and slots.dim() == 2 and slots.shape[0] == ctx.T and slots.stride(1) == 1
+    assert tier.dtype == torch.uint8 and tier.numel() == ctx.total_rows
+    check(_lib.lib().cdlrm_agg_mark_tier(ctx.handle, slots.data_ptr(), slots.shape[1], slots.stride(0), int(value),
+                                         tier.data_ptr(), stream_ptr(stream)))
+
+
+def agg_split(ctx: CacheCtx, rows: torch.Tensor, count: int, tier: torch.Tensor, n_classes: int, rows_out: torch.Tensor,
+              class_off: torch.Tensor, stream=None):
+    """Stable counting sort of the merge's row list by tier byte (cdlrm_agg_split); class_off: int64 [n_classes + 1] on the device."""
+    assert rows.dtype == torch.int64 and rows_out.dtype == torch.int64 and rows_out.numel() >= count
+    assert class_off.dtype == torch.int64 and class_off.numel() >= n_classes + 1
+    check(_lib.lib().cdlrm_agg_split(ctx.handle, rows.data_ptr(), int(count), tier.data_ptr(), int(n_classes), rows_out.data_ptr(),
+                                     class_off.data_ptr(), stream_ptr(stream)))
+
+
 # ---- dense model -------------------------------------------------------------------------------------
 
 def interact_fwd(feat: torch.Tensor, itself: bool, R: torch.Tensor, stream=None):

@@ -313,6 +313,16 @@ int cdlrm_agg_gather(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, 
                      float* buf, int64_t cap, int64_t first, void* stream);
 int cdlrm_agg_scatter(cdlrm_ctx* ctx, const int64_t* rows, const int64_t* count, const float* buf,
                       int64_t cap, int64_t first, void* stream);
+/* Deadlines for the merge: a row only has to be merged before the first later step that USES it on any rank, and the look-ahead
+ * window knows which rows the next batches use.
+ * cdlrm_agg_mark_tier: tier[row] = value for every cache slot named by a [T, n] view (row pitch ld) of RESOLVED slot ids
+ *   (cdlrm_window_resolve's wslots; aux slots are skipped).  Called class by class from the latest deadline to the earliest.
+ * cdlrm_agg_split: stable counting sort of a merge's sorted row list (cdlrm_agg_compact; `count` entries, known to the host)
+ *   by tier byte (values >= n_classes count as the last class): rows_out = the rows grouped by class, ascending inside a class
+ *   -- identical on every rank --, class_off[n_classes + 1] (device) = where each class starts. */
+int cdlrm_agg_mark_tier(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, int64_t ld, int32_t value, uint8_t* tier, void* stream);
+int cdlrm_agg_split(cdlrm_ctx* ctx, const int64_t* rows, int64_t count, const uint8_t* tier, int32_t n_classes,
+                    int64_t* rows_out, int64_t* class_off, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense model: DLRM_Net (model_no_ddp.py:215-316), loss (main_no_ddp.py:212-221), SGD (:375, 415)

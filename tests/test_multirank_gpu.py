@@ -493,3 +493,155 @@ def test_c5_flow_two_ranks_vs_oracle():
             assert np.array_equal(got[r]["top_w"][i], got[0]["top_w"][i])
     for k in range(len(ln_emb)):        # (evicted rows carry eight steps of lr = 0.8 updates in another summation order)
         np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=2e-5)
+
+
+# ---- the touched-row merge in deadline order (engine.MergePump) ----------------------------------------------------------
+LZ = dict(ln_emb=[6000, 90, 11, 2500, 30000], m_spa=16, B=64, L=24, nwin=2, agg=7, ways=4, cache=60, seed=21, alpha=1.15,
+          lr=0.1, lr_emb=0.3, bot=[13, 32, 16], top=[32, 1])
+
+
+def _lz_batches():
+    rng = np.random.RandomState(LZ["seed"] + 1)
+    out = []
+    for _ in range(LZ["L"] * LZ["nwin"]):
+        X = torch.from_numpy(rng.rand(LZ["B"], 13).astype(np.float32))
+        idx = torch.stack([torch.from_numpy((rng.zipf(LZ["alpha"], size=LZ["B"]).astype(np.int64) * 2654435761 % n))
+                           for n in LZ["ln_emb"]])
+        T = torch.from_numpy(np.round(rng.rand(LZ["B"], 1)).astype(np.float32))
+        out.append((X, idx, T))
+    return out
+
+
+def _lz_worker(rank, world, port, host_shared, ret, long_batch):
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        import cdlrm_amd.engine as engine
+        import cdlrm_amd.model_no_ddp as M
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = "cuda:0"
+        torch.cuda.set_device(0)
+        ln_emb, D, B, L = np.array(LZ["ln_emb"]), LZ["m_spa"], LZ["B"], LZ["L"]
+        lbs = B // world
+        nf = len(ln_emb) + 1
+        ln_top = np.array([D + nf * (nf - 1) // 2] + LZ["top"])
+        batches = _lz_batches()
+        host0 = [h.clone() for h in host_shared] if rank == 0 else None
+        outs = {}
+        for lazy in (True, False):
+            dist.barrier()
+            if rank == 0:
+                for h, h0 in zip(host_shared, host0):
+                    h.copy_(h0)
+            dist.barrier()
+            eg = M.Embedding_Table_Group(D, ln_emb, init="empty_meta")
+            for k in range(len(ln_emb)):
+                eg.emb_l[k].weight.data = host_shared[k]
+            eg.register_shared()
+            np.random.seed(LZ["seed"])
+            torch.manual_seed(LZ["seed"])
+            cg = M.Embedding_Table_Cache_Group(D, ln_emb, LZ["cache"], B, LZ["ways"]).to(dev)
+            dl = M.DLRM_Net(np.array(LZ["bot"]), ln_top, "dot", False, True, -1, ln_top.size - 2, 0.0).to(dev)
+            eng = engine.TrainEngine(cg, dl, eg, lr=LZ["lr"], lr_embeds=LZ["lr_emb"], world_size=world, rank=rank,
+                                     table_agg_freq=LZ["agg"], table_agg_op="mean", defer_top_update=True)
+            eng.lazy_merge = lazy
+            eng.agg_chunk_rows, eng.merge_budget_rows = 8, 8       # many small chunks: rows stay on their way for several steps
+            if long_batch:
+                eng.gather_alone_min = 1
+            pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
+            losses, pending, deferred_rows = [], 0, 0
+            for w in range(LZ["nwin"]):
+                wb = batches[w * L:(w + 1) * L]
+                win = torch.cat([b[1] for b in wb], dim=1).to(dev)
+                eng.sync_touched_to_rank0()
+                assert eng._pump is None
+                torch.manual_seed(5000 + w * L)
+                pipe.plan_window(win)
+                pipe.commit()
+                pipe.wait_writeback()
+                rs = engine.WindowResolver(eng, win, B, chunk=4)
+                for jj, (X, idx, T) in enumerate(wb):
+                    col = jj * B + rank * lbs
+                    nxt = win[:, col + B:col + B + lbs] if jj + 1 < L else None
+                    loss = eng.step(X[rank * lbs:(rank + 1) * lbs].to(dev), win[:, col:col + lbs],
+                                    T[rank * lbs:(rank + 1) * lbs].to(dev), j=jj, next_idx=nxt, res=rs.batch(jj),
+                                    next_res=rs.batch(jj + 1) if nxt is not None else None)
+                    rs.ensure(jj + rs.CH + 2)
+                    if eng._pump is not None:
+                        pending += 1
+                        deferred_rows = max(deferred_rows, eng._pump["U"] - eng._pump["issued"])
+                    losses.append(loss[0:1].clone())
+            eng.finish()
+            cg.ctx.check()
+            torch.cuda.synchronize()
+            lin = M._linears(dl.top_l)
+            outs[lazy] = dict(losses=torch.cat(losses).cpu(), tags=cg.tags.cpu().clone(),
+                              rows=[cg.emb_l[k].weight.data[: LZ["ways"] * cg.cache_sizes[k]].cpu().clone() for k in range(len(ln_emb))],
+                              top_w=[l.weight.data.cpu().clone() for l in lin], pending=pending, deferred=deferred_rows)
+        a, b = outs[True], outs[False]
+        assert a["pending"] > 0 and a["deferred"] > 0, "the fixture must leave merge rows on their way across steps"
+        assert b["pending"] == 0
+        assert torch.equal(a["losses"], b["losses"]), "losses differ between the deadline-ordered and the one-piece merge"
+        assert torch.equal(a["tags"], b["tags"])
+        for x, y in zip(a["rows"], b["rows"]):
+            assert torch.equal(x, y), "cache rows"
+        for x, y in zip(a["top_w"], b["top_w"]):
+            assert torch.equal(x, y)
+        ret.put((rank, dict(losses=a["losses"].numpy(), occ=[o.cpu().numpy() for o in cg.occupancy_tables],
+                            top_w=[w.numpy() for w in a["top_w"]], pending=a["pending"])))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        ret.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+@pytest.mark.parametrize("long_batch,port", [(False, 29871), (True, 29872)])
+def test_merge_in_deadline_order_two_ranks(long_batch, port):
+    """engine.MergePump: the touched-row merge of step j (--table-agg-freq 7 inside windows of 24 batches) applied row by row
+    before each row's next use -- the rows the next batch needs at once, the rest in deadline order over the following steps in
+    small chunks -- against (a) the same run with the merge in one piece: bit for bit, losses, tags, cache rows, weights; (b)
+    the oracle's 2-rank emulation of the reference's loop (main_no_ddp.py:387-423): per-rank losses 1e-5, tags exact."""
+    from oracle import cdlrm_oracle as O
+    world = 2
+    ln_emb, D, B, L = LZ["ln_emb"], LZ["m_spa"], LZ["B"], LZ["L"]
+    nf = len(ln_emb) + 1
+    ln_top = np.array([D + nf * (nf - 1) // 2] + LZ["top"])
+    np.random.seed(LZ["seed"])
+    host0 = O.init_host_tables(ln_emb, D)
+    host = [h.clone().share_memory_() for h in host0]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_lz_worker, args=(r, world, port, host, ret, long_batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    torch.set_num_threads(1)
+    tr = O.OracleTrainer(ln_emb, D, np.array(LZ["bot"]), ln_top, cache_size=LZ["cache"], num_ways=LZ["ways"], mini_batch_size=B,
+                         world_size=world, lr=LZ["lr"], lr_embeds=LZ["lr_emb"], lookahead=L, table_agg_freq=LZ["agg"],
+                         table_agg_op="mean", seed=LZ["seed"], host_tables=host0)
+    batches = _lz_batches()
+    lS_o = torch.arange(B // world).repeat(len(ln_emb), 1)
+    for w in range(LZ["nwin"]):
+        wb = batches[w * L:(w + 1) * L]
+        torch.manual_seed(5000 + w * L)
+        tr.refill(torch.cat([b[1] for b in wb], dim=1))
+        for jj, (X, idx, T) in enumerate(wb):
+            tr.step(jj, X, lS_o, idx, T)
+    got = {}
+    for _ in range(world):
+        r, payload = ret.get(timeout=400)
+        assert "error" not in payload, payload["error"]
+        got[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], np.array([l[r] for l in tr.losses]), rtol=1e-5)
+        for k in range(len(ln_emb)):
+            assert np.array_equal(got[r]["occ"][k], tr.occ[k].numpy()), (r, k)
+        for i in range(len(got[r]["top_w"])):
+            np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=1e-4, atol=1e-6)
