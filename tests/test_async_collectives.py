@@ -89,7 +89,7 @@ class AsyncPeers:
         raise AssertionError("the sharded window fetch is not part of this test (shard_fetch=False)")
 
 
-def _train(g, *, world, defer, chunk, agg_freq, agg_op, long_batch=False):
+def _train(g, *, world, defer, chunk, agg_freq, agg_op, long_batch=False, budget=0, skip_pump_wait=False, stats=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_engine_parity import DEV, make_batches
     import cdlrm_amd.engine as engine
@@ -113,6 +113,10 @@ def _train(g, *, world, defer, chunk, agg_freq, agg_op, long_batch=False):
         eng.agg_chunk_rows = chunk
     if long_batch:
         eng.gather_alone_min = 1
+    if budget:
+        eng.merge_budget_rows = budget
+    if skip_pump_wait:              # negative control: steps do not wait for the merge rows they use
+        eng._pump_wait = lambda everything=False: None if not everything else engine.TrainEngine._pump_wait(eng, True)
     batches = make_batches(g)
     dev_idx = [b[1].to(DEV) for b in batches]
     losses = []
@@ -133,6 +137,8 @@ def _train(g, *, world, defer, chunk, agg_freq, agg_op, long_batch=False):
                         next_res=rs.batch(j % L + 1) if (rs is not None and nxt is not None) else None)
         if rs is not None:
             rs.ensure(j % L + rs.CH + 2)
+        if stats is not None and eng._pump is not None:
+            stats["steps_with_rows_on_their_way"] = stats.get("steps_with_rows_on_their_way", 0) + 1
         losses.append(loss[0:1].clone())
     eng.finish()
     cg.ctx.check()
@@ -150,6 +156,42 @@ CASES = {
     # the long-batch schedule (gather alone on the training queue, chained take, window-resident probe), MAX merges
     "long_batch_max": dict(defer=True, chunk=16, agg_freq=2, agg_op="max", long_batch=True),
 }
+
+
+LAZY = dict(defer=True, chunk=4, agg_freq=5, agg_op="mean", long_batch=True, budget=4)
+
+
+@pytest.mark.parametrize("delay", [0, 400000])
+def test_merge_rows_on_their_way_across_steps(golden, monkeypatch, delay):
+    """engine.MergePump under delayed asynchronous collectives: windows of 32 batches, a merge every 5 steps whose rows travel
+    in chunks of 4 over the following steps (exchange stream: gather -> all-reduce -> scatter per chunk) while the steps
+    train; a step waits for the chunk that holds the last row it uses.  Two identical peers: the one-rank engine's bits."""
+    import cdlrm_amd.engine as engine
+    g = golden("train_c1")
+    main = torch.cuda.Stream(priority=-1)
+    stats = {}
+    with torch.cuda.stream(main):
+        plain = _train(g, world=1, **LAZY)
+        peers = AsyncPeers(2, "nccl", delay)
+        monkeypatch.setattr(engine, "dist", peers)
+        multi = _train(g, world=2, stats=stats, **LAZY)
+    assert stats.get("steps_with_rows_on_their_way", 0) >= 10, stats
+    for key in ("losses", "tags", "params", "weight"):
+        assert torch.equal(multi[key], plain[key]), "%s differs from the one-rank run (delay %d)" % (key, delay)
+    np.testing.assert_allclose(multi["losses"].numpy(), g["losses"], rtol=1e-5)
+
+
+def test_the_double_notices_a_step_that_does_not_wait_for_its_merge_rows(golden, monkeypatch):
+    """Negative control of the case above: without the per-step wait a step reads rows whose chunk is still in flight (NaN
+    while the collective owns the buffer, or the un-merged value) and the run leaves the one-rank bits."""
+    import cdlrm_amd.engine as engine
+    g = golden("train_c1")
+    main = torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(main):
+        plain = _train(g, world=1, **LAZY)
+        monkeypatch.setattr(engine, "dist", AsyncPeers(2, "nccl", 400000))
+        multi = _train(g, world=2, skip_pump_wait=True, **LAZY)
+    assert not torch.equal(multi["weight"], plain["weight"])
 
 
 @pytest.mark.parametrize("backend", ["nccl", "other"])
