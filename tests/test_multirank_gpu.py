@@ -374,7 +374,7 @@ def _c5_data():
 
 def _c5_worker(rank, world, port, host_shared, ret):
     import faulthandler
-    faulthandler.dump_traceback_later(400, exit=True)
+    faulthandler.dump_traceback_later(200, exit=True)        # (a stuck rank says where, well inside the runner's patience)
     try:
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
@@ -478,7 +478,7 @@ def test_c5_flow_two_ranks_vs_oracle():
             j += 1
     got = {}
     for _ in range(world):
-        r, payload = ret.get(timeout=500)
+        r, payload = ret.get(timeout=300)
         assert "error" not in payload, payload["error"]
         got[r] = payload
     for p in procs:
