@@ -374,7 +374,11 @@ def _c5_data():
 
 def _c5_worker(rank, world, port, host_shared, ret):
     import faulthandler
-    faulthandler.dump_traceback_later(200, exit=True)        # (a stuck rank says where, well inside the runner's patience)
+    # a stuck rank says where, well inside the runner's patience -- into a file the GPU runner brings back even if it has to
+    # kill the whole run (the parent's captured stderr would be lost with it)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    trace = open(os.path.join(ROOT, "gpurun_out", "c5_flow_rank%d.trace" % rank), "w")
+    faulthandler.dump_traceback_later(200, exit=True, file=trace)
     try:
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
@@ -460,7 +464,7 @@ def test_c5_flow_two_ranks_vs_oracle():
     host = [h.clone().share_memory_() for h in host0]
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_c5_worker, args=(r, world, 29861, host, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, 29865, host, ret)) for r in range(world)]
     for p in procs:
         p.start()
     # the oracle runs while the ranks train
