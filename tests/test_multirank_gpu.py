@@ -458,16 +458,18 @@ def test_c5_flow_two_ranks_vs_oracle():
     D, B, L = C5["D"], C5["B"], C5["L"]
     nf = len(ln_emb) + 1
     ln_top = np.array([D + nf * (nf - 1) // 2] + C5["top"])
-    torch.set_num_threads(16)
     np.random.seed(C5["seed"])
     host0 = O.init_host_tables(ln_emb, D)
     host = [h.clone().share_memory_() for h in host0]
-    ctx = mp.get_context("spawn")
-    ret = ctx.Queue()
-    procs = [ctx.Process(target=_c5_worker, args=(r, world, 29865, host, ret)) for r in range(world)]
-    for p in procs:
-        p.start()
-    # the oracle runs while the ranks train
+    # The oracle first, the ranks afterwards (as the other multi-rank tests do).  Run WHILE the ranks trained, this process's
+    # torch-CPU work crawled inside the full suite (> 200 s instead of 12: sixteen OpenMP threads against the ranks' host threads
+    # on the box's CPU share), the finished ranks sat in their result queue's pipe until their watchdog ended them, and the
+    # half-written results hung the parent.
+    import faulthandler
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    ptrace = open(os.path.join(ROOT, "gpurun_out", "c5_flow_parent.trace"), "w")
+    faulthandler.dump_traceback_later(330, exit=False, file=ptrace)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     tr = O.OracleTrainer(ln_emb, D, np.array(C5["bot"]), ln_top, cache_size=C5["cache"], num_ways=C5["ways"],
                          mini_batch_size=B, world_size=world, lr=C5["lr"], lr_embeds=C5["lr_emb"], lookahead=L,
                          table_agg_freq=C5["agg"], table_agg_op="mean", seed=C5["seed"], host_tables=host0)
@@ -480,6 +482,11 @@ def test_c5_flow_two_ranks_vs_oracle():
             X, T = dense[j]
             tr.step(jj, X, lS_o, win[:, jj * B:(jj + 1) * B], T)
             j += 1
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, 29865, host, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
     got = {}
     for _ in range(world):
         r, payload = ret.get(timeout=300)
@@ -495,6 +502,7 @@ def test_c5_flow_two_ranks_vs_oracle():
             # (eight steps at lr = 0.8 on 8192-sample gradients: weights of magnitude ~0.05 agree to ~1e-5 absolute)
             np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=2e-4, atol=5e-5)
             assert np.array_equal(got[r]["top_w"][i], got[0]["top_w"][i])
+    faulthandler.cancel_dump_traceback_later()
     for k in range(len(ln_emb)):        # (evicted rows carry eight steps of lr = 0.8 updates in another summation order)
         np.testing.assert_allclose(float(host[k].double().sum()), float(tr.host[k].double().sum()), rtol=2e-5)
 
@@ -619,11 +627,6 @@ def test_merge_in_deadline_order_two_ranks(long_batch, port):
     np.random.seed(LZ["seed"])
     host0 = O.init_host_tables(ln_emb, D)
     host = [h.clone().share_memory_() for h in host0]
-    ctx = mp.get_context("spawn")
-    ret = ctx.Queue()
-    procs = [ctx.Process(target=_lz_worker, args=(r, world, port, host, ret, long_batch)) for r in range(world)]
-    for p in procs:
-        p.start()
     torch.set_num_threads(1)
     tr = O.OracleTrainer(ln_emb, D, np.array(LZ["bot"]), ln_top, cache_size=LZ["cache"], num_ways=LZ["ways"], mini_batch_size=B,
                          world_size=world, lr=LZ["lr"], lr_embeds=LZ["lr_emb"], lookahead=L, table_agg_freq=LZ["agg"],
@@ -636,6 +639,11 @@ def test_merge_in_deadline_order_two_ranks(long_batch, port):
         tr.refill(torch.cat([b[1] for b in wb], dim=1))
         for jj, (X, idx, T) in enumerate(wb):
             tr.step(jj, X, lS_o, idx, T)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_lz_worker, args=(r, world, port, host, ret, long_batch)) for r in range(world)]
+    for p in procs:
+        p.start()
     got = {}
     for _ in range(world):
         r, payload = ret.get(timeout=400)
