@@ -147,10 +147,16 @@ class Prefetcher:
     def eviction_manager(emb_tables, eviction_fifo, average_on_writeback, core, timeout):
         """cache_manager.py:49-64: apply queued evictions to the host tables until the queue stays empty for
         `timeout` seconds.  The scatter into the pinned tables is a HIP kernel (rows travel over PCIe)."""
+        # The reference pins its eviction PROCESS to `core` (taskset, cache_manager.py:52); here the manager is a thread of the
+        # trainer process -- or a direct call --, so the calling thread is pinned for the duration of the loop and gets its mask
+        # back afterwards: a caller left on one core would hand that mask to every thread it creates later (an 8-thread torch
+        # CPU region spinning on one core runs ~100x slower: seen in the test suite).
+        prev = None
         try:
+            prev = os.sched_getaffinity(0)
             os.sched_setaffinity(0, {core})
         except OSError:
-            pass
+            prev = None
         ptrs = emb_tables.device_pointers()
         try:
             while True:
@@ -171,6 +177,12 @@ class Prefetcher:
                     done()
         except queue.Empty:
             print('Eviction queue empty longer than expected. Exiting eviction manager...')
+        finally:
+            if prev is not None:
+                try:
+                    os.sched_setaffinity(0, prev)
+                except OSError:
+                    pass
 
     # -- the producer --------------------------------------------------------------------------------
     def window_slices(self):

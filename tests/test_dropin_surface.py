@@ -206,7 +206,11 @@ def test_eviction_manager_writeback_arms(golden, avg):
     host.pin()
     evq = queue.Queue()
     evq.put([(t(g[f"idx_{k}"]), t(g[f"emb_{k}"])) for k in range(2)])
-    Prefetcher.eviction_manager(host, evq, bool(avg), min(os.sched_getaffinity(0)), 1)
+    mask = os.sched_getaffinity(0)
+    Prefetcher.eviction_manager(host, evq, bool(avg), min(mask), 1)
+    # the manager pins its thread to `core` while it runs (cache_manager.py:52 pins its process) and hands the mask back: a
+    # caller left on one core would pass that on to every thread it starts afterwards
+    assert os.sched_getaffinity(0) == mask
     for k in range(2):
         assert torch.equal(host.emb_l[k].weight.data, t(g[f"after_{k}"])), k
 
