@@ -403,6 +403,7 @@ def main():
     eng.finish()
     cg.ctx.check()
     loss = float(eng._bufs[lbs]["loss"][0])
+    pipe.close()            # (a plan launched late in the run may still be gathering rows: never exit under it)
 
     if rank == 0:
         g_us = [e0.elapsed_us(e1) for e0, e1 in ev_pairs]

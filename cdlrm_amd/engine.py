@@ -372,6 +372,15 @@ class WindowPipeline:
             self.written_back.record(self.side)
         self.planned = None
 
+    def close(self):
+        """Wait for a plan that is still in flight (its background thread runs C++ threads of its own; a process that exits
+        under them aborts in teardown).  Call before the process ends; the plan's result is dropped."""
+        w, self._worker = self._worker, None
+        if w is not None:
+            w.join()
+        if S.is_hip(self.dev):
+            self.side.synchronize()
+
     def plan_in_flight(self) -> bool:
         """Is the plan of the next window running right now (its kernels / DMA copies / CPU gather)?  bench.py flags the
         roofline-kernel samples taken beside one."""

@@ -549,6 +549,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 t_excluded += time.time() - t_test
             j += 1
     eng.finish()
+    pipe.close()            # a look-ahead plan past the last window may still be in flight
     torch.cuda.synchronize()
     if args.save_model:
         # --save-model is parsed but never acted on by the reference (main_no_ddp.py:111); here: flush every valid
