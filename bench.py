@@ -85,7 +85,8 @@ def cpu_baseline(cfg, ln_emb_full, seed):
     bounded sample of the same workload: same B, D, MLPs, ways and table count, tables capped at 200k rows and the
     cache at 20k sets so the host state is ~2 GB; 1 refill + L iterations (L sized for 10-30 s of CPU work)."""
     from oracle import cdlrm_oracle as O
-    threads = min(32, os.cpu_count() or 1)
+    from cdlrm_amd.hostmem import cpu_share
+    threads = min(32, cpu_share())
     torch.set_num_threads(threads)
     ln_emb = [min(n, 200000) for n in ln_emb_full]
     B, D = cfg["B"], cfg["D"]
@@ -138,6 +139,7 @@ def build_workload(config, *, lookahead=-1, batch=-1, host=None, seed=123, dev=N
     property checks on the SAME objects the bench times."""
     from cdlrm_amd import synth
     from cdlrm_amd.engine import TrainEngine, WindowPipeline
+    from cdlrm_amd.hostmem import cpu_share
     from cdlrm_amd.model_no_ddp import DLRM_Net, Embedding_Table_Cache_Group
     dev = dev or torch.device("cuda", torch.cuda.current_device())
     cfg = dict(CONFIGS[config])
@@ -170,7 +172,9 @@ def build_workload(config, *, lookahead=-1, batch=-1, host=None, seed=123, dev=N
     # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
     pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=seed, rank=rank, world_size=world,
                           host_gather=True,
-                          gather_threads=max(4, min(32, (os.cpu_count() or 8) // max(1, world))), write_back=write_back)
+                          # CPU threads of the plan's row gather: what the box grants this rank (cgroup quota, not the
+                          # machine's core count), less the threads that issue the step; they run at nice 19
+                          gather_threads=max(4, min(32, cpu_share() // max(1, world) - 3)), write_back=write_back)
     syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=seed, alpha=alpha, device=dev)
     return dict(cfg=cfg, ln_emb=ln_emb, host=host, cg=cg, dl=dl, eng=eng, pipe=pipe, syn=syn, B=B, L=L, D=D)
 

@@ -11,6 +11,26 @@ import torch
 from .model_no_ddp import Embedding_Table_Group
 
 
+def cpu_share() -> int:
+    """CPUs this process may actually use: the cgroup's quota (cpu.max / cfs_quota_us) where there is one, else the affinity
+    mask.  `os.cpu_count()` reports the machine (256 on the GPU box whose containers get 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0 and p > 0:
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def fill_uniform_from_device(dst: torch.Tensor, n_rows: int, device, seed: int, chunk_rows: int = 1 << 21):
     """dst[n, m] ~ U(-sqrt(1/n), sqrt(1/n)) (the reference's init distribution, model_no_ddp.py:70-73), drawn on
     the GPU and copied down in chunks: fast enough for the 96 GB Terabyte-shape tables."""
