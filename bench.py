@@ -269,6 +269,9 @@ def main():
 
     from cdlrm_amd.engine import WindowResolver
     use_resolver = True
+    # look-ahead chunks of the window-resident probe: 16 batches on one rank; 32 at world > 1, where the touched-row merge
+    # orders its rows by the batches resolved ahead of it (34-65 instead of 18-33: the merge's cold part gets twice the time)
+    res_chunk = 16 if world == 1 else 32
     state = {"win": None, "next": None, "w": -1}
     plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
     ev_pairs = []
@@ -315,7 +318,7 @@ def main():
         state["win"], state["next"], state["w"] = state["next"], None, w
         # window-resident probe: the window's lookups are resolved against the new tags once, in chunks ahead of the
         # training position (streamed windows: per chunk, when the chunk is loaded)
-        state["res"] = WindowResolver(eng, state["win"], B) if (use_resolver and not C) else None
+        state["res"] = WindowResolver(eng, state["win"], B, chunk=res_chunk) if (use_resolver and not C) else None
         state["cid"] = None
 
     def run_step(j, timed):
@@ -332,7 +335,7 @@ def main():
             cid, jc = divmod(j, C)
             if state.get("cid") != cid:
                 state["chunk"], state["cid"] = syn.window(cid, C), cid
-                state["res"] = WindowResolver(eng, state["chunk"], B) if use_resolver else None
+                state["res"] = WindowResolver(eng, state["chunk"], B, chunk=res_chunk) if use_resolver else None
             win_t, jloc, nloc = state["chunk"], jc, C
         else:
             win_t, jloc, nloc = state["win"], jj, L

@@ -1410,19 +1410,20 @@ class TrainEngine:
     # a row nobody uses before step j + d may be merged any time before step j + d -- it does not change in between on any
     # rank.  The window's resolved slot ids (WindowResolver.lookahead: every rank's lookups of the next batches) say which
     # rows the next K steps use: the merge's row list is sorted by the first batch that needs a row (classes: batch 1, 2, 3-4,
-    # 5-8, 9-16, 17-32, later = "cold", due at batch K + 1) and exchanged in that order on the exchange stream -- gather, all-
+    # 5-8, 9-16, 17-32, 33-64, later = "cold", due at batch K + 1) and exchanged in that order on the exchange stream -- gather, all-
     # reduce, scatter per chunk -- a few chunks per step, while the training steps run; a step waits for the chunk that holds
     # the last row it needs.  At c3 (100 steps x 8192 lookups x 26 tables, Zipf 1.05: 1.86 M rows, 0.95 GB) the next batch
     # needs 2.3 % of the merge's rows, the next 16 batches 13 %.  Same values as the merge in one piece: every rank builds the
     # same list from the same flags and the same window, and a row's gather reads what the one-piece merge would have read.
-    MERGE_CLASS_FIRST = (1, 2, 3, 5, 9, 17)     # first batch (after the merge step) of each deadline class; then: cold
+    MERGE_CLASS_FIRST = (1, 2, 3, 5, 9, 17, 33)     # first batch (after the merge step) of each deadline class; then: cold
+    MERGE_LOOKAHEAD = 64                            # batches ahead the classes reach (the resolver decides how many are known)
 
     def _pump_start(self, U, buf, scale, rop) -> bool:
         pos = self._res[3] if (self._res is not None and len(self._res) > 3) else None
         if pos is None:
             return False
         rs, j = pos
-        la = rs.lookahead(j, 32)
+        la = rs.lookahead(j, self.MERGE_LOOKAHEAD)
         if not la:
             return False            # nothing known about the next batch (end of the window): the merge in one piece
         ctx, main = self.ctx, S.current_stream(self.dev)
@@ -1442,7 +1443,7 @@ class TrainEngine:
                 main.wait_event(ev)
                 seen.add(id(ev))
         for c in reversed(range(C - 1)):        # latest deadline first: the earliest class that names a row wins
-            hi = first[c + 1] if c + 1 < len(first) else 33
+            hi = first[c + 1] if c + 1 < len(first) else self.MERGE_LOOKAHEAD + 1
             for k, ws, ev in la:
                 if first[c] <= k < hi:
                     ops.agg_mark_tier(ctx, ws, c, tier)

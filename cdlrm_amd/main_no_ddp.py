@@ -466,7 +466,8 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     if cur_win_idx is None:
                         cur_win_idx = window_indices(window)
                     if cur_win_idx.shape[1] == len(window) * args.mini_batch_size:      # whole batches only
-                        resolver = WindowResolver(eng, cur_win_idx, args.mini_batch_size)
+                        # (chunks of 32 batches at world > 1: the row merge orders its rows by the batches resolved ahead)
+                        resolver = WindowResolver(eng, cur_win_idx, args.mini_batch_size, chunk=16 if world == 1 else 32)
                 caching_overhead.append(timer() - start)
                 t_excluded += caching_overhead[-1]
                 if lookahead_plan:
