@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""What does a window plan in the background cost the steps beside it, and which phase of the plan does it?  Trains config c3 in
-blocks of 10 steps (a host synchronisation per block), launches the next window's plan after block 12 and prints every block's
-ms/step next to what the plan thread was doing (its breakdown so far).
+"""What does a window plan in the background cost the steps beside it?  Trains config c3 in blocks of 10 steps, launches the
+next window's plan after block 12 and prints every block's ms/step next to what the plan thread was doing.
 
-    python tools/plan_shadow.py [--threads 32] [--blocks 60]
+A block is timed on the TRAINING streams only (an event behind `eng.finish()` on the training stream): a device-wide
+synchronisation would also wait for the plan's own copies in flight and charge them to the block -- that instrument error sent
+round 4 looking for a 75 ms "stall" that was the plan's 4 GB row copy finishing under the timer.
+
+    python tools/plan_shadow.py [--threads 13] [--blocks 60] [--alpha 1.05]
 """
 import argparse
 import os
@@ -32,7 +35,8 @@ def main():
     eng, pipe, syn, B = wl["eng"], wl["pipe"], wl["syn"], wl["B"]
     if a.threads > 0:
         pipe.gather_threads = a.threads
-    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+    main_stream = torch.cuda.Stream(device=dev, priority=-1)
+    torch.cuda.set_stream(main_stream)
     win, nxt_win = syn.window(0, L), syn.window(1, L)
     pipe.plan_window(win)
     pipe._worker.join()
@@ -44,10 +48,12 @@ def main():
     rs = WindowResolver(eng, win, B)
     j = 0
     print("gather threads %d" % pipe.gather_threads)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for blk in range(a.blocks):
         if blk == 12:
             pipe.plan_window(nxt_win)
-        torch.cuda.synchronize()
+        eng.finish()
+        e0.record(main_stream)
         t0 = time.perf_counter()
         for _ in range(10):
             idx = win[:, j * B:(j + 1) * B]
@@ -57,13 +63,14 @@ def main():
             rs.ensure(j + rs.CH + 2)
             j += 1
         t_issue = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        eng.finish()
+        e1.record(main_stream)
+        e1.synchronize()                 # the training streams only: the plan's copies in flight are not waited for
         bd = pipe._bd or {}
         alive = pipe._worker is not None and pipe._worker.is_alive()
         state = "" if blk < 12 else ("plan thread alive; " if alive else "plan thread done; ") + " ".join(
             "%s=%.0f" % (k, v) for k, v in bd.items() if isinstance(v, float) and v > 0)
-        print("block %2d  %.4f ms/step  (issue %.4f)  %s" % (blk, dt / 10 * 1e3, t_issue / 10 * 1e3, state))
+        print("block %2d  %.4f ms/step  (issue %.4f)  %s" % (blk, e0.elapsed_time(e1) / 10, t_issue / 10 * 1e3, state))
     eng.finish()
     pipe.close()
 
