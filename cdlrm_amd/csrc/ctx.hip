@@ -139,9 +139,9 @@ extern "C" int cdlrm_host_unregister(void* host_ptr) {
 static void host_gather_range(const float* const* tables, const int64_t* idx, const int64_t* off, int T, int D, float* dst,
                               int64_t a, int64_t b, int background) {
     // A worker thread of the plan's row gather runs at the LOWEST scheduling weight (nice 19, this thread only): the gather has
-    // ~2 s of slack per window, the thread that issues the training step has none -- beside 32 gather threads at equal weight on
-    // a 16-CPU share the step took 2.1 ms instead of 0.62 for the ~100 steps the gather lasted (round 4: 0.659 -> XXX ms over a
-    // 3000-step window).
+    // ~2 s of slack per window, the thread that issues the training step has none, and the box grants the process 16 CPUs
+    // (cgroup quota; os.cpu_count() says 256) -- at equal weight beside 32 gather threads the issuing thread would get half a
+    // core for the 0.1-0.2 s a gather lasts.
     if (background) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 19);
     int t = 0;
     const size_t row_bytes = (size_t)D * sizeof(float);
