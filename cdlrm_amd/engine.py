@@ -122,6 +122,7 @@ class WindowPipeline:
         self.host_ptrs = host_tables.device_pointers()
         self.ctx.bind_host_tables(self.host_ptrs)
         self.window_no = 0
+        self._commits = 0
         self.planned = None          # event: plan of the next window is ready
         self.written_back = None     # event: evictions of the last commit are in the host tables
         self.last_offsets = None
@@ -257,8 +258,13 @@ class WindowPipeline:
                         t0 = _time.perf_counter()
                         side.synchronize()
                         self.victims[self._vnext] = vic = None
-                        vic = self.victims[self._vnext] = ops.Victims(
-                            self.ctx, min(self.victim_limit, int(need * 1.1) + 4096))
+                        cap = min(self.victim_limit, int(need * 1.1) + 4096)
+                        vic = self.victims[self._vnext] = ops.Victims(self.ctx, cap)
+                        if self._commits == 0:
+                            # the very first plan: the OTHER buffer is not bound yet either -- size it now, beside a plan nobody
+                            # trains next to, instead of inside the second window (a 40 GB allocation holds the device for ~1 s)
+                            self.victims[self._vnext ^ 1] = None
+                            self.victims[self._vnext ^ 1] = ops.Victims(self.ctx, cap)
                         plan.victims(vic, stream=side, list_only=True)
                         voff = vic.off.cpu().tolist()
                         bd["victims_regrown_ms"] = (_time.perf_counter() - t0) * 1e3
@@ -357,6 +363,7 @@ class WindowPipeline:
             dist.all_gather_into_tensor(full, full[self.rank * chunk:(self.rank + 1) * chunk], group=self.pg)
         self._exchange = []
         self.plan.commit(stream=main)
+        self._commits += 1
         if self.victims is not None:
             # from here on the per-iteration probe serves misses from this window's resident victim rows (the buffer
             # of the previous window is free for the next plan: every probe that read it is ordered before this point)

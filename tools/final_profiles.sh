@@ -20,10 +20,10 @@ run default_n1
 run c3_batch1024_n1 --batch 1024 --steps 1000 --warmup 100 --no-cpu-baseline
 run c2_n1 --config c2 --steps 600 --warmup 50 --no-cpu-baseline
 run c4_capped_n1 --config c4 --max-ind-range 2000000 --steps 300 --warmup 50 --no-cpu-baseline
-run c3_a0_whole_window_n1 --alpha 0 --steps 3000 --warmup 100 --no-cpu-baseline
+run c3_a0_whole_window_n1 --alpha 0 --steps 3000 --no-cpu-baseline
 run c3_batch4096_n1 --batch 4096 --steps 1000 --warmup 100 --no-cpu-baseline
 run c3_batch2048_n1 --batch 2048 --steps 1000 --warmup 100 --no-cpu-baseline
-if [ -n "$C5" ]; then run c5_whole_window_n1 --config c5 --steps 8000 --warmup 100 --no-cpu-baseline; fi
+if [ -n "$C5" ]; then run c5_whole_window_n1 --config c5 --steps 8000 --no-cpu-baseline; fi
 fi
 if [ "${PART:-all}" = lines ]; then ls -la $OUT; exit 0; fi
 echo "== rocprofv3 passes (c3)"
