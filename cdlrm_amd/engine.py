@@ -595,7 +595,11 @@ class TrainEngine:
         # window knows those steps --, so only the rows the very next batch needs are exchanged at step j; the others follow in
         # deadline order over the next steps, `merge_budget_rows` per step beyond what the next step needs (MergePump below).
         self.lazy_merge = True
-        self.merge_budget_rows = 2 << 16
+        # per step, beyond what the next step needs: max(this, the rank's lookups per step) rows -- 32 MB at c3's per-rank batch,
+        # 109 MB at c5's: about one step's length of xGMI time at ring rates, so that the next step's gradient exchange (same
+        # communicator stream) finds the stream free; a c3 merge drains in ~29 steps, a c5 merge in ~41 (look-ahead: 34-65)
+        self.merge_budget_rows = 1 << 16
+        self.merge_budget_auto = True           # (tests switch the per-step-lookups floor off to keep rows on their way)
         self._pump = None
         self._pref = None
         self._phase = 0                             # aux region of the batch being trained
@@ -1462,8 +1466,11 @@ class TrainEngine:
         off = [int(x) for x in off_host.tolist()]
         ready = S.new_event(self.dev)
         ready.record(main)
+        budget = int(self.merge_budget_rows)
+        if self.merge_budget_auto:
+            budget = max(budget, int(self._res[0].shape[1]) * self.T)
         self._pump = dict(rows=rows_sorted, U=U, buf=buf, scale=scale, rop=rop, off=off, K=K, step0=self.iter, issued=0,
-                          waited=0, chunks=[], ready=ready)
+                          waited=0, chunks=[], ready=ready, budget=budget)
         self._pump_advance()
         return True
 
@@ -1497,7 +1504,7 @@ class TrainEngine:
         if p is None:
             return
         d_next = self.iter + 1 - p["step0"]
-        target = p["U"] if everything else max(self._pump_need(d_next), min(p["U"], p["issued"] + int(self.merge_budget_rows)))
+        target = p["U"] if everything else max(self._pump_need(d_next), min(p["U"], p["issued"] + p["budget"]))
         ch = max(1, int(self.agg_chunk_rows))
         while p["issued"] < target:
             self._pump_issue(p["issued"], min(target, p["issued"] + ch))

@@ -114,7 +114,7 @@ def _train(g, *, world, defer, chunk, agg_freq, agg_op, long_batch=False, budget
     if long_batch:
         eng.gather_alone_min = 1
     if budget:
-        eng.merge_budget_rows = budget
+        eng.merge_budget_rows, eng.merge_budget_auto = budget, False
     if skip_pump_wait:              # negative control: steps do not wait for the merge rows they use
         eng._pump_wait = lambda everything=False: None if not everything else engine.TrainEngine._pump_wait(eng, True)
     batches = make_batches(g)

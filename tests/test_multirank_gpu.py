@@ -561,7 +561,7 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch):
             eng = engine.TrainEngine(cg, dl, eg, lr=LZ["lr"], lr_embeds=LZ["lr_emb"], world_size=world, rank=rank,
                                      table_agg_freq=LZ["agg"], table_agg_op="mean", defer_top_update=True)
             eng.lazy_merge = lazy
-            eng.agg_chunk_rows, eng.merge_budget_rows = 8, 8       # many small chunks: rows stay on their way for several steps
+            eng.agg_chunk_rows, eng.merge_budget_rows, eng.merge_budget_auto = 8, 8, False     # small chunks: rows stay on their way
             if long_batch:
                 eng.gather_alone_min = 1
             pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
