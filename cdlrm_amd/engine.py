@@ -915,6 +915,12 @@ class TrainEngine:
             self._gslot = (ops.TimingEvent(), ops.TimingEvent())
             gather_events.append(self._gslot)
         if self._pump is not None:
+            # the deadlines of a pending merge were computed for the batches FOLLOWING the merge step in its window: a step that
+            # is not the expected next batch of that window (another resolver, a jump) gets the whole merge first
+            p, pos = self._pump, (res[3] if (res is not None and len(res) > 3) else None)
+            if pos is None or pos[0] is not p["rs"] or pos[1] != p["j0"] + (self.iter - p["step0"]):
+                self._pump_finish()
+        if self._pump is not None:
             self._pump_wait()       # rows of an earlier merge that THIS step uses have landed
         if res is not None:
             # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
@@ -1470,7 +1476,7 @@ class TrainEngine:
         if self.merge_budget_auto:
             budget = max(budget, int(self._res[0].shape[1]) * self.T)
         self._pump = dict(rows=rows_sorted, U=U, buf=buf, scale=scale, rop=rop, off=off, K=K, step0=self.iter, issued=0,
-                          waited=0, chunks=[], ready=ready, budget=budget)
+                          waited=0, chunks=[], ready=ready, budget=budget, rs=rs, j0=j)
         self._pump_advance()
         return True
 
