@@ -116,6 +116,7 @@ PROTOTYPES = {
     "cdlrm_tape_cells": (vp, [vp]),
     "cdlrm_tape_length": (c_i64, [vp]),
     "cdlrm_tape_stream_arg": (c_i32, [vp]),
+    "cdlrm_tape_op_info": (C.c_char_p, [vp, c_i64, vp]),
     "cdlrm_tape_probe": (C.c_int, [c_f32, c_i64, c_f32, c_i32, vp, c_i64, c_f32, c_i32, c_i64, c_i64, vp, c_i32, c_f32, c_i64]),
     "cdlrm_tape_probe_log": (C.c_int, [c_i64, c_i64]),
     "cdlrm_tape_probe_log_take": (c_i64, [vp, c_i64]),
@@ -302,6 +303,16 @@ class NativeTape:
         addr = L.cdlrm_tape_cells(h) if order else None     # (a tape without cells has no cell array)
         self._cells = (C.c_int64 * len(order)).from_address(addr) if addr else None
         self._replay = L.cdlrm_tape_replay
+
+    def op_times(self):
+        """Development (tools/host_time.py): per recorded op (name, lane, replays timed, us per replay inside the call, us per
+        replay waiting for another lane, us of the longest call) -- the clocks run while `cdlrm_debug_set(3, 1)` is on."""
+        L, out, res = raw(), (C.c_int64 * 5)(), []
+        for k in range(int(L.cdlrm_tape_length(self._h))):
+            name = L.cdlrm_tape_op_info(self._h, k, out)
+            n = max(1, int(out[1]))
+            res.append((name.decode() if name else "?", int(out[0]), int(out[1]), out[2] / n / 1e3, out[3] / n / 1e3, out[4] / 1e3))
+        return res
 
     def _translate(self, fn, args, torch):
         if getattr(fn, "argtypes", None) is not None:

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <condition_variable>
 #include <mutex>
@@ -122,6 +123,9 @@ struct TapeOp {
     float fargs[TAPE_MAX_FLT];
     int32_t lane = 0;       // 0: issued by the replaying thread, 1 .. 3: by that helper thread (cdlrm_tape_set_lanes)
     int32_t dep = -1;       // tape index of an op of ANOTHER lane that has to be issued before this one (-1: none)
+    const char* name = "";
+    // development (cdlrm_debug_set(3, 1); tools/host_time.py): host time of this op's call / of its wait for `dep`, summed
+    int64_t call_ns = 0, wait_ns = 0, calls = 0, max_ns = 0;
 };
 
 struct cdlrm_tape {
@@ -164,6 +168,7 @@ extern "C" int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int6
     TapeOp o;
     o.fn = fn;
     o.invoke = e->invoke;
+    o.name = e->name;
     o.n_int = n_int; o.n_flt = n_flt;
     for (int i = 0; i < TAPE_MAX_INT; ++i) {
         o.iargs[i] = i < n_int ? iargs[i] : 0;
@@ -178,6 +183,17 @@ extern "C" int cdlrm_tape_add(cdlrm_tape* t, void* fn, int32_t n_int, const int6
 extern "C" int64_t* cdlrm_tape_cells(cdlrm_tape* t) { return t ? t->cells.data() : nullptr; }
 
 extern "C" int64_t cdlrm_tape_length(cdlrm_tape* t) { return t ? (int64_t)t->ops.size() : -1; }
+
+// development: what op k of a tape is and what it has cost the issuing thread (cdlrm_debug_set(3, 1) switches the clocks on):
+// out[0] = lane, out[1] = calls timed, out[2] = ns inside the call, out[3] = ns waiting for another lane's op, out[4] = the
+// longest single call.  Returns the
+// entry point's name (nullptr: no such op).
+extern "C" const char* cdlrm_tape_op_info(cdlrm_tape* t, int64_t k, int64_t* out) {
+    if (!t || !out || k < 0 || k >= (int64_t)t->ops.size()) return nullptr;
+    const TapeOp& o = t->ops[(size_t)k];
+    out[0] = o.lane; out[1] = o.calls; out[2] = o.call_ns; out[3] = o.wait_ns; out[4] = o.max_ns;
+    return o.name;
+}
 
 // position of the stream parameter of a registered entry point (-1: the call issues nothing itself, -2: not registered)
 extern "C" int32_t cdlrm_tape_stream_arg(void* fn) {
@@ -198,20 +214,28 @@ extern "C" int32_t cdlrm_tape_stream_arg(void* fn) {
 // ordered).  Dependencies point backwards in tape order: no cycles, no lost wake-ups.
 static inline void tape_pause() { __builtin_ia32_pause(); }
 
+static inline int64_t tape_now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static int tape_run_lane(cdlrm_tape* t, int lane) {
     const int64_t* cells = t->cells.data();
     const int n = (int)t->ops.size();
+    const bool timed = g_cdlrm_debug[3] != 0;
     int rc = 0;
     for (int k = 0; k < n; ++k) {
-        const TapeOp& o = t->ops[k];
+        TapeOp& o = t->ops[k];
         if (o.lane != lane) continue;
+        const int64_t t0 = timed ? tape_now_ns() : 0;
         if (o.dep >= 0) {
             const std::atomic<int>& other = t->done[t->ops[o.dep].lane];
             while (other.load(std::memory_order_acquire) < o.dep) tape_pause();
         }
+        const int64_t t1 = timed ? tape_now_ns() : 0;
         int64_t a[TAPE_MAX_INT];
         for (int i = 0; i < TAPE_MAX_INT; ++i) a[i] = o.cell[i] >= 0 ? cells[o.cell[i]] : o.iargs[i];
         rc = tape_call(o, a);
+        if (timed) { const int64_t d = tape_now_ns() - t1; o.wait_ns += t1 - t0; o.call_ns += d; ++o.calls; if (d > o.max_ns) o.max_ns = d; }
         if (rc) break;
         t->done[lane].store(k, std::memory_order_release);
     }
@@ -296,10 +320,13 @@ extern "C" int cdlrm_tape_replay(cdlrm_tape* t) {
     CDLRM_REQUIRE(t, "null tape");
     if (t->lanes <= 1) {
         const int64_t* cells = t->cells.data();
-        for (const TapeOp& o : t->ops) {
+        const bool timed = g_cdlrm_debug[3] != 0;
+        for (TapeOp& o : t->ops) {
             int64_t a[TAPE_MAX_INT];
             for (int i = 0; i < TAPE_MAX_INT; ++i) a[i] = o.cell[i] >= 0 ? cells[o.cell[i]] : o.iargs[i];
+            const int64_t t0 = timed ? tape_now_ns() : 0;
             const int rc = tape_call(o, a);
+            if (timed) { const int64_t d = tape_now_ns() - t0; o.call_ns += d; ++o.calls; if (d > o.max_ns) o.max_ns = d; }
             if (rc) return rc;
         }
         return 0;

@@ -607,7 +607,7 @@ class TrainEngine:
         ne = lambda: S.new_event(self.dev)
         self._events = dict(probed={k: ne() for k in range(4)}, probed_inline=ne(), gathered=ne(), interacted=ne(),
                             emb_done=ne(), wgrad_done=ne(), top_dz=ne(), top_updated=ne(), fwd_mark=ne(), res_slot=ne(),
-                            tier_marked=ne())
+                            tier_marked=ne(), bot_dz=ne(), bot_wg=ne())
         if S.is_hip(self.dev):
             # torch creates the HIP event at the first record: give every engine event its handle now (a launch tape stores
             # handles; a wait recorded before the event's first real record would otherwise push that tape back to Python)
@@ -654,6 +654,11 @@ class TrainEngine:
         self.fold_top_wait = True               # short batches: the wait for the deferred top-MLP update rides on the side stream
         self.chain_take = True                  # long batches: the next batch's take rides behind the embedding update
         self.fuse_sgd = True                    # one rank: the dense SGD rides in the weight gradients' reduction pass
+        # one rank, long batches: where the top MLP's weight gradients start -- "top_dz" (behind the top MLP's input-gradient
+        # chain, beside the interaction backward and the bottom MLP's backward), "interacted", "bot_dz" (behind the bottom MLP's
+        # input-gradient chain) or "bot_wg" (behind the bottom MLP's weight gradients: they then run into the next step's
+        # bottom MLP, gather and interaction forward, which leave the MFMA idle)
+        self.top_wgrad_after = "top_dz"
         # WindowResolver hands the NEXT step a look-ahead chunk to resolve (`_pending_resolve`, taken when `mark_next` is set): the
         # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
         # stream --, so the resolve (random 128-B tag reads) runs beside the top MLP's GEMMs, which leave HBM idle, instead of
@@ -1177,10 +1182,16 @@ class TrainEngine:
         #  0.675 ms: the saved bubble is worth less than the 57 us the weight gradients start later.  The interaction backward
         #  split by rows -- the dense feature's row as its own launch, the rest on the side queue -- measured slower too, 0.718
         #  vs 0.663 ms.  Both schedules were removed in round 3.)
+        late = "top_dz"
+        if split is not None and self.defer_top and not self.multi and not self.cat:
+            late = self.top_wgrad_after
+            if late == "bot_dz" and len(self.bot) < 2:
+                late = "interacted"
         if split is not None:
             if not (attach and n_top - (1 if fused_head else 0) > 0):
                 rec(ev["top_dz"].record, main)
-            top_wgrad(ev["top_dz"])
+            if late == "top_dz":
+                top_wgrad(ev["top_dz"])
         if self.cat:
             # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
             # derivative (the dot path applies it in the interaction backward's epilogue)
@@ -1194,6 +1205,8 @@ class TrainEngine:
         if not attach or self.cat:
             rec(ev["interacted"].record, main)
         rec(side.wait_event, ev["interacted"])
+        if late == "interacted":
+            top_wgrad(ev["interacted"])
         if fused_head and not self.loss_sync:
             # the head's partial sums -> loss buffer + running statistics, off the training queue.  The next head kernel
             # overwrites the partials only behind the next gather, which is ordered behind this stream's embedding update
@@ -1215,7 +1228,9 @@ class TrainEngine:
                 # ... and the sort of the next batch's slot ids for ITS backward: here it ends well before the step does; issued
                 # by the next step it ran late enough to share HBM with that step's gather (the roofline kernel)
                 ops.embbag_bwd_prepare(ctx, res[0], emb_work, stream=side)
-            chained_top = chain and self.defer_top and not self.multi and split is not None
+            # (weight gradients that start later are waited for by the next step's training queue, in front of its
+            #  interaction forward: they may run beside the next gather)
+            chained_top = chain and self.defer_top and not self.multi and split is not None and late == "top_dz"
             if chained_top:
                 rec(side.wait_event, ev["top_updated"])     # recorded above, behind this step's top-MLP SGD
             evp = ev["probed"][which]
@@ -1226,9 +1241,15 @@ class TrainEngine:
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
             dX = buf["bot_dy"][i - 1]
+            if i == 1 and late == "bot_dz" and attach:
+                ops.event_attach_next(ev["bot_dz"], main)
             ops.linear_bwd(bot_acts[i], self.W[l], bot_acts[i + 1], dY, dX, None, None, 0,
                            buf["lin_work"], x_act=self.bot[i - 1][1])
             dY = dX
+        if late == "bot_dz":
+            if not attach:
+                rec(ev["bot_dz"].record, main)
+            top_wgrad(ev["bot_dz"])
         sgd_included = False
         if split is not None:
             split[0].set_x(0, X)
@@ -1240,6 +1261,9 @@ class TrainEngine:
                 if not fused:
                     ops.sgd_step2(self.param_flat, self.grad_flat, *self.rng_bot, self.lr)
                 sgd_included = True
+            if late == "bot_wg":
+                rec(ev["bot_wg"].record, main)
+                top_wgrad(ev["bot_wg"])
         else:
             plan = buf["wgrad"]
             plan.set_x(0, X)
@@ -1329,7 +1353,7 @@ class TrainEngine:
                bool(hit and pref.get("chained_top")), bool(hit and pref.get("prepared")),
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
-               self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait,
+               self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.top_wgrad_after,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)

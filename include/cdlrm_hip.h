@@ -457,6 +457,9 @@ int64_t cdlrm_tape_length(cdlrm_tape* t);
 /* position, in fn's parameter list, of the stream the call issues on (the library's convention is "last parameter"; the
  * event / stream calls below differ); -1: the call issues nothing itself; -2: fn is not a registered tape entry point */
 int32_t cdlrm_tape_stream_arg(void* fn);
+/* development (tools/host_time.py): op k's entry-point name (NULL: no such op) and, in out[5], its lane, the replays timed,
+ * the host nanoseconds spent inside the call and waiting for another lane's op, the longest single call; the clocks run under cdlrm_debug_set(3, 1) */
+const char* cdlrm_tape_op_info(cdlrm_tape* t, int64_t k, int64_t* out);
 int cdlrm_tape_replay(cdlrm_tape* t);      /* first non-zero return code of a replayed call, else 0 */
 /* Multi-lane replay: at short per-rank batches the HOST thread that issues a step's ~45 runtime calls, not the GPU, sets the
  * step time.  lane[k] = 1 .. 3 hands op k to that helper thread of the process (one per side queue), lane[k] = 0 stays with

@@ -24,6 +24,9 @@ VARIANTS = {
     "recorded events": {"attach_events": False},
     "wait on the training queue": {"fold_top_wait": False},
     "unchained take (round-1 schedule)": {"chain_take": False},
+    "top weight gradients behind the interaction backward": {"top_wgrad_after": "interacted"},
+    "top weight gradients behind the bottom input gradients": {"top_wgrad_after": "bot_dz"},
+    "top weight gradients behind the bottom weight gradients": {"top_wgrad_after": "bot_wg"},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
 }
