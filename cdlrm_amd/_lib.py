@@ -89,6 +89,9 @@ PROTOTYPES = {
     "cdlrm_agg_split": (C.c_int, [vp, vp, c_i64, vp, c_i32, vp, vp, vp]),
     "cdlrm_interact_fwd": (C.c_int, [vp, c_i64, c_i32, c_i32, c_i32, vp, c_i64, vp]),
     "cdlrm_interact_bwd": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp]),
+    "cdlrm_gather_interact_supported": (C.c_int, [vp]),
+    "cdlrm_gather_interact_fwd": (C.c_int, [vp, vp, c_i64, vp, c_i64, c_i64, c_i32, vp, c_i64, vp]),
+    "cdlrm_gather_interact_bwd": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i32, c_i32, vp, vp]),
     "cdlrm_linear_fwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp]),
     "cdlrm_linear_bwd_work_bytes": (c_u64, [c_i64, c_i32, c_i32]),
     "cdlrm_linear_bwd": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i32, c_i32,

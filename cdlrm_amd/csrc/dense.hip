@@ -835,9 +835,25 @@ __global__ void __launch_bounds__(256) k_interact_fwd_p(const float* __restrict_
 // next sample's staging wait for vmcnt(0) -- for these stores' acknowledgements -- in every iteration.)  The first sample is
 // peeled off the loop so that the loop is only ever entered with the same memory operations in flight as its own back edge
 // leaves -- the next sample's loads, then this one's output stores: the wait in front of the staging then counts the loads alone.
-template <int D4, int NS>
-__global__ void __launch_bounds__(256) k_interact_fwd_s(const float* __restrict__ feat, int64_t B, int F, int itself,
-                                                        float* __restrict__ R, int64_t ld_r) {
+//
+// G (the fused gather, cdlrm_gather_interact_fwd): rows 1 .. F-1 of a sample are not read from a feature block but straight from
+// the cache rows the batch's slot ids name -- the sum-pool of a one-index bag IS its row (Criteo layout), so the [B, T, D] block
+// the stand-alone gather writes (and this kernel reads back) never exists: 109 MB written + 113 MB read per c3 step that are
+// not moved at all.  `feat` is then the dense feature alone (row 0, pitch ga.ldx4).  Per sample a lane needs the slot ids of
+// the NR rows its registers cover; they are loaded TWO samples ahead (slot -> row address -> row is a dependent chain: the
+// rows of the next sample are in flight while this one is computed, the slot ids of the one after are in flight behind them).
+// Same operands in the same lanes, same MFMA order: bit-identical to gather + interaction.
+struct IaGather {
+    const TableDesc* tab;       // row_base of every table's cache rows
+    const v4f* weight;          // cache rows (and the auxiliary rows behind them), D4 float4 words each
+    const int32_t* slots;       // [T, n] slot ids of the batch (cdlrm_embbag_probe / cdlrm_embbag_take)
+    int64_t n;
+    int64_t ldx4;               // pitch of the dense-feature rows, float4 words
+};
+
+template <int D4, int NS, bool G>
+__global__ void __launch_bounds__(256) k_interact_fwd_s(const float* __restrict__ feat, IaGather ga, int64_t B, int F,
+                                                        int itself, float* __restrict__ R, int64_t ld_r) {
     constexpr int D = 4 * D4, CS = D4 / NS, DS = 4 * CS, PITCH = DS + 4, NR = CS / 2;
     constexpr int OSW = D + 532;                    // output staging row: D + up to 528 pairs + the pad word
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -851,22 +867,57 @@ __global__ void __launch_bounds__(256) k_interact_fwd_s(const float* __restrict_
     const int off = itself ? 1 : 0;
     // per register i of a slab: (row, chunk) of this lane's 16 bytes; the source row is clamped to F - 1
     int soff[NR], doff[NR];
+    int srow[G ? NR : 1];               // G: where the row's slot ids start in `slots` (T * n < 2^31, checked by the host) ...
+    const v4f* wbase[G ? NR : 1];       //    ... and this lane's 16 bytes of slot 0 of the row's table
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int e = lane + 64 * i, row = e / CS, c = e % CS;
-        soff[i] = min(row, F - 1) * D4 + c;
+        soff[i] = G ? c : min(row, F - 1) * D4 + c;
         doff[i] = row * PITCH + 4 * c;
+        if constexpr (G) {
+            const int t = max(min(row, F - 1) - 1, 0);
+            srow[i] = t * (int)ga.n;
+            wbase[i] = ga.weight + (ga.tab[t].row_base * D4 + c);
+        }
     }
     v4f nxt[NS][NR];
-    auto prefetch = [&](int s, int64_t bb) __attribute__((always_inline)) {
-        const v4f* src = reinterpret_cast<const v4f*>(feat) + bb * (int64_t)F * D4 + s * CS;
+    const v4f* pn[G ? NR : 1];          // G: this lane's NR sources of the sample whose rows are fetched next
+    int32_t sl[G ? NR : 1];             //    and the slot ids of the sample after it
+    auto load_slots = [&](int64_t bb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) nxt[s][i] = src[soff[i]];
+        for (int i = 0; i < NR; ++i) sl[i] = ga.slots[srow[i] + bb];
     };
+    auto make_ptrs = [&](int64_t bb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const v4f* p = wbase[i] + (int64_t)sl[i] * D4;
+            if (i == 0 && lane < CS) p = reinterpret_cast<const v4f*>(feat) + bb * ga.ldx4 + soff[i];   // row 0: the dense feature
+            pn[i] = p;
+        }
+    };
+    auto prefetch = [&](int s, int64_t bb) __attribute__((always_inline)) {
+        if constexpr (G) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) nxt[s][i] = pn[i][s * CS];
+        } else {
+            const v4f* src = reinterpret_cast<const v4f*>(feat) + bb * (int64_t)F * D4 + s * CS;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) nxt[s][i] = src[soff[i]];
+        }
+    };
+    if constexpr (G) {
+        load_slots(b);
+        make_ptrs(b);
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) prefetch(s, b);
+    if constexpr (G) load_slots(min(b + nw, B - 1));
     auto one = [&](int64_t b) __attribute__((always_inline)) {
         const int64_t bn = min(b + nw, B - 1);
+        if constexpr (G) {
+            make_ptrs(bn);                          // (its slot ids were requested a whole sample ago)
+            load_slots(min(bn + nw, B - 1));
+        }
         v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
         const float* tp = Ts + l16 * PITCH + 4 * g4;
 #pragma unroll
@@ -1002,10 +1053,12 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
 // unconditional, fully coalesced stores per block (see the forward kernel for why).  Same products in the same order as
 // k_interact_bwd_p: bit-identical.  49.1 -> 41.2 us at B = 8192, F = 27, D = 128 (two workgroups per CU; one: 45.6).
 // Needs F > 16, a 16-byte aligned dfeat / dR and ld_r % 4 == 0.
-template <int D4, int NS>
-__global__ void __launch_bounds__(256) k_interact_bwd_s(const float* __restrict__ feat, const float* __restrict__ dR,
-                                                        int64_t ld_r, int64_t B, int F, int itself, int x_act,
-                                                        float* __restrict__ dfeat) {
+// G (cdlrm_gather_interact_bwd): as in the forward kernel -- the rows are read again from the cache (they are still the
+// forward's: the embedding update of this batch runs behind this kernel), `feat` is the dense feature alone.
+template <int D4, int NS, bool G>
+__global__ void __launch_bounds__(256, (G && D4 <= 32) ? 2 : 1) k_interact_bwd_s(const float* __restrict__ feat, IaGather ga,
+                                                        const float* __restrict__ dR, int64_t ld_r, int64_t B, int F,
+                                                        int itself, int x_act, float* __restrict__ dfeat) {
     constexpr int D = 4 * D4, CS = D4 / NS, DS = 4 * CS, PITCH = DS + 4, NR = CS / 2;
     constexpr int GMAX = D + 528;               // dense part + up to 32*33/2 pair gradients
     constexpr int NG = (GMAX / 4 + 63) / 64;
@@ -1023,24 +1076,59 @@ __global__ void __launch_bounds__(256) k_interact_bwd_s(const float* __restrict_
     int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= B) return;
     int soff[NR], doff[NR];
+    int srow[G ? NR : 1];
+    const v4f* wbase[G ? NR : 1];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int e = lane + 64 * i, row = e / CS, c = e % CS;
-        soff[i] = min(row, F - 1) * D4 + c;
+        soff[i] = G ? c : min(row, F - 1) * D4 + c;
         doff[i] = row * PITCH + 4 * c;
+        if constexpr (G) {
+            const int t = max(min(row, F - 1) - 1, 0);
+            srow[i] = t * (int)ga.n;
+            wbase[i] = ga.weight + (ga.tab[t].row_base * D4 + c);
+        }
     }
     v4f nxt[NS][NR], gn[NG];
-    auto prefetch = [&](int s, int64_t bb) __attribute__((always_inline)) {
-        const v4f* src = reinterpret_cast<const v4f*>(feat) + bb * (int64_t)F * D4 + s * CS;
+    const v4f* pn[G ? NR : 1];
+    int32_t sl[G ? NR : 1];
+    auto load_slots = [&](int64_t bb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) nxt[s][i] = src[soff[i]];
+        for (int i = 0; i < NR; ++i) sl[i] = ga.slots[srow[i] + bb];
     };
+    auto make_ptrs = [&](int64_t bb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const v4f* p = wbase[i] + (int64_t)sl[i] * D4;
+            if (i == 0 && lane < CS) p = reinterpret_cast<const v4f*>(feat) + bb * ga.ldx4 + soff[i];
+            pn[i] = p;
+        }
+    };
+    auto prefetch = [&](int s, int64_t bb) __attribute__((always_inline)) {
+        if constexpr (G) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) nxt[s][i] = pn[i][s * CS];
+        } else {
+            const v4f* src = reinterpret_cast<const v4f*>(feat) + bb * (int64_t)F * D4 + s * CS;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) nxt[s][i] = src[soff[i]];
+        }
+    };
+    if constexpr (G) {
+        load_slots(b);
+        make_ptrs(b);
+    }
 #pragma unroll
     for (int i = 0; i < NG; ++i) gn[i] = reinterpret_cast<const v4f*>(dR + b * ld_r)[min(lane + 64 * i, G4 - 1)];
 #pragma unroll
     for (int s = 0; s < NS; ++s) prefetch(s, b);
+    if constexpr (G) load_slots(min(b + nw, B - 1));
     auto one = [&](int64_t b) __attribute__((always_inline)) {
         const int64_t bn = min(b + nw, B - 1);
+        if constexpr (G) {
+            make_ptrs(bn);
+            load_slots(min(bn + nw, B - 1));
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) *reinterpret_cast<v4f*>(Gs + 4 * min(lane + 64 * i, GMAX / 4 - 1)) = gn[i];
 #pragma unroll
@@ -1132,10 +1220,10 @@ extern "C" int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32
             static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
 #define IFWD_S(D4_, A_)                                                                                               \
     do {                                                                                                              \
-        int rc = interact_set_lds(k_interact_fwd_s<D4_, D4_ / 8>, lds_s, &A_);                                        \
+        int rc = interact_set_lds(k_interact_fwd_s<D4_, D4_ / 8, false>, lds_s, &A_);                                 \
         if (rc) return rc;                                                                                            \
-        hipLaunchKernelGGL((k_interact_fwd_s<D4_, D4_ / 8>), dim3((unsigned)gp), dim3(256), lds_s, (hipStream_t)stream, feat, B, \
-                           F, itself, R, ld_r);                                                                       \
+        hipLaunchKernelGGL((k_interact_fwd_s<D4_, D4_ / 8, false>), dim3((unsigned)gp), dim3(256), lds_s,             \
+                           (hipStream_t)stream, feat, IaGather{}, B, F, itself, R, ld_r);                             \
     } while (0)
             if (D == 32) IFWD_S(8, s32);
             else if (D == 64) IFWD_S(16, s64);
@@ -1197,10 +1285,10 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
         static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
 #define IBWD_S(D4_, A_)                                                                                               \
     do {                                                                                                              \
-        int rc = interact_set_lds(k_interact_bwd_s<D4_, D4_ / 8>, lds_s, &A_);                                        \
+        int rc = interact_set_lds(k_interact_bwd_s<D4_, D4_ / 8, false>, lds_s, &A_);                                 \
         if (rc) return rc;                                                                                            \
-        CDLRM_LAUNCH_EV((k_interact_bwd_s<D4_, D4_ / 8>), dim3((unsigned)gp), dim3(256), lds_s, (hipStream_t)stream, feat, dR,   \
-                        ld_r, B, F, itself, x_act, dfeat);                                                            \
+        CDLRM_LAUNCH_EV((k_interact_bwd_s<D4_, D4_ / 8, false>), dim3((unsigned)gp), dim3(256), lds_s,                \
+                        (hipStream_t)stream, feat, IaGather{}, dR, ld_r, B, F, itself, x_act, dfeat);                 \
     } while (0)
         if (D == 32) IBWD_S(8, s32);
         else if (D == 64) IBWD_S(16, s64);
@@ -1241,6 +1329,90 @@ extern "C" int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(k_interact_bwd, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, feat, dR, ld_r, B, F, D,
                        itself, x_act, dfeat);
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused gather + interaction (Criteo layout: one index per bag, so a bag's sum-pool is its cache row) ------------------
+// cached EmbeddingBag forward (model_no_ddp.py:200-203) + interact_features "dot" (:272-293) in one launch, and the
+// interaction backward reading the same rows again: the [B, T, D] block between the two operators is never written or read.
+// Shapes the column-slab kernels take: D in {32, 64, 128, 256}, 16 < F = T + 1 <= 32, float4 output / gradient rows.
+static bool gather_interact_shape_ok(const cdlrm_ctx* ctx) {
+    const int D = ctx->D, F = ctx->T + 1;
+    return (D == 32 || D == 64 || D == 128 || D == 256) && F > 16 && F <= 32;
+}
+
+extern "C" int cdlrm_gather_interact_supported(cdlrm_ctx* ctx) {
+    return ctx && gather_interact_shape_ok(ctx) ? 1 : 0;
+}
+
+extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                                         int64_t B, int32_t itself, float* R, int64_t ld_r, void* stream) {
+    CDLRM_CLEAR_STALE();
+    CDLRM_REQUIRE(ctx && slots && x && R, "null argument");
+    CDLRM_REQUIRE(ctx->weight, "cdlrm_ctx_bind_cache first");
+    CDLRM_REQUIRE(gather_interact_shape_ok(ctx), "unsupported shape (D in 32/64/128/256, 16 < T + 1 <= 32): gather + interaction as two calls");
+    const int D = ctx->D, F = ctx->T + 1;
+    const int width = D + (itself ? F * (F + 1) / 2 : F * (F - 1) / 2);
+    CDLRM_REQUIRE(n >= B && (int64_t)ctx->T * n < INT32_MAX && aligned16(x) && ld_x % 4 == 0 && ld_x >= D,
+                  "slot pitch / dense-feature rows");
+    CDLRM_REQUIRE(ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width + 3) & ~3), "whole-float4 output rows");
+    hipEvent_t ev0 = (hipEvent_t)ctx->ev_start, ev1 = (hipEvent_t)ctx->ev_stop;     // cdlrm_ctx_time_next_gather
+    ctx->ev_start = ctx->ev_stop = nullptr;
+    if (B == 0) return 0;
+    IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4};
+    const size_t lds_s = (size_t)4 * (32 * 36 + D + 532) * sizeof(float);
+    int64_t gp = cdiv(B, 4);
+    const int per_cu = g_cdlrm_debug[4] > 0 ? g_cdlrm_debug[4] : 2;
+    if (gp > 256 * per_cu) gp = 256 * per_cu;
+    static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
+#define GIFWD(D4_, A_)                                                                                                \
+    do {                                                                                                              \
+        int rc = interact_set_lds(k_interact_fwd_s<D4_, D4_ / 8, true>, lds_s, &A_);                                  \
+        if (rc) return rc;                                                                                            \
+        hipExtLaunchKernelGGL((k_interact_fwd_s<D4_, D4_ / 8, true>), dim3((unsigned)gp), dim3(256), lds_s,           \
+                              (hipStream_t)stream, ev0, ev1, 0, x, ga, B, F, itself, R, ld_r);                        \
+    } while (0)
+    if (D == 32) GIFWD(8, s32);
+    else if (D == 64) GIFWD(16, s64);
+    else if (D == 128) GIFWD(32, s128);
+    else GIFWD(64, s256);
+#undef GIFWD
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                                         const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act,
+                                         float* dfeat, void* stream) {
+    CdlrmStopScope stop_scope;          // (first: every exit below flushes an attached completion event)
+    CDLRM_REQUIRE(ctx && slots && x && dR && dfeat, "null argument");
+    CDLRM_REQUIRE(ctx->weight, "cdlrm_ctx_bind_cache first");
+    CDLRM_REQUIRE(gather_interact_shape_ok(ctx), "unsupported shape (D in 32/64/128/256, 16 < T + 1 <= 32): cdlrm_interact_bwd on a gathered block");
+    const int D = ctx->D, F = ctx->T + 1;
+    const int npairs = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    CDLRM_REQUIRE(n >= B && (int64_t)ctx->T * n < INT32_MAX && aligned16(x) && ld_x % 4 == 0 && ld_x >= D,
+                  "slot pitch / dense-feature rows");
+    CDLRM_REQUIRE(ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3) && aligned16(dfeat), "whole-float4 gradient rows");
+    if (B == 0) return 0;
+    IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4};
+    const size_t lds_s = (size_t)4 * (32 * 36 + D + 528) * sizeof(float);
+    int64_t gp = cdiv(B, 4);
+    const int per_cu = g_cdlrm_debug[5] > 0 ? g_cdlrm_debug[5] : (D == 256 ? 1 : 2);
+    if (gp > 256 * per_cu) gp = 256 * per_cu;
+    static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
+#define GIBWD(D4_, A_)                                                                                                \
+    do {                                                                                                              \
+        int rc = interact_set_lds(k_interact_bwd_s<D4_, D4_ / 8, true>, lds_s, &A_);                                  \
+        if (rc) return rc;                                                                                            \
+        CDLRM_LAUNCH_EV((k_interact_bwd_s<D4_, D4_ / 8, true>), dim3((unsigned)gp), dim3(256), lds_s,                 \
+                        (hipStream_t)stream, x, ga, dR, ld_r, B, F, itself, x_act, dfeat);                            \
+    } while (0)
+    if (D == 32) GIBWD(8, s32);
+    else if (D == 64) GIBWD(16, s64);
+    else if (D == 128) GIBWD(32, s128);
+    else GIBWD(64, s256);
+#undef GIBWD
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

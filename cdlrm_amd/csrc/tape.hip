@@ -100,7 +100,8 @@ static const std::vector<TapeEntry>& tape_registry() {
     static const std::vector<TapeEntry> reg = {
         TAPE_FN(cdlrm_embbag_probe), TAPE_FN(cdlrm_embbag_take), TAPE_FN(cdlrm_embbag_fwd), TAPE_FN(cdlrm_embbag_bwd_sgd),
         TAPE_FN(cdlrm_embbag_bwd_prepare), TAPE_FN(cdlrm_embbag_bwd_apply), TAPE_FN(cdlrm_window_resolve),
-        TAPE_FN(cdlrm_mark_rows), TAPE_FN(cdlrm_interact_fwd), TAPE_FN(cdlrm_interact_bwd), TAPE_FN(cdlrm_linear_fwd),
+        TAPE_FN(cdlrm_mark_rows), TAPE_FN(cdlrm_interact_fwd), TAPE_FN(cdlrm_interact_bwd), TAPE_FN(cdlrm_gather_interact_fwd),
+        TAPE_FN(cdlrm_gather_interact_bwd), TAPE_FN(cdlrm_linear_fwd),
         TAPE_FN(cdlrm_linear_bwd), TAPE_FN(cdlrm_mlp_wgrad), TAPE_FN(cdlrm_mlp_wgrad_sgd), TAPE_FN(cdlrm_bce_fwd_bwd),
         TAPE_FN(cdlrm_loss_fwd_bwd), TAPE_FN(cdlrm_head_fwd_bwd), TAPE_FN(cdlrm_head_finish), TAPE_FN(cdlrm_act_bwd),
         TAPE_FN(cdlrm_sgd_step), TAPE_FN(cdlrm_sgd_step2), TAPE_FN(cdlrm_scale_div),

@@ -659,6 +659,11 @@ class TrainEngine:
         # input-gradient chain) or "bot_wg" (behind the bottom MLP's weight gradients: they then run into the next step's
         # bottom MLP, gather and interaction forward, which leave the MFMA idle)
         self.top_wgrad_after = "top_dz"
+        # Criteo layout + dot interaction: the gather IS the interaction's operand load (cdlrm_gather_interact_fwd / _bwd) -- the
+        # [B, T, D] block between cached EmbeddingBag and interact_features is neither written nor read back (c3: 109 MB + 113 MB
+        # per step), the backward reads the rows again from the cache, in front of the batch's embedding update.  Bit-identical
+        # to the two operators (False: gather + interaction as two launches; multi-hot bags and "cat" always take those).
+        self.fuse_gather = True
         # WindowResolver hands the NEXT step a look-ahead chunk to resolve (`_pending_resolve`, taken when `mark_next` is set): the
         # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
         # stream --, so the resolve (random 128-B tag reads) runs beside the top MLP's GEMMs, which leave HBM idle, instead of
@@ -736,6 +741,11 @@ class TrainEngine:
         self.mark_next = False
         if pr is not None:
             self._issue_resolve(pr, lambda fn, *a: fn(*a), S.current_stream(self.dev), placed=False)
+
+    def _fused_gather(self, lS_o) -> bool:
+        """This step's gather rides in the interaction kernels (fuse_gather)."""
+        return bool(self.fuse_gather and lS_o is None and not self.cat and S.is_hip(self.dev)
+                    and ops.gather_interact_supported(self.ctx))
 
     def _side_gather(self, B: int) -> bool:
         """Short local batches run the gather on the side stream (see _fwd_bwd)."""
@@ -1038,7 +1048,11 @@ class TrainEngine:
             rec(probed.record, side)
         n_bags = B if lS_o is None else lS_o.shape[1]
 
+        fused = self._fused_gather(lS_o)
+
         def gather(st):
+            if fused:       # the rows are the interaction kernel's operand loads: nothing to launch here
+                return
             if self._gslot is not None:         # bench.py: the roofline kernel's own start / stop timestamps
                 ops.time_next_gather(ctx, self._gslot[0], self._gslot[1])
             ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=n_bags, stream=st)
@@ -1107,7 +1121,11 @@ class TrainEngine:
             # the side stream) has to have landed before this step overwrites those buffers and reads the weights
             # (top_waited: the event this step's gather waited for was recorded behind that update)
             rec(main.wait_event, ev["top_updated"])
-        if not self.cat:
+        if fused:
+            if self._gslot is not None:         # bench.py: the kernel that does the gather, timed by its own launch
+                ops.time_next_gather(ctx, self._gslot[0], self._gslot[1])
+            ops.gather_interact_fwd(ctx, slots, feat[:, 0, :], self.itself, R)
+        elif not self.cat:
             ops.interact_fwd(feat, self.itself, R)
         if self._mark_this:
             self._issue_resolve(self._pending_resolve, rec, main, placed=True)
@@ -1199,7 +1217,10 @@ class TrainEngine:
         else:
             if attach:
                 ops.event_attach_next(ev["interacted"], main)      # completes with the interaction backward's launch
-            ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
+            if fused:
+                ops.gather_interact_bwd(ctx, slots, feat[:, 0, :], dR, self.itself, dfeat, x_act=self.bot[-1][1])
+            else:
+                ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
         # embedding backward + sparse SGD on a side stream, overlapped with the bottom-MLP backward and the
         # gradient all-reduce (the reference overlaps optimizer_embeds.step() with the all-reduce, :412-414)
         if not attach or self.cat:
@@ -1307,9 +1328,12 @@ class TrainEngine:
             y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
             ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
             cur = y
-        ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
-        if not self.cat:
-            ops.interact_fwd(feat, self.itself, R)
+        if self._fused_gather(lS_o):
+            ops.gather_interact_fwd(ctx, slots, feat[:, 0, :], self.itself, R)
+        else:
+            ops.embbag_fwd(ctx, slots, lS_o, feat[:, 1:, :], feat.stride(0), D, n_bags=(B if lS_o is None else lS_o.shape[1]))
+            if not self.cat:
+                ops.interact_fwd(feat, self.itself, R)
         cur = R
         for i, (l, act) in enumerate(self.top):
             y = buf["top_y"][i]
@@ -1354,6 +1378,7 @@ class TrainEngine:
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
                self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.top_wgrad_after,
+               self.fuse_gather,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)

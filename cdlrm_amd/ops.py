@@ -419,6 +419,30 @@ def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torc
                                         int(x_act), dfeat.data_ptr(), stream_ptr(stream)))
 
 
+def gather_interact_supported(ctx: CacheCtx) -> bool:
+    """Shapes the fused gather + interaction kernels take (D in 32 / 64 / 128 / 256, 16 < T + 1 <= 32)."""
+    return bool(_lib.lib().cdlrm_gather_interact_supported(ctx.handle))
+
+
+def gather_interact_fwd(ctx: CacheCtx, slots: torch.Tensor, x: torch.Tensor, itself: bool, R: torch.Tensor, stream=None):
+    """Cached EmbeddingBag forward (Criteo layout) + dot interaction in one launch: x [B, D] (any row pitch) is feature 0,
+    features 1 .. T are the cache rows `slots` [T, n] names.  Bit-identical to embbag_fwd + interact_fwd."""
+    B = x.shape[0]
+    assert slots.dtype == torch.int32 and slots.stride(1) == 1 and x.stride(1) == 1
+    check(_lib.lib().cdlrm_gather_interact_fwd(ctx.handle, slots.data_ptr(), slots.stride(0), x.data_ptr(), x.stride(0), B,
+                                               int(bool(itself)), R.data_ptr(), R.stride(0), stream_ptr(stream)))
+
+
+def gather_interact_bwd(ctx: CacheCtx, slots: torch.Tensor, x: torch.Tensor, dR: torch.Tensor, itself: bool,
+                        dfeat: torch.Tensor, stream=None, x_act: int = 0):
+    """interact_bwd with the rows read again from the cache (before the batch's embedding update rewrites them)."""
+    B = x.shape[0]
+    assert slots.dtype == torch.int32 and slots.stride(1) == 1 and x.stride(1) == 1 and dfeat.is_contiguous()
+    check(_lib.lib().cdlrm_gather_interact_bwd(ctx.handle, slots.data_ptr(), slots.stride(0), x.data_ptr(), x.stride(0),
+                                               dR.data_ptr(), dR.stride(0), B, int(bool(itself)), int(x_act),
+                                               dfeat.data_ptr(), stream_ptr(stream)))
+
+
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 
 

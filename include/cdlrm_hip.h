@@ -340,6 +340,24 @@ int cdlrm_interact_fwd(const float* feat, int64_t B, int32_t F, int32_t D, int32
  * act'(feat[b,0,:]) here, so the bottom MLP's backward starts from the pre-activation gradient. */
 int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t B, int32_t F,
                        int32_t D, int32_t itself, int32_t x_act, float* dfeat, void* stream);
+/* Cached EmbeddingBag forward + interact_features "dot" in ONE launch (model_no_ddp.py:200-203 + :272-293), Criteo layout
+ * (one index per bag: the bag's sum-pool is its cache row).  The rows the slot ids name are read straight into the
+ * interaction -- the [B, T, D] block cdlrm_embbag_fwd would write and cdlrm_interact_fwd read back is never moved.
+ *   slots  device int32 [T, n] (cdlrm_embbag_probe / cdlrm_embbag_take), sample b of table t at slots[t * n + b], n >= B
+ *   x      device fp32 [B, D] rows of pitch ld_x: the bottom MLP's output (feature 0)
+ *   R      as cdlrm_interact_fwd's, F = T + 1; whole float4 rows (ld_r % 4 == 0, 16-byte aligned)
+ * Bit-identical to cdlrm_embbag_fwd + cdlrm_interact_fwd.  Shapes: cdlrm_gather_interact_supported() (D in 32 / 64 / 128 /
+ * 256, 16 < T + 1 <= 32); anything else is refused -- the caller issues the two operators.  A pair of events armed with
+ * cdlrm_ctx_time_next_gather times this launch. */
+int cdlrm_gather_interact_supported(cdlrm_ctx* ctx);
+int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x, int64_t B,
+                              int32_t itself, float* R, int64_t ld_r, void* stream);
+/* Its backward: cdlrm_interact_bwd with the rows read again from the cache (call it BEFORE the batch's embedding update:
+ * cdlrm_embbag_bwd_apply rewrites them).  dfeat fp32 [B, T + 1, D] as cdlrm_interact_bwd's; carries an attached completion
+ * event (cdlrm_event_attach_next) like cdlrm_interact_bwd. */
+int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                              const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act, float* dfeat,
+                              void* stream);
 /* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
  * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */
 int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y,
@@ -491,7 +509,7 @@ int cdlrm_stream_destroy(void* stream);
 void* cdlrm_event_create(int32_t timing);
 int cdlrm_event_destroy(void* event);
 int cdlrm_event_elapsed_us(void* start, void* stop, float* us);
-/* Measurement: the NEXT cdlrm_embbag_fwd on this context leaves its start / stop timestamps in the two (timing) events --
+/* Measurement: the NEXT cdlrm_embbag_fwd (or cdlrm_gather_interact_fwd) on this context leaves its start / stop timestamps in the two (timing) events --
  * attached to the launch itself (hipExtLaunchKernel), no event records around it -- so bench.py can price the gather
  * (the roofline kernel) live, per launch.  A timed launch costs its queue ~7 us (completion signal); the elapsed time reads
  * 0.5-2 us above the profiler's duration of the same kernel. */

@@ -33,14 +33,19 @@ def t(a):
     return torch.from_numpy(np.asarray(a))
 
 
-@pytest.mark.parametrize("name,chunks,pipelined,resolved", [("train_c3shape", 0, True, False), ("train_c2shape", 0, True, True),
-                                                            ("train_c5shape", 3, True, False), ("train_c3shape", 2, False, False),
-                                                            ("train_c3shape", 0, True, True), ("train_c5shape", 0, True, True),
-                                                            ("train_c4shape", 0, True, False), ("train_c4shape", 0, True, True)])
-def test_config_shaped_training_vs_reference(golden, name, chunks, pipelined, resolved):
+@pytest.mark.parametrize("name,chunks,pipelined,resolved,fused", [
+    ("train_c3shape", 0, True, False, True), ("train_c2shape", 0, True, True, True), ("train_c5shape", 3, True, False, True),
+    ("train_c3shape", 2, False, False, True), ("train_c3shape", 0, True, True, True), ("train_c5shape", 0, True, True, True),
+    ("train_c4shape", 0, True, False, True), ("train_c4shape", 0, True, True, True),
+    # gather + interaction as two launches (the path of multi-hot bags, "cat" and shapes outside the fused kernels)
+    ("train_c3shape", 0, True, True, False), ("train_c2shape", 0, True, False, False), ("train_c5shape", 3, True, False, False),
+    ("train_c4shape", 0, False, False, False)])
+def test_config_shaped_training_vs_reference(golden, name, chunks, pipelined, resolved, fused):
     from test_engine_parity import build, make_batches
     g = golden(name)
     host, cg, dl, eng, pipe = build(g)
+    eng.fuse_gather = fused     # True (the default): the gather rides in the interaction kernels (cdlrm_gather_interact_fwd / _bwd)
+    assert eng._fused_gather(None) == fused
     assert cg.num_ways == int(g["ways"]) and len(cg.cache_sizes) == 26
     L, ways = int(g["L"]), int(g["ways"])
     batches = make_batches(g)
@@ -116,12 +121,16 @@ def _check_cache_invariants(cg):
         assert int(v.min()) >= 0 and int(v.max()) < int(cg.ln_emb[k]) if v.numel() else True
 
 
-def _run_full_size(config, host, L, n_windows, steps_per_window, max_ind_range=-1):
+def _run_full_size(config, host, L, n_windows, steps_per_window, max_ind_range=-1, fuse_gather=True):
     import bench
     w = bench.build_workload(config, lookahead=L, host=host, seed=123, cache_init="zeros", write_back=False,
                              max_ind_range=max_ind_range)
     cg, eng, pipe, syn, B = w["cg"], w["eng"], w["pipe"], w["syn"], w["B"]
     T = len(cg.cache_sizes)
+    # fuse_gather (the default): the rows are the interaction kernels' operand loads and the gathered block never exists;
+    # False: gather + interaction as two launches, whose gather output is checked against the rows the probe resolved
+    eng.fuse_gather = bool(fuse_gather)
+    assert eng._fused_gather(None) == bool(fuse_gather)
     losses, feats = [], None
     for wi in range(n_windows):
         win = syn.window(wi, L)
@@ -150,7 +159,7 @@ def _run_full_size(config, host, L, n_windows, steps_per_window, max_ind_range=-
                                next_res=rs.batch(jj + 1) if nxt is not None else None)
             rs.ensure(jj + rs.CH + 2)
             losses.append(lossbuf[0:1].clone())
-            if check_rows:
+            if check_rows and not fuse_gather:
                 # gather == row copy: feat[:, k+1] is bit-exactly the cache row the probe resolved (one lookup per bag)
                 eng.finish()
                 torch.cuda.synchronize()
@@ -175,15 +184,17 @@ def test_full_size_invariants_and_bitwise_repeat(terabyte_host, config, L, steps
     than the big tables' caches have slots, so full sets, contested slots, evictions and window victims all occur:
     every resident tag in its set and unique, the gather bit-exact against the rows the probe resolved, finite losses
     near ln 2, and a second run from the same state bitwise identical (tags, every parameter, the loss trajectory) --
-    no atomics-order or cross-stream race dependence anywhere in the step.  (Write-back is off in both runs so that the
+    no atomics-order or cross-stream race dependence anywhere in the step.  The first run is the default one (the gather
+    fused into the interaction kernels), the second issues gather + interaction as two launches: the fused kernels are held
+    to the two operators bit for bit at full size, through every step.  (Write-back is off in both runs so that the
     second run sees the host tables of the first.)"""
     a = _run_full_size(config, terabyte_host, L, 2, steps)
-    b = _run_full_size(config, terabyte_host, L, 2, steps)
+    b = _run_full_size(config, terabyte_host, L, 2, steps, fuse_gather=False)
     assert torch.isfinite(a["losses"]).all() and 0.3 < float(a["losses"][-1]) < 2.0
     assert torch.equal(a["losses"], b["losses"]), "loss trajectory differs between two identical runs"
     assert torch.equal(a["tags"], b["tags"])
     assert torch.equal(a["params"], b["params"])
-    assert a["wsum"] == b["wsum"] and a["feats"] == b["feats"]
+    assert a["wsum"] == b["wsum"] and a["feats"] is None and b["feats"] is not None
     assert int((a["tags"] != -1).sum()) > 1_000_000
 
 
@@ -198,12 +209,12 @@ def test_c4_capped_invariants_and_bitwise_repeat():
     host = bench.build_host_tables("c4", seed=123, dev=torch.device(DEV), max_ind_range=cap)
     try:
         a = _run_full_size("c4", host, 1000, 2, 4, max_ind_range=cap)
-        b = _run_full_size("c4", host, 1000, 2, 4, max_ind_range=cap)
+        b = _run_full_size("c4", host, 1000, 2, 4, max_ind_range=cap, fuse_gather=False)
     finally:
         del host
     assert torch.isfinite(a["losses"]).all() and 0.3 < float(a["losses"][-1]) < 2.0
     assert torch.equal(a["losses"], b["losses"]), "loss trajectory differs between two identical runs"
     assert torch.equal(a["tags"], b["tags"])
     assert torch.equal(a["params"], b["params"])
-    assert a["wsum"] == b["wsum"] and a["feats"] == b["feats"]
+    assert a["wsum"] == b["wsum"] and a["feats"] is None and b["feats"] is not None
     assert int((a["tags"] != -1).sum()) > 1_000_000

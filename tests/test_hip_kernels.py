@@ -549,6 +549,94 @@ def test_interaction_kernels_vs_torch(ops, B, F, D, itself, pad):
     np.testing.assert_allclose(dfeat.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("B,T,D,itself,x_act,n_extra", [(3000, 26, 128, 0, 1, 0), (1, 26, 128, 0, 1, 0), (5, 16, 32, 1, 0, 3),
+                                                         (1023, 31, 64, 0, 2, 0), (2100, 26, 256, 1, 1, 0),
+                                                         (4100, 19, 32, 0, 0, 28), (8192, 26, 128, 0, 1, 0),
+                                                         (20000, 26, 128, 0, 1, 0)])
+def test_fused_gather_interaction_equals_the_two_operators(ops, B, T, D, itself, x_act, n_extra):
+    """cdlrm_gather_interact_fwd / _bwd (cached EmbeddingBag forward of one-index bags + dot interaction in one launch, the
+    backward reading the rows again from the cache) against cdlrm_embbag_fwd + cdlrm_interact_fwd / cdlrm_interact_bwd on the
+    same slot ids: bit for bit, and against torch autograd on the oracle's interact_features over the gathered rows.  Ragged
+    batch sizes (one sample, fewer samples than waves, several samples per wave), every row width of the slab kernels, a slot
+    pitch larger than the batch, auxiliary rows behind the cache rows as slot targets; the feature block handed to the fused
+    kernels holds NaN outside feature 0 -- it must never be read."""
+    rng = np.random.RandomState(B + T + D)
+    ln = [int(v) for v in rng.randint(50, 90000, size=T)]
+    P, ways, aux = 61, 4, 512
+    cs = [min(P, v) for v in ln]
+    ctx = ops.CacheCtx(ln, cs, D, ways, aux, torch.device(DEV))
+    assert ops.gather_interact_supported(ctx)
+    tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+    weight = torch.from_numpy(rng.randn(ctx.total_rows, D).astype(np.float32)).to(DEV)
+    ctx.bind_cache(tags, weight)
+    n = B + n_extra
+    rows_of = [cs[k] * ways + aux for k in range(T)]            # cache rows + the auxiliary rows behind them
+    slots = torch.stack([torch.from_numpy(rng.randint(0, rows_of[k], size=n).astype(np.int32)) for k in range(T)]).to(DEV)
+    F = T + 1
+    npairs = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+    ld = (D + npairs + 3) // 4 * 4 + 4
+    feat = torch.zeros(B, F, D, device=DEV)
+    x = torch.from_numpy(rng.rand(B, D).astype(np.float32)).to(DEV)     # (0, 1): a valid ReLU / sigmoid output
+    feat[:, 0, :] = x
+    poisoned = torch.full((B, F, D), float("nan"), device=DEV)
+    poisoned[:, 0, :] = x
+    ops.embbag_fwd(ctx, slots, None, feat[:, 1:, :], F * D, D, n_bags=B)
+    R, R2 = torch.full((B, ld), 7.0, device=DEV), torch.full((B, ld), 7.0, device=DEV)
+    ops.interact_fwd(feat, bool(itself), R)
+    ops.gather_interact_fwd(ctx, slots, poisoned[:, 0, :], bool(itself), R2)
+    assert torch.equal(R, R2)
+    dR = torch.from_numpy(rng.randn(B, ld).astype(np.float32)).to(DEV)
+    dfeat, dfeat2 = torch.empty_like(feat), torch.empty_like(feat)
+    ops.interact_bwd(feat, dR, bool(itself), dfeat, x_act=x_act)
+    ops.gather_interact_bwd(ctx, slots, poisoned[:, 0, :], dR, bool(itself), dfeat2, x_act=x_act)
+    assert torch.equal(dfeat, dfeat2)
+    if B <= 4100:
+        rb = torch.tensor(ctx.row_base[:T] if hasattr(ctx, "row_base") else np.cumsum([0] + rows_of[:-1]), device=DEV).view(T, 1)
+        rows = weight[(slots[:, :B].to(torch.int64) + rb).reshape(-1)].view(T, B, D)
+        f = torch.cat([x.unsqueeze(1), rows.permute(1, 0, 2)], dim=1).cpu().double().requires_grad_(True)
+        ref = O.interact_features(f[:, 0, :], [f[:, k, :] for k in range(1, F)], "dot", bool(itself))
+        np.testing.assert_allclose(R2[:, :D + npairs].cpu().numpy(), ref.detach().float().numpy(), rtol=2e-5, atol=2e-5)
+        if x_act == 0:
+            ref.backward(dR[:, :D + npairs].cpu().double())
+            np.testing.assert_allclose(dfeat2.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
+
+
+def test_fused_gather_interaction_refuses_other_shapes(ops):
+    """Shapes outside the slab kernels (F <= 16, an embedding width that is none of 32 / 64 / 128 / 256) are refused with a
+    message -- the caller issues the two operators -- and a timed launch leaves its stamps in the armed events."""
+    for T, D in ((8, 128), (26, 48), (32, 128)):
+        ctx = ops.CacheCtx([1000] * T, [16] * T, D, 4, 64, torch.device(DEV))
+        assert not ops.gather_interact_supported(ctx)
+        w = torch.zeros(ctx.total_rows, D, device=DEV)
+        ctx.bind_cache(torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV), w)
+        slots = torch.zeros(T, 64, dtype=torch.int32, device=DEV)
+        x = torch.zeros(64, D, device=DEV)
+        R = torch.zeros(64, 2048, device=DEV)
+        with pytest.raises(RuntimeError, match="unsupported shape"):
+            ops.gather_interact_fwd(ctx, slots, x, False, R)
+        with pytest.raises(RuntimeError, match="unsupported shape"):
+            ops.gather_interact_bwd(ctx, slots, x, R, False, torch.zeros(64, T + 1, D, device=DEV))
+    T, D, n = 26, 128, 4096
+    ctx = ops.CacheCtx([5000] * T, [64] * T, D, 4, n, torch.device(DEV))
+    weight = torch.randn(ctx.total_rows, D, device=DEV)
+    ctx.bind_cache(torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV), weight)
+    slots = torch.randint(0, 256, (T, n), dtype=torch.int32, device=DEV)
+    x = torch.rand(n, D, device=DEV)
+    R0, R1 = torch.zeros(n, 480, device=DEV), torch.zeros(n, 480, device=DEV)
+    ops.gather_interact_fwd(ctx, slots, x, False, R0)
+    e0, e1 = ops.TimingEvent(), ops.TimingEvent()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ops.time_next_gather(ctx, e0, e1)
+    t0.record()
+    ops.gather_interact_fwd(ctx, slots, x, False, R1)
+    t1.record()
+    torch.cuda.synchronize()
+    us, around = e0.elapsed_us(e1), t0.elapsed_time(t1) * 1e3
+    assert 0.5 < us <= around + 1.0, (us, around)
+    assert torch.equal(R0, R1)
+
+
 @pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 4096, 8192])
 def test_mlp_wgrad_group(ops, M):
     """All layers' weight + bias gradients in one call (grouped LDS-free launch up to M = 2048, tiled split-M path

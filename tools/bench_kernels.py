@@ -133,6 +133,57 @@ def main():
                         us.append(e0.elapsed_us(e1))
                 print("gather stream priority %2d, %-30s: %6.1f us (min %.1f max %.1f)" % (prio, mode, np.mean(us), min(us), max(us)))
 
+    if want("fused"):
+        # gather + interaction as ONE launch (cdlrm_gather_interact_fwd / _bwd) against the two operators: bit-identical results,
+        # time by workgroups per CU (cdlrm_debug_set 4 / 5)
+        from cdlrm_amd import _lib
+        ln_emb = synth.TERABYTE_COUNTS
+        T = len(ln_emb)
+        P = 150001
+        cs = [min(n, P) for n in ln_emb]
+        ctx = ops.CacheCtx(ln_emb, cs, D, 16, B, DEV)
+        tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+        weight = torch.randn(ctx.total_rows, D, device=DEV)
+        ctx.bind_cache(tags, weight)
+        syn = synth.CriteoSynth(ln_emb, 13, B, alpha=a.alpha, device=DEV)
+        idx = syn.window(0, 1)
+        slots = torch.stack([(idx[k] % (cs[k] * 16)).to(torch.int32) for k in range(T)]).contiguous()
+        F = T + 1
+        npairs = F * (F - 1) // 2
+        ld = (D + npairs + 3) // 4 * 4
+        feat = torch.zeros(B, F, D, device=DEV)
+        feat[:, 0, :] = torch.randn(B, D, device=DEV).clamp_(min=0)
+        xonly = torch.zeros(B, F, D, device=DEV)          # the fused kernels' operand: feature 0 alone, rows 1.. poisoned
+        xonly[:, 0, :] = feat[:, 0, :]
+        xonly[:, 1:, :] = float("nan")
+        R, R2 = torch.zeros(B, ld, device=DEV), torch.zeros(B, ld, device=DEV)
+        dR = torch.randn(B, ld, device=DEV)
+        dfeat, dfeat2 = torch.zeros(B, F, D, device=DEV), torch.zeros(B, F, D, device=DEV)
+        ops.embbag_fwd(ctx, slots, None, feat[:, 1:, :], F * D, D)
+        ops.interact_fwd(feat, False, R)
+        ops.gather_interact_fwd(ctx, slots, xonly[:, 0, :], False, R2)
+        ops.interact_bwd(feat, dR, False, dfeat, x_act=1)
+        ops.gather_interact_bwd(ctx, slots, xonly[:, 0, :], dR, False, dfeat2, x_act=1)
+        torch.cuda.synchronize()
+        print("fused forward  == gather + interact_fwd bit for bit:", bool(torch.equal(R, R2)))
+        print("fused backward == interact_bwd on the gathered block:", bool(torch.equal(dfeat, dfeat2)))
+        look = B * T
+        us_g = timeit(lambda: ops.embbag_fwd(ctx, slots, None, feat[:, 1:, :], F * D, D))
+        us_i = timeit(lambda: ops.interact_fwd(feat, False, R))
+        us_b = timeit(lambda: ops.interact_bwd(feat, dR, False, dfeat, x_act=1))
+        print("gather %.1f us + interact_fwd %.1f us = %.1f us | interact_bwd %.1f us" % (us_g, us_i, us_g + us_i, us_b))
+        fbytes = look * (4 * D + 4) + B * 4 * D + B * 4 * ld      # rows + slot ids + dense feature + output rows
+        for k in (1, 2, 3, 4):
+            _lib.raw().cdlrm_debug_set(4, k)
+            us = timeit(lambda: ops.gather_interact_fwd(ctx, slots, xonly[:, 0, :], False, R2))
+            print("fused forward,  %d workgroups per CU: %6.1f us  %.2f TB/s of its own bytes (%.1f MB)" % (k, us, fbytes / us / 1e6, fbytes / 1e6))
+        _lib.raw().cdlrm_debug_set(4, 0)
+        for k in (1, 2):
+            _lib.raw().cdlrm_debug_set(5, k)
+            us = timeit(lambda: ops.gather_interact_bwd(ctx, slots, xonly[:, 0, :], dR, False, dfeat2, x_act=1))
+            print("fused backward, %d workgroups per CU: %6.1f us" % (k, us))
+        _lib.raw().cdlrm_debug_set(5, 0)
+
     if want("interact_beside"):
         # the interaction forward (HBM-bound, on the critical path) beside a weight-gradient GEMM on another stream: how much
         # does each lose?  (Would deferring the last top-MLP weight gradient under the next step's interaction pay?)
