@@ -421,7 +421,7 @@ def interact_bwd(feat: torch.Tensor, dR: torch.Tensor, itself: bool, dfeat: torc
 
 def gather_interact_supported(ctx: CacheCtx) -> bool:
     """Shapes the fused gather + interaction kernels take (D in 32 / 64 / 128 / 256, 16 < T + 1 <= 32)."""
-    return bool(_lib.lib().cdlrm_gather_interact_supported(ctx.handle))
+    return bool(_lib.raw().cdlrm_gather_interact_supported(ctx.handle))      # (a query: never on a step's tape)
 
 
 def gather_interact_fwd(ctx: CacheCtx, slots: torch.Tensor, x: torch.Tensor, itself: bool, R: torch.Tensor, stream=None):

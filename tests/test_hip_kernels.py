@@ -580,7 +580,7 @@ def test_fused_gather_interaction_equals_the_two_operators(ops, B, T, D, itself,
     feat[:, 0, :] = x
     poisoned = torch.full((B, F, D), float("nan"), device=DEV)
     poisoned[:, 0, :] = x
-    ops.embbag_fwd(ctx, slots, None, feat[:, 1:, :], F * D, D, n_bags=B)
+    ops.embbag_fwd(ctx, slots[:, :B].contiguous(), None, feat[:, 1:, :], F * D, D)
     R, R2 = torch.full((B, ld), 7.0, device=DEV), torch.full((B, ld), 7.0, device=DEV)
     ops.interact_fwd(feat, bool(itself), R)
     ops.gather_interact_fwd(ctx, slots, poisoned[:, 0, :], bool(itself), R2)
@@ -591,7 +591,7 @@ def test_fused_gather_interaction_equals_the_two_operators(ops, B, T, D, itself,
     ops.gather_interact_bwd(ctx, slots, poisoned[:, 0, :], dR, bool(itself), dfeat2, x_act=x_act)
     assert torch.equal(dfeat, dfeat2)
     if B <= 4100:
-        rb = torch.tensor(ctx.row_base[:T] if hasattr(ctx, "row_base") else np.cumsum([0] + rows_of[:-1]), device=DEV).view(T, 1)
+        rb = torch.tensor(ctx.row_base[:T], device=DEV).view(T, 1)
         rows = weight[(slots[:, :B].to(torch.int64) + rb).reshape(-1)].view(T, B, D)
         f = torch.cat([x.unsqueeze(1), rows.permute(1, 0, 2)], dim=1).cpu().double().requires_grad_(True)
         ref = O.interact_features(f[:, 0, :], [f[:, k, :] for k in range(1, F)], "dot", bool(itself))
