@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="keep the GPU busy this long between the warm-up steps and the timed region (0: off)")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--no-fuse-gather", action="store_true",
+                    help="gather + interaction as two launches (TrainEngine.fuse_gather = False): the schedule up to round 4's "
+                         "first session, kept for A/B lines")
     return ap.parse_args()
 
 
@@ -230,6 +233,9 @@ def main():
     cfg, ln_emb, cg, eng, pipe, syn = wl["cfg"], wl["ln_emb"], wl["cg"], wl["eng"], wl["pipe"], wl["syn"]
     D, B, L = wl["D"], wl["B"], wl["L"]
     lbs = math.ceil(B / world)
+    if a.no_fuse_gather:
+        eng.fuse_gather = False
+    fused = eng._fused_gather(None)     # the cache rows are the interaction forward's operand loads: no stand-alone gather in the step
     if B % world:
         # (the engine and Run handle a short last rank slice -- tests/test_distributed_gloo.py, world 3 --; the bench's synthetic
         #  stream is cut into equal rank slices)
@@ -417,11 +423,41 @@ def main():
     loss = float(eng._bufs[lbs]["loss"][0])
     pipe.close()            # (a plan launched late in the run may still be gathering rows: never exit under it)
 
+    # The cached EmbeddingBag gather as an OPERATOR of its own (cdlrm_embbag_fwd: the product path of multi-hot bags, "cat" and
+    # shapes outside the fused kernels; up to round 4's first session also this step's) -- when the step runs the fused kernel,
+    # the operator is timed here, stand-alone, after the timed region: 30 launches on the last batch's slot ids into the
+    # engine's own feature block, each with its launch-attached events.
+    op_us = []
+    if rank == 0 and fused and a.gather_sample > 0:
+        last = total_steps - 1
+        w_, jj_ = divmod(last, L)
+        if C:
+            win_t, jloc = state["chunk"], last % C
+        else:
+            win_t, jloc = state["win"], jj_
+        idx_l = win_t[:, jloc * B + rank * lbs: jloc * B + rank * lbs + lbs]
+        slots_l, _, _ = _ops.embbag_probe(cg.ctx, idx_l, aux_phase=eng._phase)
+        feat_l = eng._buffers(lbs)["feat"]
+        pairs = [(_ops.TimingEvent(), _ops.TimingEvent()) for _ in range(35)]
+        for e0, e1 in pairs:
+            _ops.time_next_gather(cg.ctx, e0, e1)
+            _ops.embbag_fwd(cg.ctx, slots_l, None, feat_l[:, 1:, :], feat_l.stride(0), D)
+        torch.cuda.synchronize()
+        op_us = [e0.elapsed_us(e1) for e0, e1 in pairs[5:]]
+
     if rank == 0:
         g_us = [e0.elapsed_us(e1) for e0, e1 in ev_pairs]
         gather_ms = float(np.mean(g_us)) * 1e-3 if g_us else float("nan")
         lookups = lbs * len(ln_emb)
-        alg_bytes = lookups * (8 * D + 16)          # fp32 row read + fp32 row write + int64 index + int64 offset
+        survey_bytes = lookups * (8 * D + 16)       # fp32 row read + fp32 row write + int64 index + int64 offset
+        if fused:
+            # what the fused kernel has to move: per lookup the row and its int32 slot id, per sample the dense feature and the
+            # interaction row it writes (D + T(T+1)/2 floats on a 4-float pitch).  The pooled rows -- half of the SURVEY's
+            # per-lookup figure -- are never written, so pricing the launch at 8D + 16 would credit bytes that do not move
+            Tn = len(ln_emb)
+            alg_bytes = lookups * (4 * D + 4) + lbs * 4 * D + lbs * 4 * ((D + Tn * (Tn + 1) // 2 + 3) // 4 * 4)
+        else:
+            alg_bytes = survey_bytes
         achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms == gather_ms and gather_ms > 0 else None
         # HBM traffic of the gather kernel comes from separate rocprofv3 --pmc passes of this same command (PMC
         # counters cannot be read from inside the process); a committed summary applies only to its own workload
@@ -432,7 +468,8 @@ def main():
                 pp = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pp):
                     doc = json.load(open(pp))
-                    if doc.get("workload") == cfg_id and doc.get("n_gpus") == world and doc.get("alpha", 1.05) == alpha:
+                    if (doc.get("workload") == cfg_id and doc.get("n_gpus") == world and doc.get("alpha", 1.05) == alpha
+                            and doc.get("kernel_kind", "gather") == ("fused" if fused else "gather")):
                         return doc, "profiles/" + name
             return None, None
 
@@ -449,7 +486,17 @@ def main():
             frac_uniform_counter = uni["hbm_bytes_per_launch"] / (uni["kernel_us_median_during_pmc_pass"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         # what THIS kernel moves per lookup: one fp32 row in, one out, an int32 slot id -- the tag probe has already turned the
         # int64 index into a slot and Criteo's offsets are arange (no read): 12 B per lookup less than the SURVEY basis
-        kern_bytes = lookups * (8 * D + 4)
+        kern_bytes = alg_bytes if fused else lookups * (8 * D + 4)
+        gather_operator = None
+        if op_us:
+            m_us = float(np.mean(op_us))
+            gather_operator = {"kernel": "k_embbag_fwd_arange_p (cdlrm_embbag_fwd: the stand-alone operator; not in this step)",
+                               "measured": "stand-alone after the timed region, %d launches on the last batch's slot ids, "
+                                           "launch-attached HIP events" % len(op_us),
+                               "bytes_per_launch": survey_bytes, "avg_launch_us": m_us,
+                               "launch_us": {"p10": pct(op_us, 10), "p50": pct(op_us, 50), "p90": pct(op_us, 90)},
+                               "achieved": survey_bytes / m_us / 1e3, "unit": "GB/s",
+                               "frac": survey_bytes / m_us / 1e3 / HBM_PEAK_GBS}
         # row a-6 as a whole (per step: the gather, the take of the batch's slot ids / miss rows, and 1/16 of the look-ahead
         # chunk's resolve): from the committed kernel trace of this configuration (tools/a6_summary.py)
         a6 = None
@@ -457,6 +504,8 @@ def main():
         if os.path.exists(a6_path) and a.batch <= 0 and a.max_ind_range <= 0 and a.alpha == 1.05:
             a6 = json.load(open(a6_path))
             a6["source"] = "profiles/" + os.path.basename(a6_path)
+            if a6.get("gather_kernel", "gather") != ("fused" if fused else "gather"):
+                a6 = None       # (a summary of the other schedule)
         quiet = [u for u, f in zip(g_us, ev_flags) if not f]
         out = {
             "metric": "training samples/sec, Criteo-Terabyte-shape synthetic (cached data-parallel DLRM step; look-ahead "
@@ -502,10 +551,21 @@ def main():
                                        "commit_ms": refills["first_commit_ms"],
                                        "commit_ms_per_step_amortised": (refills["first_commit_ms"] / L)
                                        if refills["first_commit_ms"] is not None else None}},
-            "roofline": {"kernel": "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
-                         "basis": "achieved / frac price ALGORITHMIC bytes (SURVEY 8d: 8D+16 per lookup); repeated rows of a "
+            "roofline": {"kernel": ("k_interact_fwd_s<D/4, slabs, true> (cdlrm_gather_interact_fwd: cached EmbeddingBag gather of all "
+                                    "tables + dot interaction in one launch; the pooled rows are never written or read back)")
+                                   if fused else "k_embbag_fwd_arange (cached EmbeddingBag gather, all tables in one launch)",
+                         "basis": ("achieved / frac price the bytes the fused operator has to move: rows + slot ids (4D+4 per lookup), "
+                                   "the dense feature, the interaction rows.  The SURVEY's 8D+16 per lookup prices a pooled-row "
+                                   "write this design does not do (frac_survey_basis: above 1 means exactly that); the stand-alone "
+                                   "gather operator on the SURVEY basis is in gather_operator.  traffic / frac_counter: HBM "
+                                   "counters of this kernel (repeated rows of a skewed batch are served by L2 / Infinity Cache)")
+                                  if fused else
+                                  "achieved / frac price ALGORITHMIC bytes (SURVEY 8d: 8D+16 per lookup); repeated rows of a "
                                   "skewed batch are served by L2 / Infinity Cache, so the HBM counters see fewer bytes: "
                                   "traffic, achieved_counter and frac_counter are the same launch time on those",
+                         "fused_gather": fused,
+                         "frac_survey_basis": (survey_bytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if achieved else None,
+                         "gather_operator": gather_operator,
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          # `achieved` / `frac` count ALGORITHMIC bytes (every lookup reads a row); `traffic` is what the

@@ -17,7 +17,10 @@ import os
 import statistics
 import sys
 
-GATHER, TAKE = "k_embbag_fwd_arange", "k_take"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import roofkernel  # noqa: E402
+
+TAKE = "k_take"
 RESOLVE = ("k_probe", "k_victim_pos", "k_resolve_seg")
 
 
@@ -27,11 +30,15 @@ def main():
     D = int(sys.argv[4]) if len(sys.argv) > 4 else 128
     kt = sorted(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)[-1]
     dur = {}
-    for r in csv.DictReader(open(kt)):
+    rows = list(csv.DictReader(open(kt)))
+    which = roofkernel.pick({r["Kernel_Name"] for r in rows})
+    for r in rows:
         name = r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
+        if roofkernel.kind(r["Kernel_Name"]) == which:
+            name = "<the gather>"       # the stand-alone gather, or the interaction forward that does the gather (fused)
         dur.setdefault(name, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    steps = len(dur.get(GATHER + "_p", dur.get(GATHER, [])))
-    gname = GATHER + "_p" if GATHER + "_p" in dur else GATHER
+    gname = "<the gather>"
+    steps = len(dur.get(gname, []))
     g = dur[gname][10:] if steps > 30 else dur[gname]
     take = dur.get(TAKE, [])
     take = take[10:] if len(take) > 30 else take
@@ -41,7 +48,11 @@ def main():
     resolve_us = res_total / max(1, steps)
     whole = gather_us + take_us + resolve_us
     alg = lookups * (8 * D + 16)
-    doc = {"source": kt.split("gpurun_out/")[-1], "steps_in_trace": steps,
+    if which == "fused":
+        # the row's work is now: read the rows (+ slot ids) -- the pooled output is never written; the fused kernel's time also
+        # holds the interaction forward itself (a-9), which no longer has a launch of its own
+        alg = lookups * (4 * D + 4)
+    doc = {"source": kt.split("gpurun_out/")[-1], "steps_in_trace": steps, "gather_kernel": which,
            "gather_us": gather_us, "take_us_in_step": take_us, "window_resolve_us_per_step_amortised": resolve_us,
            "resolve_launches": res_launches, "a6_us_per_step": whole,
            "algorithmic_bytes_per_step": alg, "roofline_us_at_8TBps": alg / 8e6,

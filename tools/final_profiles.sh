@@ -46,7 +46,7 @@ if [ -n "$C5" ]; then
   STEPS=24 WARMUP=6 PASSES="stats fetch write" bash tools/profile_round.sh c5 --config c5
   P5=$ROOT/gpurun_out/prof_c5
   python3 tools/pmc_summary.py $P5/fetch $P5/write $OUT/${TAG}_gather_pmc_c5_a1p05.json c5 1.05
-  python3 tools/gather_launches.py $P5/stats $OUT/${TAG}_c5_gather_launches.json $((65536 * 26 * 1040))
+  python3 tools/gather_launches.py $P5/stats $OUT/${TAG}_c5_gather_launches.json 65536
 fi
 echo "== rocprofv3 kernel trace (per-rank batch 1024)"
 PASSES=stats bash tools/profile_round.sh b1024 --batch 1024

@@ -14,7 +14,8 @@ import os
 import statistics
 import sys
 
-GATHER = "k_embbag_fwd_arange"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import roofkernel  # noqa: E402
 PLAN = ("k_bm_", "k_uniq_probe", "k_kept_flags", "k_assign", "k_winner", "k_host_rows", "k_victim", "k_cf_", "k_scan_tops",
         "k_prot_clear", "k_commit", "k_writeback")
 
@@ -26,11 +27,16 @@ def pct(v, q):
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
-    nbytes = float(sys.argv[3]) if len(sys.argv) > 3 else 8192 * 26 * (8 * 128 + 16)
     kt = sorted(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)[-1]
     rows = list(csv.DictReader(open(kt)))
+    which = roofkernel.pick({r["Kernel_Name"] for r in rows})
+    # bytes per launch: argv[3] = lookups per table and launch (default 8192; T = 26, D = 128) -- priced per kernel kind
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+    survey_bytes, nbytes = roofkernel.bytes_per_launch(which, B, 26, 128)
+    if which == "gather":
+        nbytes = survey_bytes       # (the stand-alone gather is priced on the SURVEY's 8D + 16, as in every earlier round)
     plan = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if any(p in r["Kernel_Name"] for p in PLAN))
-    g = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if GATHER in r["Kernel_Name"]]
+    g = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if roofkernel.kind(r["Kernel_Name"]) == which]
     g = g[10:] if len(g) > 30 else g                       # warm-up launches
     dur, quiet = [], []
     import bisect
@@ -49,7 +55,13 @@ def main():
         return {"launches": len(v), "mean_us": statistics.mean(v), "p10_us": pct(v, 10), "p50_us": pct(v, 50), "p90_us": pct(v, 90),
                 "min_us": min(v), "max_us": max(v), "GBps_at_mean": nbytes / statistics.mean(v) / 1e3,
                 "GBps_at_p50": nbytes / pct(v, 50) / 1e3, "frac_of_8TBps_at_mean": nbytes / statistics.mean(v) / 1e3 / 8000.0}
-    doc = {"source": kt.split("gpurun_out/")[-1], "kernel": GATHER, "algorithmic_bytes_per_launch": nbytes,
+    gname = sorted({r["Kernel_Name"].replace("void ", "").split("(")[0] for r in rows if roofkernel.kind(r["Kernel_Name"]) == which})
+    doc = {"source": kt.split("gpurun_out/")[-1], "kernel": gname[0] if gname else None, "kernel_kind": which,
+           "algorithmic_bytes_per_launch": nbytes,
+           "basis": ("fused gather + interaction: what the kernel moves -- per lookup the row and its slot id (4D + 4), per sample the "
+                     "dense feature and the interaction row; the pooled rows are never written (the SURVEY's 8D + 16 per lookup "
+                     "= %d bytes would price a write that does not exist)" % survey_bytes) if which == "fused"
+                    else "SURVEY 8(d): 8D + 16 per lookup",
            "all_launches": summ(dur), "launches_not_beside_a_window_plan": summ(quiet),
            "note": "durations are rocprofv3 kernel-trace End - Start; the profiled run is slower per step than the "
                    "un-profiled one (host-bound under the tracer) but a kernel's own duration is not"}

@@ -15,7 +15,8 @@ import os
 import statistics
 import sys
 
-GATHER = "k_embbag_fwd_arange"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import roofkernel  # noqa: E402
 
 
 def load(d, ctr, skip):
@@ -44,7 +45,8 @@ def main():
     workload = sys.argv[4] if len(sys.argv) > 4 else "c3"
     alpha = float(sys.argv[5]) if len(sys.argv) > 5 else 1.05
     fe, wr = load(fetch_dir, "FETCH_SIZE", 10), load(write_dir, "WRITE_SIZE", 10)
-    gk = [k for k in fe if GATHER in k][0]
+    which = roofkernel.pick(fe)        # the fused gather + interaction kernel when the step ran it, else the stand-alone gather
+    gk = [k for k in fe if roofkernel.kind(k) == which][0]
     rd = fe[gk]["median_counter_KB"] * 1024 * 2
     wb = wr[gk]["median_counter_KB"] * 1024
     doc = {
@@ -62,8 +64,12 @@ def main():
         "hbm_read_bytes_per_launch": rd,
         "hbm_write_bytes_per_launch": wb,
         "hbm_bytes_per_launch": rd + wb,
-        "note": "reads are below the algorithmic 109 MB because repeated ids of a Zipf batch are served by L2 / "
-                "Infinity Cache; writes equal the pooled output exactly",
+        "kernel_kind": which,
+        "note": ("fused gather + interaction: reads = cache rows + slot ids + the dense feature (repeated ids of a Zipf batch are "
+                 "served by L2 / Infinity Cache), writes = the interaction rows; the pooled rows are never written"
+                 if which == "fused" else
+                 "reads are below the algorithmic 109 MB because repeated ids of a Zipf batch are served by L2 / "
+                 "Infinity Cache; writes equal the pooled output exactly"),
         "all_kernels": {k: {"FETCH_SIZE": fe[k], "WRITE_SIZE": wr.get(k)} for k in sorted(fe)},
     }
     json.dump(doc, open(dst, "w"), indent=1)

@@ -28,6 +28,9 @@ def main():
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     rows.sort(key=lambda r: r["s"])
     anchors = [i for i, r in enumerate(rows) if a.anchor in r["Kernel_Name"]]
+    if not anchors and a.anchor == "k_embbag_fwd":
+        # no stand-alone gather in the step (fused into the interaction forward, cdlrm_gather_interact_fwd): that kernel anchors
+        anchors = [i for i, r in enumerate(rows) if "k_interact_fwd" in r["Kernel_Name"]]
     if not anchors:
         sys.exit("no launch of " + a.anchor)
     i0 = anchors[a.step]
