@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="keep the GPU busy this long between the warm-up steps and the timed region (0: off)")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--debug", default="", help="development switches inside the library, 'key=value,key=value' "
+                                                "(cdlrm_debug_set; csrc/common.h): kernel-variant A/Bs, all zero in production")
     ap.add_argument("--no-fuse-gather", action="store_true",
                     help="gather + interaction as two launches (TrainEngine.fuse_gather = False): the schedule up to round 4's "
                          "first session, kept for A/B lines")
@@ -235,6 +237,9 @@ def main():
     lbs = math.ceil(B / world)
     if a.no_fuse_gather:
         eng.fuse_gather = False
+    for kv in filter(None, a.debug.split(",")):
+        k_, v_ = kv.split("=")
+        assert _lib.raw().cdlrm_debug_set(int(k_), int(v_)) == 0
     fused = eng._fused_gather(None)     # the cache rows are the interaction forward's operand loads: no stand-alone gather in the step
     if B % world:
         # (the engine and Run handle a short last rank slice -- tests/test_distributed_gloo.py, world 3 --; the bench's synthetic
@@ -439,10 +444,15 @@ def main():
         slots_l, _, _ = _ops.embbag_probe(cg.ctx, idx_l, aux_phase=eng._phase)
         feat_l = eng._buffers(lbs)["feat"]
         pairs = [(_ops.TimingEvent(), _ops.TimingEvent()) for _ in range(35)]
+        # between two launches 1 GB of scratch is copied: the rows of the launch before (113 MB at c3) would otherwise wait in
+        # the 256 MB Infinity Cache for the next one -- in a training step 0.6 ms of other traffic lies between two gathers
+        flush = torch.empty(2, 1 << 27, dtype=torch.float32, device=dev)
         for e0, e1 in pairs:
+            flush[1].copy_(flush[0])
             _ops.time_next_gather(cg.ctx, e0, e1)
             _ops.embbag_fwd(cg.ctx, slots_l, None, feat_l[:, 1:, :], feat_l.stride(0), D)
         torch.cuda.synchronize()
+        del flush
         op_us = [e0.elapsed_us(e1) for e0, e1 in pairs[5:]]
 
     if rank == 0:
@@ -491,8 +501,8 @@ def main():
         if op_us:
             m_us = float(np.mean(op_us))
             gather_operator = {"kernel": "k_embbag_fwd_arange_p (cdlrm_embbag_fwd: the stand-alone operator; not in this step)",
-                               "measured": "stand-alone after the timed region, %d launches on the last batch's slot ids, "
-                                           "launch-attached HIP events" % len(op_us),
+                               "measured": "stand-alone after the timed region, %d launches on the last batch's slot ids, 1 GB of "
+                                           "scratch copied between launches (cold caches), launch-attached HIP events" % len(op_us),
                                "bytes_per_launch": survey_bytes, "avg_launch_us": m_us,
                                "launch_us": {"p10": pct(op_us, 10), "p50": pct(op_us, 50), "p90": pct(op_us, 90)},
                                "achieved": survey_bytes / m_us / 1e3, "unit": "GB/s",

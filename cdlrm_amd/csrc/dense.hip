@@ -1363,7 +1363,11 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4};
     const size_t lds_s = (size_t)4 * (32 * 36 + D + 532) * sizeof(float);
     int64_t gp = cdiv(B, 4);
-    const int per_cu = g_cdlrm_debug[4] > 0 ? g_cdlrm_debug[4] : 2;
+    // ONE workgroup per CU, a wave walks 8 samples of a c3 batch: in the step 23.6 us against 25.2 on two and 26.5 on three
+    // (bench.py --debug 4=<n>; stand-alone 27.4 / 27.2 / 27.2).  Two samples' rows in flight per wave (a second register set,
+    // the loop unrolled by two) measured SLOWER in the step, 25.1 us: the compiler's wait counts at the joins of the unrolled
+    // loop wait for part of the younger sample's rows at every slab -- removed
+    const int per_cu = g_cdlrm_debug[4] > 0 ? g_cdlrm_debug[4] : 1;
     if (gp > 256 * per_cu) gp = 256 * per_cu;
     static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
 #define GIFWD(D4_, A_)                                                                                                \
