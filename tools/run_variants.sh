@@ -1,4 +1,6 @@
-for dbg in "" "6=2" "6=2,4=1" "6=1,4=1" "4=1" "4=3"; do
+# development: the 40-step bench line under library switches (bench.py --debug "k=v,..."), one box:
+#   bash tools/run_variants.sh "" "4=2" "6=2,4=1"
+for dbg in "${@:-}"; do
   python bench.py --steps 40 --warmup 10 --no-cpu-baseline --debug "$dbg" > gpurun_out/var.json 2> gpurun_out/var.err
   python - "$dbg" <<'PY'
 import json,sys
