@@ -16,6 +16,7 @@ run() { name=$1; shift; echo "== $name: bench.py $*"; python3 bench.py "$@" > $O
 # of a round's profiles go in two calls, on two boxes -- each half is self-consistent); default: both
 if [ "${PART:-all}" != prof ]; then
 run steps20_n1 --steps 20 --warmup 5
+run steps20_two_launches_n1 --steps 20 --warmup 5 --no-fuse-gather --no-cpu-baseline
 run default_n1
 run c3_batch1024_n1 --batch 1024 --steps 1000 --warmup 100 --no-cpu-baseline
 run c2_n1 --config c2 --steps 600 --warmup 50 --no-cpu-baseline

@@ -28,9 +28,11 @@ def main():
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     rows.sort(key=lambda r: r["s"])
     anchors = [i for i, r in enumerate(rows) if a.anchor in r["Kernel_Name"]]
-    if not anchors and a.anchor == "k_embbag_fwd":
-        # no stand-alone gather in the step (fused into the interaction forward, cdlrm_gather_interact_fwd): that kernel anchors
-        anchors = [i for i, r in enumerate(rows) if "k_interact_fwd" in r["Kernel_Name"]]
+    if a.anchor == "k_embbag_fwd":
+        # the step's gather fused into the interaction forward (cdlrm_gather_interact_fwd): that kernel anchors the steps (the
+        # stand-alone gather launches of such a trace are bench.py's operator timing after the timed region)
+        fused = [i for i, r in enumerate(rows) if "k_interact_fwd_s<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]]
+        anchors = fused or anchors
     if not anchors:
         sys.exit("no launch of " + a.anchor)
     i0 = anchors[a.step]
