@@ -51,12 +51,16 @@ def main():
     if which == "fused":
         # the row's work is now: read the rows (+ slot ids) -- the pooled output is never written; the fused kernel's time also
         # holds the interaction forward itself (a-9), which no longer has a launch of its own
-        alg = lookups * (4 * D + 4)
+        # priced on what the fused operator moves (rows + slot ids, the dense feature, the interaction rows): tools/roofkernel.py
+        T = 26
+        alg = roofkernel.bytes_per_launch("fused", lookups // T, T, D)[1]
     doc = {"source": kt.split("gpurun_out/")[-1], "steps_in_trace": steps, "gather_kernel": which,
            "gather_us": gather_us, "take_us_in_step": take_us, "window_resolve_us_per_step_amortised": resolve_us,
            "resolve_launches": res_launches, "a6_us_per_step": whole,
            "algorithmic_bytes_per_step": alg, "roofline_us_at_8TBps": alg / 8e6,
            "frac_of_8TBps_whole_row": alg / whole / 1e3 / 8000.0,
+           "basis": ("fused: the gather IS the interaction forward's operand load -- gather_us is that one kernel (rows a-6 + a-9 forward), "
+                     "priced on its own bytes" if which == "fused" else "SURVEY 8(d): 8D + 16 per lookup"),
            "note": "gather: the roofline kernel alone on the training queue; take and resolve run on side queues beside the "
                    "step's GEMMs (contended durations: k_take is ~10-19 us stand-alone); the resolve's total GPU time in the "
                    "trace is spread over the steps it covers"}
