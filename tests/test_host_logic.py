@@ -425,10 +425,38 @@ def test_two_lane_tape_replay_orders_the_lanes(built_lib):
 
 
 def test_event_consumers_reject_bad_arguments_through_their_scope_guard(built_lib):
-    """cdlrm_linear_bwd / cdlrm_interact_bwd open the scope that flushes an attached completion event on EVERY exit path; the
+    """cdlrm_linear_bwd / cdlrm_interact_bwd / cdlrm_gather_interact_bwd open the scope that flushes an attached completion event on EVERY exit path; the
     argument-check exits are reachable without a GPU (no launch happens) and must return the error code, not crash."""
     from cdlrm_amd import _lib
     L = _lib.raw()
     assert L.cdlrm_interact_bwd(None, None, 0, 0, 1, 4, 0, 0, None, None) == -22
     assert b"cdlrm_interact_bwd" in L.cdlrm_last_error()
     assert L.cdlrm_linear_bwd(None, 0, None, None, 0, None, 0, None, 0, None, None, 0, 0, 0, 0, 0, None, None) == -22
+    # the fused gather + interaction operators (the backward opens the same scope)
+    assert L.cdlrm_gather_interact_bwd(None, None, 0, None, 0, None, 0, 0, 0, 0, None, None) == -22
+    assert b"cdlrm_gather_interact_bwd" in L.cdlrm_last_error()
+    assert L.cdlrm_gather_interact_fwd(None, None, 0, None, 0, 0, 0, None, 0, None) == -22
+    assert L.cdlrm_gather_interact_supported(None) == 0
+
+
+def test_roofline_kernel_choice_and_bytes():
+    """tools/roofkernel.py: which kernel of a trace is the roofline kernel (the fused gather + interaction forward when the step
+    ran it, the stand-alone gather otherwise) and the bytes a launch is priced at -- the numbers bench.py and DESIGN.md quote."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import roofkernel as rk
+    fused = "void k_interact_fwd_s<32, 4, true>(float const*, IaGather, long, int, int, float*, long)"
+    block = "void k_interact_fwd_s<32, 4, false>(float const*, IaGather, long, int, int, float*, long)"
+    gather = "void k_embbag_fwd_arange_p<32, 4>(TableDesc const*, int, int, HIP_vector_type<float, 4u> const*, int const*, long, float*, long, long, int)"
+    assert rk.kind(fused) == "fused" and rk.kind(block) is None and rk.kind(gather) == "gather"
+    assert rk.kind("void k_interact_bwd_s<32, 4, true>(float const*)") is None
+    assert rk.pick([block, gather, "k_take<32>"]) == "gather"
+    assert rk.pick([block, gather, fused]) == "fused"          # (a fused trace also holds bench.py's stand-alone operator timing)
+    assert rk.pick([block]) is None
+    survey, own = rk.bytes_per_launch("gather", 8192, 26, 128)
+    assert survey == 221511680 and own == 8192 * 26 * (8 * 128 + 4)
+    survey, own = rk.bytes_per_launch("fused", 8192, 26, 128)
+    # rows + slot ids, the dense feature, the 479-wide interaction row on its 480-float pitch
+    assert survey == 221511680 and own == 8192 * 26 * 516 + 8192 * 512 + 8192 * 480 * 4 == 129826816
+    assert rk.bytes_per_launch("fused", 65536, 26, 128)[1] == 1038614528
