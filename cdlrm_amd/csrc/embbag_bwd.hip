@@ -470,6 +470,17 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     w.longcount = reinterpret_cast<int32_t*>(ctx->d_small + 16);       // self-resetting (k_bwd_long), zero since ctx creation
     int64_t gx = cdiv(n, gpb);
     if (gx > 65535) gx = 65535;
+    {
+        // at most 12 workgroups per CU (the position loop strides): the kernel runs on a side queue beside the weight-gradient and
+        // bottom-MLP GEMMs, and an unbounded grid (26 624 workgroups at c3, 213 k at c5) takes every free wave slot between their
+        // launches.  Same box, same process, 6 x 90 steps each (tools/ab_step.py --attr debug:1): uncapped / 12 / 8 / 6 / 4 per CU
+        // -> 0.5804 / 0.5754 / 0.5762 / 0.5977 / 0.6386 ms at c3 (10 .. 24: the same as 12), 3.762 / 3.722 ms at c5, nothing at a
+        // per-rank batch of 1024 (3328 workgroups to begin with).  Results do not depend on the grid (a position is owned by
+        // one lane group).  cdlrm_debug_set(1, n): n per CU, -1 uncapped
+        const int per_cu = g_cdlrm_debug[1] > 0 ? g_cdlrm_debug[1] : 12;
+        const int64_t cap = cdiv((int64_t)256 * per_cu, T);
+        if (g_cdlrm_debug[1] >= 0 && gx > cap) gx = cap;
+    }
     dim3 grid((unsigned)gx, (unsigned)T);
     float4* wt = reinterpret_cast<float4*>(ctx->weight);
     const int64_t aux_total = (int64_t)ctx->aux * ctx->aux_phases;
