@@ -402,12 +402,14 @@ def main():
         pw_x = torch.randn(8192, 512, device=dev)
         pw_w = torch.randn(512, 512, device=dev) * 0.04
         pw_y = torch.empty(8192, 512, device=dev)
+        pw_m = torch.empty(2, 1 << 26, device=dev)      # ... and 2 x 256 MB copied per round: the memory side under load as well
         t_pw = time.perf_counter()
         while (time.perf_counter() - t_pw) * 1e3 < a.prewarm_ms:
             for _ in range(64):
                 _ops.linear_fwd(pw_x, pw_w, None, pw_y, 1)
+            pw_m[1].copy_(pw_m[0])
             torch.cuda.synchronize()
-        del pw_x, pw_w, pw_y
+        del pw_x, pw_w, pw_y, pw_m
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
