@@ -1357,9 +1357,9 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     CDLRM_REQUIRE(n >= B && (int64_t)ctx->T * n < INT32_MAX && aligned16(x) && ld_x % 4 == 0 && ld_x >= D,
                   "slot pitch / dense-feature rows");
     CDLRM_REQUIRE(ld_r % 4 == 0 && aligned16(R) && ld_r >= ((width + 3) & ~3), "whole-float4 output rows");
+    if (B == 0) return 0;       // (an armed event pair stays armed for the next launch that can carry it)
     hipEvent_t ev0 = (hipEvent_t)ctx->ev_start, ev1 = (hipEvent_t)ctx->ev_stop;     // cdlrm_ctx_time_next_gather
     ctx->ev_start = ctx->ev_stop = nullptr;
-    if (B == 0) return 0;
     IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4};
     const size_t lds_s = (size_t)4 * (32 * 36 + D + 532) * sizeof(float);
     int64_t gp = cdiv(B, 4);
