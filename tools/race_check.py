@@ -18,7 +18,7 @@ import bench  # noqa: E402
 from cdlrm_amd.engine import WindowResolver  # noqa: E402
 
 VARIANTS = {
-    "default (three lanes, attached events, folded wait)": {},
+    "default (three lanes, attached events, folded wait, the gather fused into the interaction kernels)": {},
     "two lanes": {"tape_lanes": 2},
     "one lane": {"tape_lanes": 1},
     "recorded events": {"attach_events": False},
@@ -27,6 +27,7 @@ VARIANTS = {
     "top weight gradients behind the interaction backward": {"top_wgrad_after": "interacted"},
     "top weight gradients behind the bottom input gradients": {"top_wgrad_after": "bot_dz"},
     "top weight gradients behind the bottom weight gradients": {"top_wgrad_after": "bot_wg"},
+    "gather + interaction as two launches (the block written and read back)": {"fuse_gather": False},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
 }
