@@ -1365,8 +1365,13 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     int64_t gp = cdiv(B, 4);
     // ONE workgroup per CU, a wave walks 8 samples of a c3 batch: in the step 23.6 us against 25.2 on two and 26.5 on three
     // (bench.py --debug 4=<n>; stand-alone 27.4 / 27.2 / 27.2).  Two samples' rows in flight per wave (a second register set,
-    // the loop unrolled by two) measured SLOWER in the step, 25.1 us: the compiler's wait counts at the joins of the unrolled
-    // loop wait for part of the younger sample's rows at every slab -- removed
+    // the loop unrolled by two) measured SLOWER in the step, twice: 25.1 us as hipcc compiled it (its wait counts at the joins
+    // of the unrolled loop wait for part of the younger sample's rows at every slab), and 25.7 against 24.0 us on one box
+    // with every vector-memory instruction issued from inline asm and ONE counted wait per sample (exact: vmcnt(19) in front
+    // of the address arithmetic, nothing else; bit-identical once the 16-byte stores had wait states behind them -- the
+    // compiler reuses a store's data registers at once when it does not know the statement is a store).  More rows in flight
+    // do not help: a c3 launch is 1024 waves x 8 samples, 2.9 us per sample against 2.3 us at c5 (64 samples per wave, 0.89
+    // of 8 TB/s) -- the difference is ramp, and neither variant shortens it.  Both removed
     const int per_cu = g_cdlrm_debug[4] > 0 ? g_cdlrm_debug[4] : 1;
     if (gp > 256 * per_cu) gp = 256 * per_cu;
     static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
