@@ -80,7 +80,7 @@ void cdlrm_set_error(const char* fmt, ...);
 // on ONE box in ONE process -- box-to-box spread is larger than most single-kernel gains.  All zero in production.
 //   0: 13-wide forward on the LDS-tiled kernel   1: workgroups per CU of the embedding backward's chunk kernel (0: 12, -1: one per
 //   8 positions)   2: scalar slab reduction   3: per-op host clocks of a tape   4 / 5: workgroups per CU of the fused gather +
-//   interaction forward / backward   6: slabs of the fused forward at D = 128 (1, 2; 0: four)
+//   interaction forward / backward
 extern CDLRM_HIDDEN_DATA int g_cdlrm_debug[8];
 
 // Completion events attached to a launch (cdlrm_event_attach_next).  An event RECORDED on the training queue is a marker

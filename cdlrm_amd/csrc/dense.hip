@@ -1382,21 +1382,8 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
         hipExtLaunchKernelGGL((k_interact_fwd_s<D4_, D4_ / 8, true>), dim3((unsigned)gp), dim3(256), lds_s,           \
                               (hipStream_t)stream, ev0, ev1, 0, x, ga, B, F, itself, R, ld_r);                        \
     } while (0)
-    if (D == 128 && (g_cdlrm_debug[6] == 1 || g_cdlrm_debug[6] == 2)) {       // development: wider slabs (whole / half rows per load)
-        const int ns = g_cdlrm_debug[6];
-        const size_t lds_w = (size_t)4 * (32 * (D / ns + 4) + D + 532) * sizeof(float);
-        static size_t w1 = 0, w2 = 0;
-        if (gp > 512) gp = 512;
-        if (ns == 1) {
-            if (int rc = interact_set_lds(k_interact_fwd_s<32, 1, true>, lds_w, &w1)) return rc;
-            hipExtLaunchKernelGGL((k_interact_fwd_s<32, 1, true>), dim3((unsigned)gp), dim3(256), lds_w, (hipStream_t)stream, ev0, ev1, 0, x, ga, B, F, itself, R, ld_r);
-        } else {
-            if (int rc = interact_set_lds(k_interact_fwd_s<32, 2, true>, lds_w, &w2)) return rc;
-            hipExtLaunchKernelGGL((k_interact_fwd_s<32, 2, true>), dim3((unsigned)gp), dim3(256), lds_w, (hipStream_t)stream, ev0, ev1, 0, x, ga, B, F, itself, R, ld_r);
-        }
-        CDLRM_LAUNCH_CHECK();
-        return 0;
-    }
+    // (slabs of 256 or 512 B instead of 128 -- NS = 2, 1 at D = 128 -- measured the same in the step and 24.6-25.8 / 26.6-28.3 against
+    //  27.2 us stand-alone; the variants were removed)
     if (D == 32) GIFWD(8, s32);
     else if (D == 64) GIFWD(16, s64);
     else if (D == 128) GIFWD(32, s128);

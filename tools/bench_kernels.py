@@ -177,15 +177,6 @@ def main():
             _lib.raw().cdlrm_debug_set(4, k)
             us = timeit(lambda: ops.gather_interact_fwd(ctx, slots, xonly[:, 0, :], False, R2))
             print("fused forward,  %d workgroups per CU: %6.1f us  %.2f TB/s of its own bytes (%.1f MB)" % (k, us, fbytes / us / 1e6, fbytes / 1e6))
-        for ns in (1, 2):
-            _lib.raw().cdlrm_debug_set(6, ns)
-            for k in (1, 2):
-                _lib.raw().cdlrm_debug_set(4, k)
-                ops.gather_interact_fwd(ctx, slots, xonly[:, 0, :], False, R2)
-                ok = bool(torch.equal(R, R2))
-                us = timeit(lambda: ops.gather_interact_fwd(ctx, slots, xonly[:, 0, :], False, R2))
-                print("fused forward, %d slab(s), %d workgroups per CU: %6.1f us  (== two operators: %s)" % (ns, k, us, ok))
-        _lib.raw().cdlrm_debug_set(6, 0)
         _lib.raw().cdlrm_debug_set(4, 0)
         for k in (1, 2):
             _lib.raw().cdlrm_debug_set(5, k)
