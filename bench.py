@@ -134,6 +134,20 @@ def build_host_tables(config, *, seed, dev, rank=0, world=1, barrier=None, max_i
     """The host master tables of a bench configuration (pinned; /dev/shm-shared at world > 1)."""
     from cdlrm_amd.hostmem import make_host_tables
     cfg = CONFIGS[config]
+    # Guard: the host tables are pinned memory, and a one-GPU box of this pool admits ~320 GB per job (cgroup) -- c3 / c5 pin 96 GB
+    # (+ up to 30 GB of plan staging), c4 UNCAPPED pins 192 GB and has taken the whole machine down both times it was tried
+    # (round 1 and round 4: the box was lost before the first step).  Refuse what exceeds half of the limit unless told otherwise.
+    need = int(sum(config_tables(cfg, max_ind_range))) * cfg["D"] * 4
+    limit = None
+    try:
+        txt = open("/sys/fs/cgroup/memory.max").read().strip()
+        limit = int(txt) if txt.isdigit() else None
+    except OSError:
+        pass
+    if limit and need > limit // 2 and os.environ.get("CDLRM_ALLOW_HUGE_HOST_TABLES") != "1":
+        raise SystemExit("bench.py: config %s pins %.0f GB of host tables, more than half of this job's memory limit (%.0f GB): "
+                         "use --max-ind-range to cap the tables (DESIGN.md section 7), or CDLRM_ALLOW_HUGE_HOST_TABLES=1"
+                         % (config, need / 1e9, limit / 1e9))
     return make_host_tables(config_tables(cfg, max_ind_range), cfg["D"], device=dev, seed=seed, rank=rank, world=world,
                             shm_name="cdlrm_bench_%s" % os.environ.get("MASTER_PORT", "0"),
                             barrier=barrier or (lambda: None))
