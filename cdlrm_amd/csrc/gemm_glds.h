@@ -405,10 +405,13 @@ static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
     }
     if (gemm2_applies<A_KC, B_KC>(g)) {
         // LDS-DMA kernel.  Measured on the c3 layer shapes (tools/gemm2_bench.hip, M = 8192, all three layouts): 128x64
-        // tiles win wherever they leave >= 1 workgroup per CU (512-wide layers 40-42 us against 43-47 for 64x64), the
-        // 64x64 tile below that (128-wide output: 9.9 against 14.3 us)
+        // tiles win wherever they leave MORE than one workgroup per CU (512-wide layers 40-42 us against 43-47 for 64x64), the
+        // 64x64 tile from there down (128-wide output: 9.9 against 14.3 us).  At exactly one per CU -- the 256-wide layers at
+        // M = 8192: top forward 512 -> 256, bottom forward 512 -> 256, bottom dgrad 256 <- 128 -- 512 workgroups of 64x64 beat
+        // 256 of 128x64 in the step: 0.5740 against 0.5767 ms, six rounds of 110 steps each, every round (round 4; bit-identical:
+        // a tile's k order does not depend on its shape)
         int tm2 = 2, tn2 = 1;
-        if (g.M <= 64 || cdiv(g.M, 128) * cdiv(g.N, 64) * splits < 256) tm2 = 1;
+        if (g.M <= 64 || cdiv(g.M, 128) * cdiv(g.N, 64) * splits <= 256) tm2 = 1;
         launch_gemm2<A_KC, B_KC>(g, tm2, tn2, splits, s);
         CDLRM_LAUNCH_CHECK();
         return 0;
