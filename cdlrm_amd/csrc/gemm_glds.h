@@ -412,6 +412,11 @@ static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
         // a tile's k order does not depend on its shape)
         int tm2 = 2, tn2 = 1;
         if (g.M <= 64 || cdiv(g.M, 128) * cdiv(g.N, 64) * splits <= 256) tm2 = 1;
+        // ... and so do the short contractions (K <= 256 un-split: the dgrads 512 <- 256 of both sub-networks, eight K tiles per
+        // workgroup, where prologue and store tail weigh most): 1024 workgroups of 64x64 instead of 512 of 128x64, 0.5681 against
+        // 0.5739 ms per c3 step, six rounds, every round.  (EVERY forward / dgrad on 64x64: 0.5776 against 0.5747; the weight
+        // gradients too: 0.5819 / 0.5863 -- the 512-wide layers keep 128x64.)
+        if (splits == 1 && g.K <= 256) tm2 = 1;
         launch_gemm2<A_KC, B_KC>(g, tm2, tn2, splits, s);
         CDLRM_LAUNCH_CHECK();
         return 0;
