@@ -713,8 +713,13 @@ static void launch_gemm_v(const GemmArgs& g, dim3 grid, hipStream_t s) {
 
 // the tiled kernel needs this many 64x64 workgroups to be the better choice (2 per CU); below it the
 // LDS-free kernel's 4x finer cut wins.  CDLRM_GEMM_DIRECT=0 / 1 forces one or the other (experiments).
+// Fewer than 256 tiles of 64x64 (one per CU): the 32x32-tile kernels (staged / LDS-free), whose workgroups split the contraction.
+// The bound was 512 until round 4 -- set when the tiled kernel was the register-staged one; with the LDS-DMA kernel a 512-wide
+// layer at M = 2048 (256 tiles) is better off tiled: same box, same process, five rounds each, 0.2710 -> 0.2418 ms per step at a
+// per-rank batch of 2048 (-10.8 %), 0.1997 -> 0.1832 at c2 (B = 2048, D = 32), ties at 4096 and 8192; lower bounds LOSE at 1024
+// (128 tiles: 0.1869 at 512 / 256 against 0.1986 / 0.2046 / 0.2074 at 128 / 64 / 32).
 static inline bool gemm_use_direct(int64_t M, int64_t N, int64_t splits) {
-    return cdiv(M, 64) * cdiv(N, 64) * splits < 512;
+    return cdiv(M, 64) * cdiv(N, 64) * splits < 256;
 }
 
 // per-wave share of the contraction (a quarter, rounded up to 8 -- to 32 on the aligned path): one batch of 64, two
