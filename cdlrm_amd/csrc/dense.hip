@@ -432,7 +432,12 @@ static int mlp_wgrad_impl(int32_t n_layers, const float* const* X, const int64_t
         int64_t kchunk = M;
         int zs = 1;
         if (!tiled.empty()) {
-            const int64_t target_wgs = 1024;    // workgroups the grouped launch aims at (slabs = target / tiles)
+            // workgroups the grouped launch aims at (slabs = target / tiles).  1024 until round 4 (7 slabs for the top MLP's 160
+            // tiles); measured in the step, five rounds each: per-rank batch 1024 -- 384 / 640 / 768 / 896 / 1024 / 1536 ->
+            // 0.1802 / 0.1814 / 0.1797 / 0.1813 / 0.1856 / 0.1851 ms; 2048 -- 256 / 384 / 512 / 640 / 768 / 1024 / 2048 ->
+            // 0.2495 / 0.2489 / 0.2372 / 0.2367 / 0.2404 / 0.2416 / 0.2405: four to five slabs, not seven (fewer partial
+            // slabs to write and reduce; three is too few workgroups at 2048)
+            const int64_t target_wgs = M <= 1024 ? 768 : 640;
             int64_t splits = cdiv(target_wgs, tiles);
             const int64_t smax = cdiv(M, 4 * GBK);
             if (splits > smax) splits = smax;
