@@ -37,10 +37,14 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
 template <int E>
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __restrict__ slots, int64_t n,
                                                               uint64_t* __restrict__ keys, int32_t* __restrict__ meta,
-                                                              int npow2, int write_meta) {
+                                                              int npow2, int write_meta, int32_t* __restrict__ longcount) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
     __shared__ int wmax[16];
     const int t = blockIdx.y;
+    // the long-run list of THIS work buffer starts empty: cleared here, by the first kernel of every prepare (an apply always
+    // follows a prepare on the same buffer, in stream order), so no clearing launch sits on the queue (a 4-byte hipMemsetAsync
+    // is a 5.4 us kernel of its own) and two backward passes in flight on different work buffers share nothing
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { longcount[0] = 0; longcount[2] = 0; }
     const int chunk = SORT_THREADS * E;       // == sort_chunk(n): whole chunks, a shorter last one
     const int64_t base = (int64_t)blockIdx.x * chunk;
     const int cnt = (int)min((int64_t)chunk, n - base);
@@ -296,9 +300,9 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
     const int cnt = *longcount;
-    // The list counter lives in the context (zero at creation) and is left zero by the LAST workgroup of this kernel to
-    // finish -- every workgroup has read it by then --, so no clearing launch sits in front of the next backward (a 4-byte
-    // hipMemsetAsync is a 5.4 us kernel of its own on the queue).  longcount[2] counts the workgroups that are through.
+    // The list counter lives in the work buffer: cleared by the first kernel of every prepare (k_sort_chunks) AND left zero by
+    // the last workgroup of this kernel to finish -- every workgroup has read it by then --, so a second apply on one prepare
+    // (a benchmark loop) starts from an empty list too.  longcount[2] counts the workgroups that are through.
     __syncthreads();
     if (threadIdx.x == 0) {
         const int through = atomicAdd(longcount + 2, 1);
@@ -431,10 +435,10 @@ extern "C" int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, in
     const dim3 sgrid((unsigned)nchunks, (unsigned)T);
     const size_t slds = (size_t)SORT_THREADS * E * 8;
     const int wm = nchunks == 1 ? 1 : 0;
-    if (E == 1) hipLaunchKernelGGL(k_sort_chunks<1>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
-    else if (E == 2) hipLaunchKernelGGL(k_sort_chunks<2>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
-    else if (E == 4) hipLaunchKernelGGL(k_sort_chunks<4>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
-    else hipLaunchKernelGGL(k_sort_chunks<8>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm);
+    if (E == 1) hipLaunchKernelGGL(k_sort_chunks<1>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
+    else if (E == 2) hipLaunchKernelGGL(k_sort_chunks<2>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
+    else if (E == 4) hipLaunchKernelGGL(k_sort_chunks<4>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
+    else hipLaunchKernelGGL(k_sort_chunks<8>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
     uint64_t* cur = w.keysA;
     uint64_t* alt = w.keysB;
     for (int64_t run = chunk; run < n; run *= 2) {
@@ -467,7 +471,6 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     const int gpb = 256 / lpr;
     BwdWork w = carve(work, T, n, ctx->D);
     const uint64_t* cur = sorted_in_B(n) ? w.keysB : w.keysA;
-    w.longcount = reinterpret_cast<int32_t*>(ctx->d_small + 16);       // self-resetting (k_bwd_long), zero since ctx creation
     int64_t gx = cdiv(n, gpb);
     if (gx > 65535) gx = 65535;
     {

@@ -257,16 +257,12 @@ class WindowPipeline:
                         # nothing reads it yet), and the list again
                         t0 = _time.perf_counter()
                         side.synchronize()
-                        self.victims[self._vnext] = vic = None
-                        cap = min(self.victim_limit, int(need * 1.1) + 4096)
-                        vic = self.victims[self._vnext] = ops.Victims(self.ctx, cap)
-                        if self._commits == 0:
-                            # the very first plan: the OTHER buffer is not bound yet either -- size it now, beside a plan nobody
-                            # trains next to, instead of inside the second window (a 40 GB allocation holds the device for ~1 s)
-                            self.victims[self._vnext ^ 1] = None
-                            self.victims[self._vnext ^ 1] = ops.Victims(self.ctx, cap)
-                        plan.victims(vic, stream=side, list_only=True)
-                        voff = vic.off.cpu().tolist()
+                        old_cap, vic = vic.cap, None        # (no reference of ours keeps the old buffer alive)
+                        grown = self._grow_victims(old_cap, min(self.victim_limit, int(need * 1.1) + 4096), self._commits == 0)
+                        vic = self.victims[self._vnext]
+                        if grown:
+                            plan.victims(vic, stream=side, list_only=True)
+                            voff = vic.off.cpu().tolist()
                         bd["victims_regrown_ms"] = (_time.perf_counter() - t0) * 1e3
                     bd["victims_in_window"], bd["victim_capacity"] = int(voff[T + 1]), int(vic.cap)
                     V = min(voff[T], vic.cap)
@@ -279,6 +275,34 @@ class WindowPipeline:
                 self.planned.record(side)
         except BaseException as e:          # surfaced by commit()
             self._worker_err = e
+
+    def _grow_victims(self, old_cap: int, want: int, both: bool) -> bool:
+        """Replace the victim buffer of the window being planned (both: the other one too -- the very first plan, when neither is
+        bound: sized now, beside a plan nobody trains next to, instead of inside the second window; a 40 GB allocation holds the
+        device for ~1 s) by one of `want` rows -- or of what the device has FREE right now, less 4 GiB of headroom for the
+        trainer's own later allocations: this runs in the plan's background thread in the middle of training, where an
+        out-of-memory error would surface windows after set-up.  True: the buffers are new objects (the list has to be made
+        again); False: the old ones stay -- the misses that do not fit read the host table, as the reference serves all of them."""
+        n_buf = 2 if both else 1
+        row = 4 * self.ctx.D + 12                     # row + index + position per entry (ops.Victims)
+        free = torch.cuda.mem_get_info(self.dev)[0] if S.is_hip(self.dev) else (1 << 62)
+        free += n_buf * old_cap * row                 # what releasing the old buffer(s) gives back
+        cap = int(min(want, (free - (4 << 30)) // (n_buf * row)))
+        if cap <= old_cap:
+            return False
+        slots = [self._vnext, self._vnext ^ 1][:n_buf]
+        for c in (cap, old_cap):
+            try:
+                for i in slots:
+                    self.victims[i] = None
+                for i in slots:
+                    self.victims[i] = ops.Victims(self.ctx, c)
+                return True
+            except torch.OutOfMemoryError:          # (the allocator's view and the driver's can differ): the old size again
+                for i in slots:
+                    self.victims[i] = None
+                torch.cuda.empty_cache()
+        raise RuntimeError("victim buffers: not even the previous capacity could be allocated again")
 
     def _unique(self, window_idx, side):
         """K1 on the plan stream: one [T, n] tensor, or a window streamed as chunks (a callable returning an iterator
@@ -1311,6 +1335,13 @@ class TrainEngine:
         ctx = self.ctx
         B, n = X.shape[0], lS_i.shape[1]
         assert n <= ctx.aux, "test batch larger than the aux table (test_mini_batch_size <= aux_table_size)"
+        if self._pump is not None:
+            # Rows of the last merge are still on their way, and landing them means COLLECTIVES.  The test loop runs on rank 0
+            # only (main_no_ddp.py:478-494): a rank that issued the remaining exchanges from here would issue them alone, in
+            # other pieces and at another place of the communicator's order than its peers (a hang, or other ranks' gradients
+            # reduced into rows).  Every rank calls drain_merge() at the same step first -- Run does, in front of its rank-0
+            # test block.
+            raise RuntimeError("evaluate(): a row merge is still draining; every rank has to call drain_merge() first")
         self.finish()
         pend = self._pref
         if pend is not None and pend["phase"] == self._phase:
@@ -1343,9 +1374,15 @@ class TrainEngine:
             cur = torch.clamp(cur, min=self.loss_threshold, max=1.0 - self.loss_threshold)
         return cur
 
+    def drain_merge(self):
+        """Land every row of a merge that is still travelling in deadline order (MergePump).  COLLECTIVE: call it on every rank
+        at the same step, or on none -- in front of anything only some ranks do next (the rank-0 test loop, a checkpoint)."""
+        self._pump_finish()
+
     def finish(self):
         """Order the current stream behind a deferred top-MLP update (defer_top_update): call before reading the top
-        MLP's weights, gradients or activation buffers outside step() / evaluate()."""
+        MLP's weights, gradients or activation buffers outside step() / evaluate().  Collective while a row merge is
+        draining (drain_merge): every rank calls it at the same step, as Run does at print boundaries and at the end."""
         if self.defer_top:
             S.current_stream(self.dev).wait_event(self._events["top_updated"])
         if self._emb_done is not None:          # a pipelined short-batch step leaves the embedding update un-joined
@@ -1521,9 +1558,11 @@ class TrainEngine:
         off = [int(x) for x in off_host.tolist()]
         ready = S.new_event(self.dev)
         ready.record(main)
+        # (the budget cuts the exchange into pieces: it has to be the same number on every rank -- the resolver's lbs =
+        #  ceil(B / world), not this rank's slice width, which is shorter on the last rank when world does not divide B)
         budget = int(self.merge_budget_rows)
         if self.merge_budget_auto:
-            budget = max(budget, int(self._res[0].shape[1]) * self.T)
+            budget = max(budget, int(rs.lbs) * self.T)
         self._pump = dict(rows=rows_sorted, U=U, buf=buf, scale=scale, rop=rop, off=off, K=K, step0=self.iter, issued=0,
                           waited=0, chunks=[], ready=ready, budget=budget, rs=rs, j0=j)
         self._pump_advance()

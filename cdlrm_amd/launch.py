@@ -53,7 +53,9 @@ def spawn_ranks(n: int, argv, *, script: str | None = None, module: str | None =
     env = dict(os.environ)
     env.setdefault("GPU_MAX_HW_QUEUES", "4")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between the ranks of this host
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    # the CPUs this job may USE (cgroup quota / affinity), not the machine's: os.cpu_count() says 256 on a box that grants 16
+    from .hostmem import cpu_share
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_share() // max(1, n))))
     cmd = launcher_command(n, argv, script=script, module=module, port=port)
     sys.stdout.flush()
     sys.stderr.flush()

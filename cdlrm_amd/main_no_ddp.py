@@ -527,6 +527,10 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 total_iter = total_samp = 0
                 caching_overhead = []
                 t_mark, t_excluded = time.time(), 0.0
+            if should_test and world > 1:
+                # rows of a merge that are still travelling land through collectives: every rank issues them here, at the same
+                # step, BEFORE the part only rank 0 runs (the test loop issues none)
+                eng.drain_merge()
             if rank == 0 and should_test:
                 # Testing -- only rank 0 tests (main_no_ddp.py:478-494).  The reference's `j % args.test_freq == 0`
                 # with its default test_freq = -1 is true for every j; here test_freq <= 0 means "at the end only".

@@ -136,7 +136,9 @@ int cdlrm_embbag_fwd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offset
  *            (replaces cache_group_idxs_window, main_no_ddp.py:417-423)                          */
 uint64_t cdlrm_embbag_bwd_work_bytes(int32_t num_tables, int64_t n, int32_t dim);
 /* The same in two halves: `prepare` (sort of the slot ids + run metadata into `work`) depends only on
- * the probe result, so a trainer issues it during the forward pass; `apply` consumes the gradient. */
+ * the probe result, so a trainer issues it during the forward pass; `apply` consumes the gradient.
+ * Every `apply` follows a `prepare` on the SAME work buffer, in stream order (prepare also empties the buffer's long-run list);
+ * backward passes on different work buffers share no state and may be in flight together. */
 int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, void* work, void* stream);
 int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, int64_t n_bags,
                            int64_t ld_off, const float* grad, int64_t ld_bag, int64_t ld_table, float lr,

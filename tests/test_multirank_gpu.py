@@ -524,7 +524,7 @@ def _lz_batches():
     return out
 
 
-def _lz_worker(rank, world, port, host_shared, ret, long_batch):
+def _lz_worker(rank, world, port, host_shared, ret, long_batch, auto_budget=False):
     import faulthandler
     faulthandler.dump_traceback_later(300, exit=True)
     try:
@@ -538,12 +538,14 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch):
         dev = "cuda:0"
         torch.cuda.set_device(0)
         ln_emb, D, B, L = np.array(LZ["ln_emb"]), LZ["m_spa"], LZ["B"], LZ["L"]
-        lbs = B // world
+        lbs = -(-B // world)            # ceil: the last rank's slice is shorter when world does not divide B
+        r0, r1 = min(rank * lbs, B), min((rank + 1) * lbs, B)
         nf = len(ln_emb) + 1
         ln_top = np.array([D + nf * (nf - 1) // 2] + LZ["top"])
         batches = _lz_batches()
         host0 = [h.clone() for h in host_shared] if rank == 0 else None
         outs = {}
+        eval_at, evals = -1, []
         for lazy in (True, False):
             dist.barrier()
             if rank == 0:
@@ -562,6 +564,10 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch):
                                      table_agg_freq=LZ["agg"], table_agg_op="mean", defer_top_update=True)
             eng.lazy_merge = lazy
             eng.agg_chunk_rows, eng.merge_budget_rows, eng.merge_budget_auto = 8, 8, False     # small chunks: rows stay on their way
+            if auto_budget:
+                # the per-step budget follows the rank's lookups per step: it has to be the SAME number on a rank with a short
+                # slice (it cuts the exchange into pieces; 22 * 5 rows on every rank, not 20 * 5 on the last)
+                eng.merge_budget_auto = True
             if long_batch:
                 eng.gather_alone_min = 1
             pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
@@ -577,15 +583,31 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch):
                 pipe.wait_writeback()
                 rs = engine.WindowResolver(eng, win, B, chunk=4)
                 for jj, (X, idx, T) in enumerate(wb):
-                    col = jj * B + rank * lbs
-                    nxt = win[:, col + B:col + B + lbs] if jj + 1 < L else None
-                    loss = eng.step(X[rank * lbs:(rank + 1) * lbs].to(dev), win[:, col:col + lbs],
-                                    T[rank * lbs:(rank + 1) * lbs].to(dev), j=jj, next_idx=nxt, res=rs.batch(jj),
+                    col, w_ = jj * B + r0, r1 - r0
+                    nxt = win[:, col + B:col + B + w_] if jj + 1 < L else None
+                    loss = eng.step(X[r0:r1].to(dev), win[:, col:col + w_],
+                                    T[r0:r1].to(dev), j=jj, next_idx=nxt, res=rs.batch(jj),
                                     next_res=rs.batch(jj + 1) if nxt is not None else None)
                     rs.ensure(jj + rs.CH + 2)
+                    gstep = w * L + jj
                     if eng._pump is not None:
                         pending += 1
                         deferred_rows = max(deferred_rows, eng._pump["U"] - eng._pump["issued"])
+                        if pending == 1 and rank == 0:
+                            # a rank-local test loop (main_no_ddp.py:478-494 runs on rank 0 only) must not land the rows that
+                            # are still travelling: that takes collectives, which this rank would issue alone
+                            issued = eng._pump["issued"]
+                            with pytest.raises(RuntimeError, match="drain_merge"):
+                                eng.evaluate(batches[0][0].to(dev), batches[0][1].to(dev))
+                            assert eng._pump is not None and eng._pump["issued"] == issued
+                        if pending == 2:
+                            eval_at = gstep
+                    if gstep == eval_at:
+                        # what Run does at a test step: every rank drains, then rank 0 alone evaluates
+                        eng.drain_merge()
+                        assert eng._pump is None
+                        if rank == 0:
+                            evals.append(eng.evaluate(batches[0][0].to(dev), batches[0][1].to(dev)).cpu().clone())
                     losses.append(loss[0:1].clone())
             eng.finish()
             cg.ctx.check()
@@ -597,6 +619,8 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch):
         a, b = outs[True], outs[False]
         assert a["pending"] > 0 and a["deferred"] > 0, "the fixture must leave merge rows on their way across steps"
         assert b["pending"] == 0
+        assert eval_at >= 0 and (rank != 0 or (len(evals) == 2 and torch.equal(evals[0], evals[1]))), \
+            "rank 0's mid-training test batch behind drain_merge() must see the one-piece merge's rows"
         assert torch.equal(a["losses"], b["losses"]), "losses differ between the deadline-ordered and the one-piece merge"
         assert torch.equal(a["tags"], b["tags"])
         for x, y in zip(a["rows"], b["rows"]):
@@ -613,14 +637,14 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch):
         raise
 
 
-@pytest.mark.parametrize("long_batch,port", [(False, 29871), (True, 29872)])
-def test_merge_in_deadline_order_two_ranks(long_batch, port):
+@pytest.mark.parametrize("long_batch,port,world,auto_budget", [(False, 29871, 2, False), (True, 29872, 2, False),
+                                                               (True, 29873, 3, True)])
+def test_merge_in_deadline_order_two_ranks(long_batch, port, world, auto_budget):
     """engine.MergePump: the touched-row merge of step j (--table-agg-freq 7 inside windows of 24 batches) applied row by row
     before each row's next use -- the rows the next batch needs at once, the rest in deadline order over the following steps in
     small chunks -- against (a) the same run with the merge in one piece: bit for bit, losses, tags, cache rows, weights; (b)
     the oracle's 2-rank emulation of the reference's loop (main_no_ddp.py:387-423): per-rank losses 1e-5, tags exact."""
     from oracle import cdlrm_oracle as O
-    world = 2
     ln_emb, D, B, L = LZ["ln_emb"], LZ["m_spa"], LZ["B"], LZ["L"]
     nf = len(ln_emb) + 1
     ln_top = np.array([D + nf * (nf - 1) // 2] + LZ["top"])
@@ -632,7 +656,7 @@ def test_merge_in_deadline_order_two_ranks(long_batch, port):
                          world_size=world, lr=LZ["lr"], lr_embeds=LZ["lr_emb"], lookahead=L, table_agg_freq=LZ["agg"],
                          table_agg_op="mean", seed=LZ["seed"], host_tables=host0)
     batches = _lz_batches()
-    lS_o = torch.arange(B // world).repeat(len(ln_emb), 1)
+    lS_o = torch.arange(-(-B // world)).repeat(len(ln_emb), 1)
     for w in range(LZ["nwin"]):
         wb = batches[w * L:(w + 1) * L]
         torch.manual_seed(5000 + w * L)
@@ -641,7 +665,7 @@ def test_merge_in_deadline_order_two_ranks(long_batch, port):
             tr.step(jj, X, lS_o, idx, T)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_lz_worker, args=(r, world, port, host, ret, long_batch)) for r in range(world)]
+    procs = [ctx.Process(target=_lz_worker, args=(r, world, port, host, ret, long_batch, auto_budget)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
