@@ -81,44 +81,95 @@ def parse():
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--debug", default="", help="development switches inside the library, 'key=value,key=value' "
                                                 "(cdlrm_debug_set; csrc/common.h): kernel-variant A/Bs, all zero in production")
+    ap.add_argument("--whole-window", default="auto", choices=["auto", "on", "off"],
+                    help="one GPU: after the K timed steps keep training through one whole look-ahead window (L steps: one window "
+                         "commit + one WHOLE background plan) and report it as config.whole_window; value / ms_per_step stay the "
+                         "K-step figure.  auto: when the timed region itself held no commit + plan and the leg takes < 20 s")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="print what every rank of this command would ask the node for (host / pinned / HBM bytes, threads, "
+                         "streams, hardware queues, port) and exit -- no HIP call, no process group")
     ap.add_argument("--no-fuse-gather", action="store_true",
                     help="gather + interaction as two launches (TrainEngine.fuse_gather = False): the schedule up to round 4's "
                          "first session, kept for A/B lines")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, ln_emb_full, seed):
-    """The oracle (CPU restatement of the reference's path, kind "port") timed on this box's host cores, on a
-    bounded sample of the same workload: same B, D, MLPs, ways and table count, tables capped at 200k rows and the
-    cache at 20k sets so the host state is ~2 GB; 1 refill + L iterations (L sized for 10-30 s of CPU work)."""
+def cpu_baseline(cfg, ln_emb_full, seed, gpu_regime=None):
+    """The oracle (CPU restatement of the reference's path, kind "port") timed on this box's host cores, on a bounded sample
+    of the same workload IN THE WORKLOAD'S CACHE REGIME: same B, D, MLPs, ways and table count; tables capped at 2 M rows; a
+    look-ahead window of L_s batches (sized for 10-30 s of CPU work); and the cache sized so that the window's unique indices
+    stand to the cache slots as they do in the configuration on the GPU (gpu_regime["uniques_per_slot"], measured by the
+    first plan of this run) -- so sets fill up, ways are contested, rows are evicted and written back, and lookups miss at a
+    rate near the configuration's.  Two warm refills (windows 0 and 1, no steps) fill the cache; the third refill and its
+    L_s steps are timed, refill and steps separately.  `value` amortises the refill the way the configuration does: a window
+    of the configuration holds `uniques_config` unique indices and is paid once per L = cfg["L"] steps, so
+        seconds per step = step_s + refill_s * (uniques_config / uniques_sample) / L."""
     from oracle import cdlrm_oracle as O
     from cdlrm_amd.hostmem import cpu_share
+    from cdlrm_amd.model_no_ddp import isPrime
+    from cdlrm_amd.synth import CriteoSynth
     threads = min(32, cpu_share())
     torch.set_num_threads(threads)
-    ln_emb = [min(n, 200000) for n in ln_emb_full]
-    B, D = cfg["B"], cfg["D"]
+    ln_emb = [min(n, 2000000) for n in ln_emb_full]
+    B, D, ways, T = cfg["B"], cfg["D"], cfg["ways"], len(ln_emb_full)
     L = max(2, min(48, (48 * 8192) // B))
-    nf = len(ln_emb) + 1
+    nf = T + 1
     ln_top = np.array([D + nf * (nf - 1) // 2] + cfg["top"])
-    rng = np.random.RandomState(seed)
-    host = [torch.from_numpy(rng.uniform(-1, 1, size=(n, D)).astype(np.float32) * np.float32(np.sqrt(1.0 / n)))
-            for n in ln_emb]
-    tr = O.OracleTrainer(ln_emb, D, np.array(cfg["bot"]), ln_top, cache_size=min(cfg["cache"], 20000),
-                         num_ways=cfg["ways"], mini_batch_size=B, lr=cfg["lr"], lr_embeds=cfg["lr_emb"], lookahead=L,
-                         table_agg_freq=10 ** 9, seed=seed, host_tables=host, cache_init="zeros")
-    from cdlrm_amd.synth import CriteoSynth
+    gen = torch.Generator().manual_seed(seed)       # (8 GB of host rows: torch's float32 generator, not numpy's float64 one)
+    host = [torch.empty(n, D).uniform_(-float(np.sqrt(1.0 / n)), float(np.sqrt(1.0 / n)), generator=gen) for n in ln_emb]
     syn = CriteoSynth(ln_emb, cfg["bot"][0], B, seed=seed, alpha=1.05, device="cpu")
-    win = syn.window(0, L)
-    lS_o = torch.arange(B).repeat(len(ln_emb), 1)
+    wins = [syn.window(w, L) for w in range(3)]
+    uniq = [int(torch.unique(wins[2][k]).numel()) for k in range(T)]
+    # cache geometry of the sample: the largest --cache-size whose slots hold at most uniques / target of the window's uniques
+    target = float((gpu_regime or {}).get("uniques_per_slot") or 1.0)
+
+    def slots_at(c):
+        P = next(i for i in range(c, 2 * c) if isPrime(i))
+        return sum(ways * min(n, P) for n in ln_emb)
+
+    lo, hi = 4, max(8, min(cfg["cache"], 2000000))
+    while lo < hi:              # slots_at is monotone in c
+        mid = (lo + hi + 1) // 2
+        if sum(uniq) / slots_at(mid) >= target:
+            lo = mid
+        else:
+            hi = mid - 1
+    cache_size = lo
+    tr = O.OracleTrainer(ln_emb, D, np.array(cfg["bot"]), ln_top, cache_size=cache_size, num_ways=ways, mini_batch_size=B,
+                         lr=cfg["lr"], lr_embeds=cfg["lr_emb"], lookahead=L, table_agg_freq=10 ** 9, seed=seed,
+                         host_tables=host, cache_init="zeros")
+    lS_o = torch.arange(B).repeat(T, 1)
+    tr.refill(wins[0])
+    tr.refill(wins[1])
     t0 = time.perf_counter()
-    tr.refill(win)
+    ev, _ = tr.refill(wins[2])
+    refill_s = time.perf_counter() - t0
+    evictions = int(sum(int(torch.unique(i).numel()) for i, _ in ev))
+    misses = 0
+    t1 = time.perf_counter()
     for j in range(L):
-        X, T = syn.dense(j)
-        tr.step(j, X, lS_o, win[:, j * B:(j + 1) * B], T)
-    dt = time.perf_counter() - t0
-    return {"value": L * B / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "oracle (torch-CPU restatement): %d iterations + 1 refill at L=%d, B=%d, D=%d, 26 tables capped "
-                      "at 200k rows, cache %d x %d-way; %.1f s" % (L, L, B, D, min(cfg["cache"], 20000), cfg["ways"], dt)}
+        X, Tt = syn.dense(2 * L + j)
+        tr.step(j, X, lS_o, wins[2][:, j * B:(j + 1) * B], Tt)
+    step_s = (time.perf_counter() - t1) / L
+    for cg_l in tr.touched[0]:          # slot ids of every step: a lookup served from the aux rows is a miss (model_no_ddp.py:176-179)
+        misses += sum(int((cg_l[k].long() >= ways * int(tr.cache_sizes[k])).sum()) for k in range(T))
+    u_cfg = (gpu_regime or {}).get("window_uniques")
+    scale = (u_cfg / sum(uniq)) if u_cfg else (cfg["L"] / L)
+    per_step = step_s + refill_s * scale / cfg["L"]
+    return {"value": B / per_step, "unit": "samples/s", "cores": threads, "kind": "port",
+            "step_s": step_s, "refill_s": refill_s, "refill_s_scaled_to_the_config_window": refill_s * scale,
+            "refill_amortised_over_steps": cfg["L"], "hit_rate": 1.0 - misses / float(L * B * T), "evictions": evictions,
+            "window_uniques": int(sum(uniq)), "cache_slots": int(slots_at(cache_size)),
+            "uniques_per_slot": sum(uniq) / slots_at(cache_size), "cache_size_flag": int(cache_size),
+            "config_regime_on_the_gpu": gpu_regime,
+            "sample": "oracle (torch-CPU restatement of the reference's path), %d threads: 26 tables capped at 2 M rows, B=%d, "
+                      "D=%d, %d-way, look-ahead window of %d batches, --cache-size %d chosen so that window uniques : cache "
+                      "slots = %.2f as in the configuration's first window on the GPU; two warm refills, then ONE refill "
+                      "(%.2f s, %d rows evicted and written back) and %d steps (%.3f s each, hit rate %.3f) timed; value = B / "
+                      "(step_s + refill_s x %.1f / %d): the refill scaled to the configuration's window (%s unique indices "
+                      "against %d here) and paid once per L = %d steps"
+                      % (threads, B, D, ways, L, cache_size, sum(uniq) / slots_at(cache_size), refill_s, evictions, L, step_s,
+                         1.0 - misses / float(L * B * T), scale, cfg["L"], str(u_cfg), sum(uniq), cfg["L"])}
 
 
 def config_tables(cfg, max_ind_range=-1):
@@ -128,6 +179,136 @@ def config_tables(cfg, max_ind_range=-1):
     if max_ind_range > 0:
         ln_emb = [min(n, max_ind_range) for n in ln_emb]
     return ln_emb
+
+
+def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, steps=20, warmup=5, prewarm=True, cpus=None,
+                   mem_limit=None):
+    """What ONE rank of `bench.py --gpus world` asks the node for -- computed without a HIP call (`--plan-only` prints it
+    for every rank; build_workload() takes its thread counts from here, so the plan and the run cannot disagree).
+    cpus: the CPUs the whole job may use (default: the cgroup quota / affinity mask, hostmem.cpu_share())."""
+    from cdlrm_amd.hostmem import cpu_share
+    from cdlrm_amd.model_no_ddp import isPrime
+    cfg = dict(CONFIGS[config])
+    if lookahead > 0:
+        cfg["L"] = lookahead
+    if batch > 0:
+        cfg["B"] = batch
+    ln_emb = config_tables(cfg, max_ind_range)
+    D, B, L, ways, T = cfg["D"], cfg["B"], cfg["L"], cfg["ways"], len(ln_emb)
+    lbs = -(-B // world)
+    cpus = int(cpus) if cpus else cpu_share()
+    per_rank = max(1, cpus // world)
+    notes = []
+    # threads that SPIN while steps are replayed: the issuing thread + one helper per extra tape lane (engine.tape_lanes: three
+    # lanes below a local batch of 4096).  A rank that does not get a CPU per spinning thread issues its step from one thread.
+    lanes = 3 if lbs < 4096 else 1
+    if lanes > 1 and per_rank < lanes + 1:
+        notes.append("only %d CPUs per rank: launch tapes replay in ONE lane (three need %d)" % (per_rank, lanes + 1))
+        lanes = 1
+    gather_threads = min(32, per_rank - 3)
+    if gather_threads < 4:
+        gather_threads = max(1, per_rank - lanes)
+        notes.append("only %d CPUs per rank: %d row-gather threads for the window plan (a roomy box gets 4-32)"
+                     % (per_rank, gather_threads))
+    P = next(i for i in range(cfg["cache"], 2 * cfg["cache"]) if isPrime(i))
+    sets = [min(n, P) for n in ln_emb]
+    cache_rows = sum(ways * p + 2 * B for p in sets)
+    total_steps = warmup + (min(steps, 50) if prewarm else 0) + steps
+    n_windows = (total_steps + L - 1) // L + 1
+    win_bytes = T * L * B * 8
+    streamed = not (n_windows * win_bytes <= (64 << 30)) and win_bytes > (16 << 30)
+    per_table = [min(L * B, n) for n in ln_emb]
+    cap_uniq = max(16, sum(per_table))
+    cap_win = max(16, sum(min(u, ways * p) for u, p in zip(per_table, sets)))
+    victims0 = min(cap_uniq, (8 << 30) // (4 * D))
+    hbm = {
+        "cache_rows": cache_rows * D * 4, "tags": sum(sets) * ways * 8,
+        "window_indices": (T * 8 * B * max(c for c in range(1, L + 1) if L % c == 0 and c * T * B * 8 <= (4 << 30)) * 2)
+        if streamed else n_windows * win_bytes,
+        "plan_lists_and_staging": cap_uniq * (8 + 4 + 3) + cap_win * (4 + 8 * 4 + 4 * D) + cache_rows * 4 + sum(ln_emb) // 8,
+        "victim_rows_2_buffers_initial": 2 * victims0 * (4 * D + 12),
+        "victim_rows_2_buffers_limit": "each grows with the window up to a fifth of HBM, never past what is free less 4 GiB",
+        "resolver_ring": 3 * 2 * T * (16 if world == 1 else 32) * B * 4,
+        "step_buffers": lbs * 4 * (2 * (T + 1) * D + 2 * (D + T * (T + 1) // 2 + 4)
+                                   + 2 * sum(cfg["bot"][1:]) + 2 * sum(cfg["top"])),
+    }
+    hbm["sum_without_growth"] = int(sum(v for v in hbm.values() if isinstance(v, int)))
+    host_tables = int(sum(ln_emb)) * D * 4
+    # pinned staging of the plan's row lists (winners + window victims), this rank's 1/world slice (sharded fetch)
+    staging = int(1.25 * (cap_win + victims0) * (4 * D + 8) / world)
+    streams = ["train (priority -1)", "side (embedding backward, take, sort)", "pref / weight gradients",
+               "window plan (least priority)"] + (["exchange (row merge)", "ProcessGroupNCCL's own stream"] if world > 1 else [])
+    out = {
+        "config": config, "world": world, "global_batch": B, "local_batch": lbs, "lookahead": L,
+        "cpus_of_the_job": cpus, "cpus_per_rank": per_rank, "omp_num_threads": max(1, cpus // world),
+        "tape_lanes": lanes, "spinning_threads": lanes, "plan_gather_threads": gather_threads, "plan_worker_threads": 1,
+        "hip_streams": streams, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0 (set by the launcher)"),
+        "host_tables_bytes_one_mapping_per_node": host_tables,
+        "host_tables_mapping": ("/dev/shm file created by rank 0 (first touch: rank 0's NUMA node), mapped and hipHostRegister-ed "
+                                "by every rank") if world > 1 else "pinned allocations of this process",
+        "pinned_staging_bytes_per_rank": staging, "hbm_bytes_per_rank": hbm, "notes": notes,
+    }
+    limit = mem_limit
+    if limit is None:
+        try:
+            txt = open("/sys/fs/cgroup/memory.max").read().strip()
+            limit = int(txt) if txt.isdigit() else None
+        except OSError:
+            limit = None
+    out["host_memory_limit_bytes"] = limit
+    refuse = []
+    if limit and host_tables + world * staging > 0.9 * limit:
+        refuse.append("host tables (%.0f GB) + %d x pinned staging (%.1f GB) exceed 90 %% of the job's memory limit (%.0f GB)"
+                      % (host_tables / 1e9, world, staging / 1e9, limit / 1e9))
+    if hbm["sum_without_growth"] > 280e9:
+        refuse.append("%.0f GB of HBM per rank before the victim buffers grow" % (hbm["sum_without_growth"] / 1e9))
+    if B % world:
+        refuse.append("the global batch %d does not divide by %d ranks" % (B, world))
+    out["refused"] = refuse
+    return out
+
+
+# DESIGN.md section 6, "projection": one-GPU per-rank steps MEASURED at the per-rank batch + PRICED exchanges (nothing here ran on
+# xGMI).  Printed beside the measured value of an N-rank run (config.projection) so that a SCALE record reads against it.
+PROJECTION = {
+    "assumptions": "per-step bottom-MLP exchange on the critical path 15 / 20 / 25 us at 2 / 4 / 8 ranks; row merge in deadline "
+                   "order: its first class (2.3 % of 0.95 GB per 100 steps at c3, 4.5 GB at c5) at 70 / 150 / 170 GB/s in front of "
+                   "the next step, the rest in the background; one-GPU step = the N=1 line of the same build",
+    "c3": {1: dict(per_rank_step_ms=0.5952, projected_step_ms=0.5952, projected_scaling=1.0),
+           2: dict(per_rank_step_ms=0.3340, projected_step_ms=0.352, projected_scaling=1.69),
+           4: dict(per_rank_step_ms=0.2389, projected_step_ms=0.260, projected_scaling=2.29),
+           8: dict(per_rank_step_ms=0.1834, projected_step_ms=0.209, projected_scaling=2.84)},
+    "c5": {1: dict(per_rank_step_ms=3.788, projected_step_ms=3.788, projected_scaling=1.0),
+           2: dict(per_rank_step_ms=1.91, projected_step_ms=1.94, projected_scaling=1.95),
+           4: dict(per_rank_step_ms=0.96, projected_step_ms=0.987, projected_scaling=3.84),
+           8: dict(per_rank_step_ms=0.5733, projected_step_ms=0.604, projected_scaling=6.27)},
+}
+
+
+def projection_for(config, world):
+    row = PROJECTION.get(config, {}).get(world)
+    if row is None:
+        return None
+    return dict(row, source="DESIGN.md section 6 (one-GPU measurement + priced exchanges; NOT measured on xGMI)",
+                assumptions=PROJECTION["assumptions"])
+
+
+def plan_only(a):
+    """`bench.py --gpus N --plan-only`: one JSON object per rank + a verdict line; exit code 1 when a rank cannot fit."""
+    from cdlrm_amd import launch
+    port = int(os.environ.get("MASTER_PORT", "0")) or launch.free_port()
+    res = rank_resources(a.config, a.gpus, lookahead=a.lookahead, batch=a.batch, max_ind_range=a.max_ind_range,
+                         steps=a.steps, warmup=a.warmup, prewarm=a.prewarm_ms > 0)
+    for r in range(a.gpus):
+        print(json.dumps(dict(res, rank=r, hip_device=r, master_addr="127.0.0.1", master_port=port,
+                              writes_evictions_back=(r == 0), projection=projection_for(a.config, a.gpus))))
+    if res["refused"]:
+        print("bench.py --plan-only: REFUSED -- " + "; ".join(res["refused"]), file=sys.stderr)
+        return 1
+    for n in res["notes"]:
+        print("bench.py --plan-only: note -- " + n, file=sys.stderr)
+    return 0
 
 
 def build_host_tables(config, *, seed, dev, rank=0, world=1, barrier=None, max_ind_range=-1):
@@ -191,11 +372,13 @@ def build_workload(config, *, lookahead=-1, batch=-1, host=None, seed=123, dev=N
                       table_agg_freq=cfg["agg"], table_agg_op="mean", defer_top_update=defer_top)
     # launches replayed from the engine's recorded tapes + cross-iteration pipelining of the probe / aux fill at
     # every N (a hipGraph capture of the step was measured slower at local batches 1024 .. 8192 and was dropped)
+    # CPU threads of the plan's row gather and the launch tapes' lanes: what the box grants this rank (cgroup quota, not the
+    # machine's core count), less the threads that issue the step (rank_resources: the numbers --plan-only prints)
+    res = rank_resources(config, world, lookahead=lookahead, batch=batch, max_ind_range=max_ind_range)
+    if res["tape_lanes"] == 1:
+        eng.tape_lanes = 1
     pipe = WindowPipeline(cg, host, L * B, parity_rng=False, seed=seed, rank=rank, world_size=world,
-                          host_gather=True,
-                          # CPU threads of the plan's row gather: what the box grants this rank (cgroup quota, not the
-                          # machine's core count), less the threads that issue the step; they run at nice 19
-                          gather_threads=max(4, min(32, cpu_share() // max(1, world) - 3)), write_back=write_back)
+                          host_gather=True, gather_threads=res["plan_gather_threads"], write_back=write_back)
     syn = synth.CriteoSynth(ln_emb, int(ln_bot[0]), B, seed=seed, alpha=alpha, device=dev)
     return dict(cfg=cfg, ln_emb=ln_emb, host=host, cg=cg, dl=dl, eng=eng, pipe=pipe, syn=syn, B=B, L=L, D=D)
 
@@ -207,6 +390,8 @@ def pct(xs, q):
 def main():
     a = parse()
     from cdlrm_amd import launch
+    if a.plan_only:
+        raise SystemExit(plan_only(a))
     if a.gpus > 1 and not launch.under_launcher():
         # `python bench.py --gpus N` as typed: this process -- before its first HIP call -- starts the N ranks as children
         # (one process per GPU under torch.distributed.run, what the reference's mp.spawn does, main_no_ddp.py:638-643),
@@ -271,10 +456,29 @@ def main():
     cold_steps = min(a.steps, 50) if a.prewarm_ms > 0 else 0
     t_start = a.warmup + cold_steps
     total_steps = t_start + a.steps
+    plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
+    # The whole-window leg (one GPU): the driver's K = 20 timed steps of a 3000-step window hold neither a window commit nor a
+    # background plan, so after them the run keeps training through ONE WHOLE WINDOW -- L more steps, timed on their own, holding
+    # exactly one plan launch (at iteration plan_at of the window, the plan running beside the steps that follow) and the commit of
+    # that plan at the window boundary -- and reports it as config.whole_window.  value / ms_per_step stay the K-step figure.
+    # WW_LEAD untimed steps in front record the leg's launch tapes (steps without the roofline kernel's timing events are
+    # another control path).  It needs the K steps to end before plan_at; a timed region that already crossed a boundary and
+    # launched a plan (the default 3000-step run) IS a whole window and is reported as such.
+    WW_LEAD = 8
+    ww_why = None
+    if world > 1:
+        ww_why = "one GPU only"
+    elif a.whole_window == "off":
+        ww_why = "--whole-window off"
+    elif L < 2 * WW_LEAD or total_steps + WW_LEAD > plan_at:
+        ww_why = ("the timed region ends at iteration %d, behind the window's plan launch at %d: see refills_in_timed_region"
+                  % (total_steps, plan_at))
+    ww_j0 = total_steps + WW_LEAD
+    run_end = (ww_j0 + L) if ww_why is None else total_steps      # (reduced to total_steps below when the leg is not run)
     # The synthetic index stream is the input: generate it BEFORE the timed region (windows of L batches, int64
     # [T, L*B] each = 5.1 GB at c3) so that the timed steps see inputs already resident in HBM, as a real loader
     # thread would leave them.  Beyond the memory budget the windows are generated on the fly (inside the timing).
-    n_windows = (total_steps + L - 1) // L + 1
+    n_windows = (run_end + L - 1) // L + 1
     win_bytes = len(ln_emb) * L * B * 8
     pregen = {}
     # Windows that fit neither the pre-generation budget nor HBM as ONE tensor (c5: 8000 batches x 65536 = 109 GB) are
@@ -299,11 +503,11 @@ def main():
     # look-ahead chunks of the window-resident probe: 16 batches on one rank; 32 at world > 1, where the touched-row merge
     # orders its rows by the batches resolved ahead of it (34-65 instead of 18-33: the merge's cold part gets twice the time)
     res_chunk = 16 if world == 1 else 32
-    state = {"win": None, "next": None, "w": -1}
-    plan_at = max(1, min(L // 2, 64))      # iteration inside a window at which the next window's plan is launched
+    state = {"win": None, "next": None, "w": -1, "run_end": run_end}
     ev_pairs = []
     ev_flags = []                           # per sampled launch: did a window plan run beside it?
     refills = {"commits": 0, "plans": 0, "merges": 0, "first_plan_ms": None, "first_commit_ms": None}
+    ww_tally = {"commits": 0, "plans": 0}
     # the roofline kernel is timed with HIP events ATTACHED TO ITS LAUNCH (cdlrm_ctx_time_next_gather -> hipExtLaunchKernel:
     # timestamps the runtime takes for the launch, no event records around it; 0.5-2 us above the profiler's End - Start of the
     # same kernel).  A timed launch carries a completion signal
@@ -319,7 +523,7 @@ def main():
                for j in range(t_start, total_steps) if a.gather_sample > 0 and j % sample_every == 0}
     warm_pair = (_ops.TimingEvent(), _ops.TimingEvent())
 
-    def begin_window(w, timed):
+    def begin_window(w, timed, tally=None):
         if state["next"] is None:           # very first window: plan it synchronously
             state["next"] = get_window(w)
             t_p = time.perf_counter()
@@ -328,6 +532,11 @@ def main():
                 pipe._worker.join()
             torch.cuda.synchronize()
             refills["first_plan_ms"] = (time.perf_counter() - t_p) * 1e3
+            # the cache regime of this configuration, for the CPU baseline's sample: unique indices of the window per cache slot
+            uo_, _, _ = pipe.plan.offsets()
+            slots_ = int(sum(cg.num_ways * int(p) for p in cg.cache_sizes))
+            refills["regime"] = {"window_uniques": int(uo_[len(ln_emb)]), "cache_slots": slots_,
+                                 "uniques_per_slot": uo_[len(ln_emb)] / float(slots_)}
         if world > 1:
             eng.sync_touched_to_rank0()
         t_c = time.perf_counter() if refills["first_commit_ms"] is None else None
@@ -337,6 +546,8 @@ def main():
             refills["first_commit_ms"] = (time.perf_counter() - t_c) * 1e3
         if timed:
             refills["commits"] += 1
+        if tally is not None:
+            tally["commits"] += 1
         # where this window's plan spent its time (first window: planned stand-alone); resolved after the timed region -- reading
         # the DMA timing events waits for them
         bd = pipe.breakdown_deferred()
@@ -348,19 +559,21 @@ def main():
         state["res"] = WindowResolver(eng, state["win"], B, chunk=res_chunk) if (use_resolver and not C) else None
         state["cid"] = None
 
-    def run_step(j, timed):
+    def run_step(j, timed, tally=None):
         w, jj = divmod(j, L)
         if jj == 0:
-            begin_window(w, timed)
+            begin_window(w, timed, tally)
         # (a window the run ends before is not planned: its plan would be work for steps outside the run, and the closing
         #  device synchronisation of the timed region would wait for its row copies -- 0.3 s of a plan launched 36-86 steps before
         #  the end used to sit in the default run's 3000-step figure: 0.659 against 0.623 ms/step)
-        if (jj == plan_at or (L == 1)) and (w + 1) * L < total_steps:
+        if (jj == plan_at or (L == 1)) and (w + 1) * L < state["run_end"]:
             pipe.wait_writeback()
             state["next"] = get_window(w + 1)
             pipe.plan_window(state["next"])
             if timed:
                 refills["plans"] += 1
+            if tally is not None:
+                tally["plans"] += 1
         if C:       # streamed windows: the steps read from the current chunk
             cid, jc = divmod(j, C)
             if state.get("cid") != cid:
@@ -386,7 +599,8 @@ def main():
         rs = state.get("res")
         # (warm-up steps time their gather into a scratch pair at the same cadence: the launch tapes the timed steps replay -- a
         #  timed launch is another control path than an untimed one -- are then recorded before the timed region starts)
-        gev = ev_pool[j] if sample else (warm_pair if (not timed and a.gather_sample > 0 and j % sample_every == 0) else None)
+        gev = ev_pool[j] if sample else (warm_pair if (not timed and tally is None and a.gather_sample > 0
+                                                       and j % sample_every == 0) else None)
         eng.step(X, idx, T, j=jj, gather_events=gev, next_idx=nxt,
                  res=rs.batch(jloc) if rs is not None else None,
                  next_res=rs.batch(jloc + 1) if (rs is not None and nxt is not None) else None,
@@ -442,6 +656,41 @@ def main():
     eng.finish()
     cg.ctx.check()
     loss = float(eng._bufs[lbs]["loss"][0])
+    last_j = total_steps - 1
+
+    # ---- the whole-window leg (see above): L more steps = one plan launch + one commit, timed on their own ----
+    whole_window = None
+    if refills["commits"] >= 1 and refills["plans"] >= 1:
+        whole_window = {"source": "the timed region itself (it crossed a window boundary and launched a plan)", "steps": a.steps,
+                        "ms_per_step": dt / a.steps * 1e3, "samples_per_s": B * a.steps / dt,
+                        "window_commits": refills["commits"], "plans_launched": refills["plans"]}
+    elif ww_why is None and a.whole_window == "auto" and L * (dt / a.steps) > 20.0:
+        ww_why = "a window of %d steps takes ~%.0f s at this step time (--whole-window on runs it)" % (L, L * dt / a.steps)
+    if whole_window is None and ww_why is None:
+        for j in range(total_steps, ww_j0):
+            run_step(j, False, ww_tally)            # (untimed: the leg's launch tapes)
+        assert ww_tally["plans"] == 0 and ww_tally["commits"] == 0 and not pipe.plan_in_flight()
+        torch.cuda.synchronize()
+        t_w0 = time.perf_counter()
+        for j in range(ww_j0, ww_j0 + L):
+            run_step(j, False, ww_tally)
+        t_wi = time.perf_counter() - t_w0
+        torch.cuda.synchronize()
+        dt_w = time.perf_counter() - t_w0
+        eng.finish()
+        cg.ctx.check()
+        last_j = ww_j0 + L - 1
+        whole_window = {"source": "a leg of its own behind the timed region: %d untimed steps, then L = %d steps timed between "
+                                  "two device synchronisations; no clock pre-warm, no roofline-kernel timing events, inputs "
+                                  "resident in HBM" % (WW_LEAD, L),
+                        "steps": L, "ms_per_step": dt_w / L * 1e3, "samples_per_s": B * L / dt_w,
+                        "host_issue_ms_per_step": t_wi / L * 1e3,
+                        "window_commits": ww_tally["commits"], "plans_launched": ww_tally["plans"],
+                        "final_loss": float(eng._bufs[lbs]["loss"][0]),
+                        # the plan that ran in the background of this leg, itemised (its GPU half shares the device with the steps)
+                        "plan_breakdown_ms_background": pipe.resolve_breakdown(refills.get("breakdown_last"))}
+    elif whole_window is None:
+        whole_window = {"skipped": ww_why}
     pipe.close()            # (a plan launched late in the run may still be gathering rows: never exit under it)
 
     # The cached EmbeddingBag gather as an OPERATOR of its own (cdlrm_embbag_fwd: the product path of multi-hot bags, "cat" and
@@ -449,15 +698,19 @@ def main():
     # the operator is timed here, stand-alone, after the timed region: 30 launches on the last batch's slot ids into the
     # engine's own feature block, each with its launch-attached events.
     op_us = []
-    if rank == 0 and fused and a.gather_sample > 0:
-        last = total_steps - 1
+    gpu_regime = refills.get("regime")
+    if rank == 0:
+        last = last_j
         w_, jj_ = divmod(last, L)
         if C:
             win_t, jloc = state["chunk"], last % C
         else:
             win_t, jloc = state["win"], jj_
         idx_l = win_t[:, jloc * B + rank * lbs: jloc * B + rank * lbs + lbs]
-        slots_l, _, _ = _ops.embbag_probe(cg.ctx, idx_l, aux_phase=eng._phase)
+        slots_l, _, mc_l = _ops.embbag_probe(cg.ctx, idx_l, aux_phase=eng._phase)
+        if gpu_regime is not None:      # lookups of the last batch served from the cache (the others read aux rows)
+            gpu_regime["hit_rate_last_batch"] = 1.0 - float(mc_l.sum().item()) / float(idx_l.numel())
+    if rank == 0 and fused and a.gather_sample > 0:
         feat_l = eng._buffers(lbs)["feat"]
         pairs = [(_ops.TimingEvent(), _ops.TimingEvent()) for _ in range(35)]
         # between two launches 1 GB of scratch is copied: the rows of the launch before (113 MB at c3) would otherwise wait in
@@ -563,6 +816,10 @@ def main():
                        # none; the default 3000-step run crosses one boundary and one background plan)
                        "refills_in_timed_region": {"window_commits": refills["commits"], "plans_launched": refills["plans"],
                                                    "row_merges": refills["merges"]},
+                       # the look-ahead side INSIDE a measurement: one whole window (one commit + one whole background plan)
+                       "whole_window": whole_window,
+                       # what DESIGN.md section 6 projects for this rank count (one-GPU measurement + priced exchanges)
+                       "projection": projection_for(a.config, world) if (a.batch <= 0 and a.max_ind_range <= 0) else None,
                        # stand-alone cost of the first window's plan (unique scan, tag probe, way choice, row fetch:
                        # runs in the background of the previous window in steady state) and of its commit (row swap +
                        # tag write on the main stream: the only part on the critical path), for amortising over L
@@ -615,7 +872,7 @@ def main():
                          "launches_timed": len(ev_pairs), "sampled_every": sample_every},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, ln_emb, a.seed)
+            out["cpu_baseline"] = cpu_baseline(cfg, ln_emb, a.seed, gpu_regime)
         print(json.dumps(out))
     barrier()
     if world > 1:

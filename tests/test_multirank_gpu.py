@@ -619,14 +619,22 @@ def _lz_worker(rank, world, port, host_shared, ret, long_batch, auto_budget=Fals
         a, b = outs[True], outs[False]
         assert a["pending"] > 0 and a["deferred"] > 0, "the fixture must leave merge rows on their way across steps"
         assert b["pending"] == 0
-        assert eval_at >= 0 and (rank != 0 or (len(evals) == 2 and torch.equal(evals[0], evals[1]))), \
+        # Two ranks: a + b is one rounding whatever the order, so the two schedules agree BIT FOR BIT.  Three and more: a ring
+        # all-reduce sums an element's contributions in an order that depends on the element's place in the exchanged buffer
+        # ((a + b) + c here, (b + c) + a there), so the same rows exchanged in other pieces agree to the last rounding only -- the
+        # freedom the reference's own NCCL all-reduce has (main_no_ddp.py:279-284); the replicas still agree with each other.
+        if world == 2:
+            same = torch.equal
+        else:
+            same = lambda x, y: torch.allclose(x, y, rtol=2e-5, atol=2e-7)
+        assert eval_at >= 0 and (rank != 0 or (len(evals) == 2 and same(evals[0], evals[1]))), \
             "rank 0's mid-training test batch behind drain_merge() must see the one-piece merge's rows"
-        assert torch.equal(a["losses"], b["losses"]), "losses differ between the deadline-ordered and the one-piece merge"
+        assert same(a["losses"], b["losses"]), "losses differ between the deadline-ordered and the one-piece merge"
         assert torch.equal(a["tags"], b["tags"])
         for x, y in zip(a["rows"], b["rows"]):
-            assert torch.equal(x, y), "cache rows"
+            assert same(x, y), "cache rows"
         for x, y in zip(a["top_w"], b["top_w"]):
-            assert torch.equal(x, y)
+            assert same(x, y)
         ret.put((rank, dict(losses=a["losses"].numpy(), occ=[o.cpu().numpy() for o in cg.occupancy_tables],
                             top_w=[w.numpy() for w in a["top_w"]], pending=a["pending"])))
         dist.barrier()
@@ -681,3 +689,4 @@ def test_merge_in_deadline_order_two_ranks(long_batch, port, world, auto_budget)
             assert np.array_equal(got[r]["occ"][k], tr.occ[k].numpy()), (r, k)
         for i in range(len(got[r]["top_w"])):
             np.testing.assert_allclose(got[r]["top_w"][i], tr.top[r][0][i].numpy(), rtol=1e-4, atol=1e-6)
+            assert np.array_equal(got[r]["top_w"][i], got[0]["top_w"][i]), "weight replicas agree bit for bit"

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--only", default="")
     ap.add_argument("--alpha", type=float, default=1.05)
+    ap.add_argument("--json", default="", help="--only vendor: write the table here")
     a = ap.parse_args()
     B, D = a.B, a.D
     only = set(a.only.split(",")) if a.only else None
@@ -249,6 +250,53 @@ def main():
             plan = ops.WgradPlan(Xs, dZs, dWs, dbs, ops.mlp_wgrad_work(B, [N], [K], DEV))
             us = timeit(lambda: ops.mlp_wgrad(plan))
             print("wgrad %4d x %4d (+ slab reduction) %8.1f us   %7.1f GB/s of operands" % (N, K, us, B * (N + K) * 4 / us / 1e3))
+
+    if a.only and "vendor" in only:
+        # YARDSTICK, tools only, never product: the vendor library's fp32 GEMM (torch.mm / addmm -> hipBLASLt / rocBLAS; the
+        # reference hands its MLPs to exactly that, model_no_ddp.py:244-270) on the step's GEMM shapes, same box, same process,
+        # beside this repo's kernels.  allow_tf32 stays off: both sides compute true fp32 products.
+        import json
+        torch.backends.cuda.matmul.allow_tf32 = False
+        rows = []
+        shapes = [(512, 480), (512, 512), (256, 512), (128, 256)]       # (N = out, K = in) of the LDS-tiled layers at c3
+        for M in (8192, 65536, 1024, 2048):
+            for N, K in shapes:
+                X = torch.randn(M, K, device=DEV)
+                W = torch.randn(N, K, device=DEV) / np.sqrt(K)
+                b = torch.randn(N, device=DEV)
+                Y = torch.empty(M, N, device=DEV)
+                dY = torch.randn(M, N, device=DEV)
+                dX = torch.empty(M, K, device=DEV)
+                dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+                work = ops.linear_bwd_work(M, N, K, DEV)
+                plan = ops.WgradPlan([X], [dY], [dW], [db], ops.mlp_wgrad_work(M, [N], [K], DEV))
+                Wt = W.t()
+                dYt = dY.t()
+                fl = 2.0 * M * N * K
+                reps = 10 if M > 8192 else 30
+                r = dict(M=M, N=N, K=K, gflop=fl / 1e9)
+                r["fwd_ours_us"] = timeit(lambda: ops.linear_fwd(X, W, b, Y, 1), reps)                     # bias + ReLU fused
+                r["fwd_vendor_us"] = timeit(lambda: torch.addmm(b, X, Wt, out=Y), reps)                    # bias, no activation
+                r["fwd_vendor_relu_us"] = timeit(lambda: torch.relu_(torch.addmm(b, X, Wt, out=Y)), reps)
+                r["dgrad_ours_us"] = timeit(lambda: ops.linear_bwd(X, W, Y, dY, dX, None, None, 0, work, x_act=1), reps)  # act' fused
+                r["dgrad_vendor_us"] = timeit(lambda: torch.mm(dY, W, out=dX), reps)
+                r["wgrad_ours_us"] = timeit(lambda: ops.mlp_wgrad(plan), reps)                             # dW + db (+ slab reduce)
+                r["wgrad_vendor_us"] = timeit(lambda: torch.mm(dYt, X, out=dW), reps)
+                r["wgrad_vendor_db_us"] = timeit(lambda: (torch.mm(dYt, X, out=dW), torch.sum(dY, 0, out=db)), reps)
+                for k in ("fwd_ours", "fwd_vendor", "dgrad_ours", "dgrad_vendor", "wgrad_ours", "wgrad_vendor"):
+                    r[k + "_tflops"] = fl / r[k + "_us"] / 1e6
+                rows.append(r)
+                print("M=%6d N=%4d K=%4d | fwd ours %7.1f us (%5.1f TF) vendor %7.1f (+relu %7.1f) | dgrad ours %7.1f vendor %7.1f | "
+                      "wgrad ours %7.1f vendor %7.1f (+db %7.1f)" % (M, N, K, r["fwd_ours_us"], r["fwd_ours_tflops"], r["fwd_vendor_us"],
+                                                                    r["fwd_vendor_relu_us"], r["dgrad_ours_us"], r["dgrad_vendor_us"],
+                                                                    r["wgrad_ours_us"], r["wgrad_vendor_us"], r["wgrad_vendor_db_us"]),
+                      flush=True)
+                del X, W, Y, dY, dX, work, plan
+        if a.json:
+            json.dump({"what": "fp32 GEMMs of the c3 step: this repo's kernels (epilogues fused: bias + ReLU, act', dW + db) against "
+                               "torch.mm / addmm = the vendor library, same box, same process, back-to-back launches (HIP events "
+                               "around 10-30 launches)", "torch": torch.__version__,
+                       "device": torch.cuda.get_device_name(0), "rows": rows}, open(a.json, "w"), indent=1)
 
     if want("gemm"):
         layers = [(13, 512, 1), (512, 256, 1), (256, 128, 1), (D + 351, 512, 1), (512, 512, 1), (512, 256, 1), (256, 1, 2)]
