@@ -360,6 +360,22 @@ __global__ void __launch_bounds__(256) k_gemm2(GemmArgs g) {
 //     the epilogue stays at 10.8 k / 9.6 k cycles (11.6 k / 11.0 k) and the kernel at 41.9 / 42.6 us -- the store tail is the
 //     write burst itself (16 MB leaving 512 lock-stepped workgroups in ~5 us = 3.3 TB/s; the weight-gradient layout, whose
 //     workgroups drift apart in the loop, shows 5.0 k cycles for the same bytes), not the latency of its operands.
+//   * (round 5) the yardstick: the vendor library's fp32 GEMM on these shapes (torch.mm / addmm, tools/bench_kernels.py --only
+//     vendor, profiles/r05_gemm_vs_vendor.json): 8192 x 512 x 512 forward 38.9 us against 41.8-45.1 here, 65536 x 512 x 512
+//     251 us (137 TF/s) against 298-320 -- its kernel (rocprofv3 name: MT256x256x32_MI16x16x1 ... MIWT8_8 ... SK3) is a 256x256
+//     macro tile, 128x128 per wave, ONE workgroup per CU, stream-K over the contraction; the weight gradients go the other way
+//     (48.6 against 55.3 us, 294 against 406 at M = 65536), and with the epilogues the library leaves to other kernels (ReLU, act',
+//     bias gradient) the MLP's whole GEMM set costs 389 us here against 535 at c3, 2454 against 3287 at c5.  What was built on
+//     that evidence, measured and left in tools/ (tools/gemm2p_experiment.h, tools/gemm_big_tile.hip; bit-identical outputs):
+//     - this kernel on 128x128 / 256x128 / 128x256 / 256x256 tiles (per wave up to 128x128, one wave per SIMD): 300.7 / 317.6 /
+//       318.4 / 312.3 us against 317.7 at M = 65536, 44.2 / 76.4 / 76.9 / 145.2 against 44.2 at M = 8192 -- this loop needs its
+//       second wave per SIMD; the library's schedule at one wave per SIMD is hand-placed assembly;
+//     - a PERSISTENT form (workgroup slots walk their tiles; the K-tile DMA pipeline runs on across output tiles, so the next
+//       tile's first fragments are in LDS when the epilogue ends; the epilogue loads all bias / mask words first and its stores
+//       leave back to back and drain under the next tile's MFMAs, counted vmcnt): stand-alone 42.7 against 44.4 us at M = 8192,
+//       83.2 against 87.0 at 16384, 316 against 320 at 65536 -- and in the STEP, same box, six rounds (tools/ab_step.py): c3
+//       0.5658 against 0.5635 ms, c5 3.7355 against 3.7219, per-rank 4096 a tie: 0.4 % SLOWER (102 + 62 registers against
+//       52 + 32; the tails it removes lie under the side queues' kernels in the step).  Not taken.
 // Where a workgroup's 83 k cycles go at 8192 x 512 x 512 (128x64 tile, two workgroups per CU, 2.3-2.4 GHz): prologue 2.5 k,
 // loop 73.7 k (ideal 65.5 k), epilogue 10.5 k -- the 16 MB of output leave all 512 workgroups at the same moment.
 

@@ -15,6 +15,7 @@ static int g_extra_lds = 0;      // development: extra dynamic LDS per workgroup
 #define G2_EXTRA_LDS(tm, tn) g_extra_lds
 #include "gemm_glds.h"
 
+int g_cdlrm_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 void cdlrm_set_error(const char* fmt, ...) {}
 CdlrmStopState* cdlrm_stop_state() {
     static thread_local CdlrmStopState st{nullptr, nullptr, 0};

@@ -1,7 +1,8 @@
 // Experiment (round 5): the LDS-DMA GEMM (gemm_glds.h: k_gemm2) on LARGER macro tiles -- per wave 128x64 / 64x128 / 128x128
 // accumulator tiles (the vendor library's pick for these shapes is a 256x256 macro tile, 128x128 per wave, one workgroup per CU,
 // profiles/r05_gemm_vs_vendor.json) -- against the production 128x64 tile, forward and dgrad layouts, M = 8192 and 65536.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cdlrm_amd/csrc -I include tools/gemm_big_tile.hip -o build_tmp/gbt
+// ... and the persistent form of the kernel (tools/gemm2p_experiment.h).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cdlrm_amd/csrc -I include -I tools tools/gemm_big_tile.hip -o build_tmp/gbt
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -9,8 +10,9 @@
 #include <algorithm>
 #include <functional>
 #include <vector>
-#include "gemm_glds.h"
+#include "gemm2p_experiment.h"
 
+int g_cdlrm_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 void cdlrm_set_error(const char* fmt, ...) {}
 CdlrmStopState* cdlrm_stop_state() {
     static thread_local CdlrmStopState st{nullptr, nullptr, 0};
@@ -32,6 +34,12 @@ template <bool A_KC, bool B_KC, int TM, int TN>
 static void launch(const GemmArgs& g) {
     dim3 grid((unsigned)cdiv(g.N, 64 * TN), (unsigned)cdiv(g.M, 64 * TM), 1);
     hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, TM, TN>), grid, dim3(256), 0, 0, g);
+}
+template <bool A_KC, bool B_KC, int TM, int TN>
+static void launch_p(const GemmArgs& g, unsigned slots) {
+    const unsigned ntx = (unsigned)cdiv(g.N, 64 * TN), nty = (unsigned)cdiv(g.M, 64 * TM);
+    const unsigned ntiles = ntx * nty;
+    hipLaunchKernelGGL((k_gemm2p<A_KC, B_KC, TM, TN>), dim3(std::min(slots, ntiles)), dim3(256), 0, 0, g, ntx, ntiles);
 }
 template <bool A_KC, bool B_KC>
 static void run(const char* name, int64_t M, int N, int64_t K) {
@@ -58,21 +66,26 @@ static void run(const char* name, int64_t M, int N, int64_t K) {
         double maxd = 0; for (size_t i = 0; i < h0.size(); ++i) maxd = std::max(maxd, (double)fabsf(h0[i] - h1[i]));
         std::vector<double> t; for (int r = 0; r < 5; ++r) t.push_back(time_us(f, M > 8192 ? 10 : 30));
         std::sort(t.begin(), t.end());
-        printf("%-28s M=%6lld N=%4d K=%4lld tile %-8s %8.1f us %6.1f TF/s  maxdiff vs 128x64 %g\n", name, (long long)M, N, (long long)K, tile,
+        printf("%-28s M=%6lld N=%4d K=%4lld tile %-14s %8.1f us %6.1f TF/s  maxdiff vs 128x64 %g\n", name, (long long)M, N, (long long)K, tile,
                t[2], fl / t[2] / 1e6, maxd);
         fflush(stdout);
     };
     one("128x64", [&]() { launch<A_KC, B_KC, 2, 1>(g1); });
     one("128x128", [&]() { launch<A_KC, B_KC, 2, 2>(g1); });
-    one("256x128", [&]() { launch<A_KC, B_KC, 4, 2>(g1); });
-    one("128x256", [&]() { launch<A_KC, B_KC, 2, 4>(g1); });
-    one("256x256", [&]() { launch<A_KC, B_KC, 4, 4>(g1); });
+    one("p128x64 G512", [&]() { launch_p<A_KC, B_KC, 2, 1>(g1, 512); });
+    one("p128x64 G768", [&]() { launch_p<A_KC, B_KC, 2, 1>(g1, 768); });
+    one("p128x64 G256", [&]() { launch_p<A_KC, B_KC, 2, 1>(g1, 256); });
+    one("p128x128 G256", [&]() { launch_p<A_KC, B_KC, 2, 2>(g1, 256); });
+    one("p128x128 G512", [&]() { launch_p<A_KC, B_KC, 2, 2>(g1, 512); });
+    one("p64x64 G1024", [&]() { launch_p<A_KC, B_KC, 1, 1>(g1, 1024); });
     hipFree(A); hipFree(B); hipFree(bias); hipFree(mask); hipFree(C0); hipFree(C1);
 }
 int main() {
-    for (int64_t M : {(int64_t)65536, (int64_t)8192}) {
+    for (int64_t M : {(int64_t)65536, (int64_t)16384, (int64_t)8192}) {
         run<true, true>("forward 512<-512", M, 512, 512);
         run<true, false>("dgrad 512<-512", M, 512, 512);
+        run<true, true>("forward 512<-480", M, 512, 480);
+        run<true, false>("dgrad 480<-512", M, 480, 512);
         run<true, true>("forward 256<-512", M, 256, 512);
     }
     return 0;
