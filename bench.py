@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--plan-only", action="store_true",
                     help="print what every rank of this command would ask the node for (host / pinned / HBM bytes, threads, "
                          "streams, hardware queues, port) and exit -- no HIP call, no process group")
+    ap.add_argument("--engine-attr", default="", help="development: TrainEngine schedule knobs for A/B lines, 'name=value,name=value' "
+                                                      "(python literals); reported as config.engine_attr")
     ap.add_argument("--no-fuse-gather", action="store_true",
                     help="gather + interaction as two launches (TrainEngine.fuse_gather = False): the schedule up to round 4's "
                          "first session, kept for A/B lines")
@@ -436,6 +438,10 @@ def main():
     lbs = math.ceil(B / world)
     if a.no_fuse_gather:
         eng.fuse_gather = False
+    for kv in filter(None, a.engine_attr.split(",")):
+        k_, v_ = kv.split("=")
+        assert hasattr(eng, k_), k_
+        setattr(eng, k_, eval(v_))
     for kv in filter(None, a.debug.split(",")):
         k_, v_ = kv.split("=")
         assert _lib.raw().cdlrm_debug_set(int(k_), int(v_)) == 0
@@ -697,7 +703,7 @@ def main():
     # shapes outside the fused kernels; up to round 4's first session also this step's) -- when the step runs the fused kernel,
     # the operator is timed here, stand-alone, after the timed region: 30 launches on the last batch's slot ids into the
     # engine's own feature block, each with its launch-attached events.
-    op_us = []
+    op_us, alone_us = [], []
     gpu_regime = refills.get("regime")
     if rank == 0:
         last = last_j
@@ -721,8 +727,19 @@ def main():
             _ops.time_next_gather(cg.ctx, e0, e1)
             _ops.embbag_fwd(cg.ctx, slots_l, None, feat_l[:, 1:, :], feat_l.stride(0), D)
         torch.cuda.synchronize()
-        del flush
         op_us = [e0.elapsed_us(e1) for e0, e1 in pairs[5:]]
+        # ... and the step's own roofline kernel ALONE (the fused gather + interaction forward): in the step it may run beside
+        # the next batch's take and this batch's slot sort (TrainEngine.gather_alone_min: a samples/s decision), here nothing
+        # runs beside it -- same slot ids, cold caches, launch-attached events
+        R_l = eng._buffers(lbs)["R"]
+        pairs = [(_ops.TimingEvent(), _ops.TimingEvent()) for _ in range(35)]
+        for e0, e1 in pairs:
+            flush[1].copy_(flush[0])
+            _ops.time_next_gather(cg.ctx, e0, e1)
+            _ops.gather_interact_fwd(cg.ctx, slots_l, feat_l[:, 0, :], eng.itself, R_l)
+        torch.cuda.synchronize()
+        alone_us = [e0.elapsed_us(e1) for e0, e1 in pairs[5:]]
+        del flush
 
     if rank == 0:
         g_us = [e0.elapsed_us(e1) for e0, e1 in ev_pairs]
@@ -799,7 +816,12 @@ def main():
                        # what torch.distributed itself reports for this run (a SCALE record can be checked for N ranks on RCCL)
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "dist_backend": dist.get_backend() if dist.is_initialized() else "none (one process, no collectives)",
-                       "final_loss": loss, "setup_s": round(setup_s, 1),
+                       "final_loss": loss, "setup_s": round(setup_s, 1), "engine_attr": a.engine_attr or None,
+                       # which take schedule the local batch gets (TrainEngine.gather_alone_min, decided by samples/s)
+                       "schedule": ("two aux regions: next batch's take at the head of the step, beside the bottom MLP and the "
+                                    "interaction forward" if eng._side_gather(lbs) else
+                                    "chained take: one aux region, take + slot sort behind the embedding update; the interaction "
+                                    "forward runs alone"),
                        # GPU kept busy (scratch GEMMs, no training state) between the W warm-up steps and the timed region
                        "gpu_prewarm_ms": a.prewarm_ms,
                        # the same step right after the warm-up, BEFORE the pre-warm (rank 0's clock over a bounded pass of
@@ -847,6 +869,12 @@ def main():
                                   "skewed batch are served by L2 / Infinity Cache, so the HBM counters see fewer bytes: "
                                   "traffic, achieved_counter and frac_counter are the same launch time on those",
                          "fused_gather": fused,
+                         # the same kernel with nothing beside it (after the timed region, cold caches, 30 launches): in the step
+                         # it shares the GPU with whatever the schedule places beside it (config.schedule)
+                         "alone": ({"avg_launch_us": float(np.mean(alone_us)),
+                                    "launch_us": {"p10": pct(alone_us, 10), "p50": pct(alone_us, 50), "p90": pct(alone_us, 90)},
+                                    "achieved": alg_bytes / float(np.mean(alone_us)) / 1e3,
+                                    "frac": alg_bytes / float(np.mean(alone_us)) / 1e3 / HBM_PEAK_GBS} if alone_us else None),
                          "frac_survey_basis": (survey_bytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if achieved else None,
                          "gather_operator": gather_operator,
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1353,6 +1353,7 @@ extern "C" int cdlrm_gather_interact_supported(cdlrm_ctx* ctx) {
 
 extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
                                          int64_t B, int32_t itself, float* R, int64_t ld_r, void* stream) {
+    CdlrmStopScope stop_scope;          // (first: every exit below flushes an attached completion event)
     CDLRM_CLEAR_STALE();
     CDLRM_REQUIRE(ctx && slots && x && R, "null argument");
     CDLRM_REQUIRE(ctx->weight, "cdlrm_ctx_bind_cache first");
@@ -1365,6 +1366,11 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     if (B == 0) return 0;       // (an armed event pair stays armed for the next launch that can carry it)
     hipEvent_t ev0 = (hipEvent_t)ctx->ev_start, ev1 = (hipEvent_t)ctx->ev_stop;     // cdlrm_ctx_time_next_gather
     ctx->ev_start = ctx->ev_stop = nullptr;
+    // a completion event attached to this launch (cdlrm_event_attach_next: the trainer's side queue starts the batch's slot sort
+    // and the look-ahead resolve behind the interaction forward): it IS the launch's stop event -- unless the launch is being
+    // timed (the roofline samples of bench.py carry their own pair), then it is recorded behind the launch
+    hipEvent_t se = cdlrm_take_stop_event((hipStream_t)stream);
+    if (!ev1 && se) { ev1 = se; se = nullptr; }
     IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4};
     const size_t lds_s = (size_t)4 * (32 * 36 + D + 532) * sizeof(float);
     int64_t gp = cdiv(B, 4);
@@ -1394,6 +1400,7 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     else if (D == 128) GIFWD(32, s128);
     else GIFWD(64, s256);
 #undef GIFWD
+    if (se) CDLRM_HIP_CHECK(hipEventRecord(se, (hipStream_t)stream));
     CDLRM_LAUNCH_CHECK();
     return 0;
 }

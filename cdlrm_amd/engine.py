@@ -654,11 +654,17 @@ class TrainEngine:
         # measured (c3 shapes): the split loses ~3 % at B <= 2048 (two more launches on a latency-bound step), gains
         # 8 % at 4096 (0.580 -> 0.534 ms) and at 8192 (0.853 -> 0.782 ms)
         self.split_wgrad_min = 2049
-        # local batches below this run the gather on the side stream beside the bottom MLP's forward (measured: 0.216 ->
-        # 0.211 ms at 1024, 0.307 -> 0.301 at 2048, 0.493 -> 0.461 at 4096); from it on the gather stays alone on the
-        # main stream: at 8192 the overlap buys 2 % (0.783 -> 0.766 ms) and costs the roofline kernel 6 points of its
-        # own rate (35.4 -> 38.3 us, 78 % -> 72 % of peak)
-        self.gather_alone_min = 8192
+        # Local batches below this take the TWO-AUX-REGION schedule (the next batch's take on the prefetch stream at the head of
+        # the step, into the other aux region; its slot sort at the head of the next step; stand-alone gather, where there is one,
+        # on the side stream beside the bottom MLP's forward), from it on the CHAINED take (one aux region; take and sort of the
+        # next batch behind this batch's embedding update, the gather / fused interaction forward alone on the training queue).
+        # Decided by samples/s on the fused build (round 5, tools/ab_step.py, one box, six rounds each, three sessions): at 8192
+        # the two-region schedule is 0.8-1.3 % faster (0.5588 / 0.5591 / 0.5593 against 0.5662 / 0.5636 / 0.5651 ms; the driver's
+        # 20 steps 0.5737 against 0.5797, a whole window 0.5865 against 0.5906) although the fused kernel -- the HBM-roofline
+        # kernel -- then runs beside the next batch's take and this batch's sort: 28.3 us in the step against 23.9 alone (0.57
+        # against 0.68 of 8 TB/s; bench.py reports both, roofline.frac and roofline.alone).  At 65536 the chained take stays
+        # (3.718 against 3.741 ms), 4096 is a tie, 2048 / 1024 keep two regions (0.2422 / 0.2433, 0.1798 / 0.1845 the other way).
+        self.gather_alone_min = 16384
         self._gslot = None
         self._res = self._next_res = None
         self._tapes = {}
@@ -688,12 +694,22 @@ class TrainEngine:
         # per step), the backward reads the rows again from the cache, in front of the batch's embedding update.  Bit-identical
         # to the two operators (False: gather + interaction as two launches; multi-hot bags and "cat" always take those).
         self.fuse_gather = True
+        # fused gather, a knob measured and left OFF (round 5): the sort of the batch's slot ids (the embedding backward's prepare;
+        # side stream) started BEHIND the interaction forward -- an event attached to that launch -- instead of at the head of
+        # the step (two aux regions) or at the tail of the previous one (chained take), so that it runs under the top MLP's
+        # forward.  tools/ab_step.py, same box, six rounds: c3 0.5646 against 0.5632 ms (chained take), 0.5660 against 0.5625 (two
+        # aux regions), per-rank 4096 0.3337 / 0.3306, 1024 0.1787 / 0.1776 -- slower everywhere: the first half of the step is
+        # the training queue's GEMM chain alone, and the sort takes its CUs.  (A third placement -- the next batch's sort behind
+        # this batch's embedding update in the step's tail, two aux regions -- measured 0.5669 against 0.5643, 0.1844 / 0.1810 at
+        # 1024, and was removed.)
+        self.sort_after_fwd = False
         # WindowResolver hands the NEXT step a look-ahead chunk to resolve (`_pending_resolve`, taken when `mark_next` is set): the
         # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
         # stream --, so the resolve (random 128-B tag reads) runs beside the top MLP's GEMMs, which leave HBM idle, instead of
         # behind the weight gradients at the end of the step, where it lands on the next step's gather (the roofline kernel)
         self.mark_next = False
         self._mark_this = False
+        self._fwd_marked = False
         self._pending_resolve = None
 
     # all Linear weights in one flat buffer (one all-reduce, main_no_ddp.py:234-247), biases behind them
@@ -742,7 +758,8 @@ class TrainEngine:
         behind its interaction forward (an event recorded on the training queue: one marker packet per chunk, i.e. per 16 steps)."""
         pst, ev = self.pref, self._events
         if placed:
-            rec(ev["fwd_mark"].record, main)
+            if not self._fwd_marked:            # (else: fwd_mark completes with the interaction forward's launch)
+                rec(ev["fwd_mark"].record, main)
             rec(pst.wait_event, ev["fwd_mark"])
         elif pr["first"]:
             pst.wait_stream(main)               # the commit (tags, victims) is on the main stream
@@ -1138,17 +1155,28 @@ class TrainEngine:
         emb_work = self._emb_work(n)
         if not side_gather:
             rec(side.wait_event, probed)
-        if not prepared:        # (a chained take sorted this batch's slots right behind itself, in the previous step)
+        attach = self.attach_events and S.is_hip(self.dev)
+        # the sort behind the interaction forward (sort_after_fwd): issued below, behind that launch
+        defer_sort = bool(self.sort_after_fwd and fused and attach and not prepared)
+        if not prepared and not defer_sort:     # (prepared: a chained take sorted this batch's slots right behind itself)
             ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         if self.defer_top and not self.cat and not top_waited:
             # the previous step's top-MLP update (weight gradients read R / top_y / top_dy, then all-reduce and SGD on
             # the side stream) has to have landed before this step overwrites those buffers and reads the weights
             # (top_waited: the event this step's gather waited for was recorded behind that update)
             rec(main.wait_event, ev["top_updated"])
+        self._fwd_marked = False
         if fused:
             if self._gslot is not None:         # bench.py: the kernel that does the gather, timed by its own launch
                 ops.time_next_gather(ctx, self._gslot[0], self._gslot[1])
+            if attach and (defer_sort or self._mark_this):
+                # what the side queues start behind the interaction forward waits for an event that completes WITH this launch
+                ops.event_attach_next(ev["fwd_mark"], main)
+                self._fwd_marked = True
             ops.gather_interact_fwd(ctx, slots, feat[:, 0, :], self.itself, R)
+            if defer_sort:
+                rec(side.wait_event, ev["fwd_mark"])
+                ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         elif not self.cat:
             ops.interact_fwd(feat, self.itself, R)
         if self._mark_this:
@@ -1269,9 +1297,11 @@ class TrainEngine:
                 ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=0, stream=side)
             else:
                 res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
-            if chain:
+            chain_sort = chain and not (self.sort_after_fwd and fused and attach)
+            if chain_sort:
                 # ... and the sort of the next batch's slot ids for ITS backward: here it ends well before the step does; issued
-                # by the next step it ran late enough to share HBM with that step's gather (the roofline kernel)
+                # at the head of the next step it shared HBM with that step's gather (the roofline kernel).  (sort_after_fwd: the
+                # next step issues it behind its interaction forward instead)
                 ops.embbag_bwd_prepare(ctx, res[0], emb_work, stream=side)
             # (weight gradients that start later are waited for by the next step's training queue, in front of its
             #  interaction forward: they may run beside the next gather)
@@ -1281,7 +1311,7 @@ class TrainEngine:
             evp = ev["probed"][which]
             rec(evp.record, side)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
-                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain)
+                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain_sort)
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
@@ -1415,7 +1445,7 @@ class TrainEngine:
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
                self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.top_wgrad_after,
-               self.fuse_gather,
+               self.fuse_gather, self.sort_after_fwd,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)

@@ -350,7 +350,8 @@ int cdlrm_interact_bwd(const float* feat, const float* dR, int64_t ld_r, int64_t
  *   R      as cdlrm_interact_fwd's, F = T + 1; whole float4 rows (ld_r % 4 == 0, 16-byte aligned)
  * Bit-identical to cdlrm_embbag_fwd + cdlrm_interact_fwd.  Shapes: cdlrm_gather_interact_supported() (D in 32 / 64 / 128 /
  * 256, 16 < T + 1 <= 32); anything else is refused -- the caller issues the two operators.  A pair of events armed with
- * cdlrm_ctx_time_next_gather times this launch. */
+ * cdlrm_ctx_time_next_gather times this launch; a completion event attached with cdlrm_event_attach_next completes with it
+ * (as the launch's stop event; recorded behind the launch when the launch is being timed). */
 int cdlrm_gather_interact_supported(cdlrm_ctx* ctx);
 int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x, int64_t B,
                               int32_t itself, float* R, int64_t ld_r, void* stream);
@@ -498,8 +499,8 @@ int64_t cdlrm_tape_probe_log_take(int64_t* out, int64_t cap);
 /* hipEventRecord / hipStreamWaitEvent as tape-able entry points (raw hipEvent_t / hipStream_t handles) */
 int cdlrm_event_record(void* event, void* stream);
 int cdlrm_stream_wait_event(void* stream, void* event);
-/* `event` completes with the next kernel the calling thread launches on `stream` through cdlrm_linear_bwd or
- * cdlrm_interact_bwd -- attached to that launch as its stop event instead of recorded behind it: a record is a marker packet
+/* `event` completes with the next kernel the calling thread launches on `stream` through cdlrm_linear_bwd,
+ * cdlrm_interact_bwd, cdlrm_gather_interact_bwd or cdlrm_gather_interact_fwd -- attached to that launch as its stop event instead of recorded behind it: a record is a marker packet
  * and a 6-8 us bubble on the training queue, an attached event is free.  If the call cannot attach it (several launches, a
  * kernel path without the plumbing) it records the event behind its launches: same guarantees either way. */
 int cdlrm_event_attach_next(void* event, void* stream);

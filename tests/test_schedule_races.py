@@ -3,8 +3,9 @@ the engine can run -- three-lane / two-lane / one-lane / Python-replayed / untap
 behind them, the deferred-update wait on the side stream or on the training queue -- must end on the same BITS: final loss,
 every dense parameter, the cache rows' checksum, the tags, the running statistics.  Same kernels, same inputs, same stream
 dependencies; only who issues which call, and when, differs -- so any difference is a missing dependency.  Run at the per-rank
-batch of an 8-GPU run (short-batch schedule: gather on the side stream, two-phase aux regions) and at the c3 batch (long-batch
-schedule: chained take, window-resident probe), across a window boundary, on c3's shapes with the tables capped at 2 M rows."""
+batch of an 8-GPU run and at the c3 batch, each under BOTH take schedules (two aux regions: the next batch's take at the head of
+the step; chained take: one aux region, take and sort behind the embedding update -- `gather_alone_min` picks by batch size in
+production), across a window boundary, on c3's shapes with the tables capped at 2 M rows."""
 import os
 import subprocess
 import sys

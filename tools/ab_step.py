@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--max-ind-range", type=int, default=-1)
+    ap.add_argument("--set", default="", help="other TrainEngine attributes held fixed for the whole run: 'name=value,name=value'")
     a = ap.parse_args()
     vals = [eval(v) for v in a.values.split(";")]
     dev = torch.device("cuda", 0)
@@ -36,6 +37,10 @@ def main():
     L = a.steps * 2 + 8
     wl = bench.build_workload(a.config, lookahead=L, batch=a.batch, dev=dev, max_ind_range=a.max_ind_range)
     eng, pipe, syn, B = wl["eng"], wl["pipe"], wl["syn"], wl["B"]
+    for kv in filter(None, a.set.split(",")):
+        k_, v_ = kv.split("=")
+        assert hasattr(eng, k_), k_
+        setattr(eng, k_, eval(v_))
     torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     win = syn.window(0, L)
     pipe.plan_window(win)

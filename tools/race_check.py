@@ -24,6 +24,10 @@ VARIANTS = {
     "recorded events": {"attach_events": False},
     "wait on the training queue": {"fold_top_wait": False},
     "unchained take (round-1 schedule)": {"chain_take": False},
+    "chained take at every batch (one aux region)": {"gather_alone_min": 1},
+    "two aux regions at every batch": {"gather_alone_min": 1 << 30},
+    "slot sort behind the interaction forward": {"sort_after_fwd": True},
+    "slot sort behind the interaction forward, chained take": {"sort_after_fwd": True, "gather_alone_min": 1},
     "top weight gradients behind the interaction backward": {"top_wgrad_after": "interacted"},
     "top weight gradients behind the bottom input gradients": {"top_wgrad_after": "bot_dz"},
     "top weight gradients behind the bottom weight gradients": {"top_wgrad_after": "bot_wg"},
