@@ -689,6 +689,10 @@ class TrainEngine:
         # input-gradient chain) or "bot_wg" (behind the bottom MLP's weight gradients: they then run into the next step's
         # bottom MLP, gather and interaction forward, which leave the MFMA idle)
         self.top_wgrad_after = "top_dz"
+        # (Round 5, measured and removed: the weight gradients of the top MLP's LAST TWO layers started behind the first GEMM of
+        #  the input-gradient chain -- their dZ are final behind the head kernel, that GEMM is the last reader of their weights --
+        #  to use the MFMA capacity the chain leaves: c3 0.5679 against 0.5646 ms, c5 3.788 against 3.719, per-rank 4096 a tie.
+        #  Like every placement beside that chain since round 1, it costs the chain more than it takes off the second half.)
         # Criteo layout + dot interaction: the gather IS the interaction's operand load (cdlrm_gather_interact_fwd / _bwd) -- the
         # [B, T, D] block between cached EmbeddingBag and interact_features is neither written nor read back (c3: 109 MB + 113 MB
         # per step), the backward reads the rows again from the cache, in front of the batch's embedding update.  Bit-identical
@@ -1218,6 +1222,13 @@ class TrainEngine:
                              threshold=self.loss_threshold, Zc=buf["Zc"], sigmoid_bwd=(last_act == 2))
             rec(self.stat_acc.add_, buf["loss"][1:3])
             dY = buf["top_dy"][-1]
+        # where the top MLP's weight gradients start (one rank: a knob; several ranks: behind the input-gradient chain, their
+        # exchange follows them)
+        late = "top_dz"
+        if split is not None and self.defer_top and not self.multi and not self.cat:
+            late = self.top_wgrad_after
+            if late == "bot_dz" and len(self.bot) < 2:
+                late = "interacted"
         for i in reversed(range(n_top - 1 if fused_head else n_top)):
             l, act = self.top[i]
             if i == len(self.top) - 1 and act == 2:
@@ -1225,7 +1236,7 @@ class TrainEngine:
             elif i < len(self.top) - 1:
                 act = 0                                      # applied by the dgrad epilogue of layer i+1
             dX = dR if i == 0 else buf["top_dy"][i - 1]
-            if i == 0 and attach and split is not None:
+            if i == 0 and attach and split is not None and late == "top_dz":
                 # `top_dz` (every top-layer dZ is final: the weight gradients may start) completes WITH the chain's last GEMM
                 # -- attached to its launch instead of recorded behind it: a record is a marker packet of its own and left
                 # a 6-8 us bubble on the training queue
@@ -1252,16 +1263,10 @@ class TrainEngine:
         #  0.675 ms: the saved bubble is worth less than the 57 us the weight gradients start later.  The interaction backward
         #  split by rows -- the dense feature's row as its own launch, the rest on the side queue -- measured slower too, 0.718
         #  vs 0.663 ms.  Both schedules were removed in round 3.)
-        late = "top_dz"
-        if split is not None and self.defer_top and not self.multi and not self.cat:
-            late = self.top_wgrad_after
-            if late == "bot_dz" and len(self.bot) < 2:
-                late = "interacted"
-        if split is not None:
+        if split is not None and late == "top_dz":
             if not (attach and n_top - (1 if fused_head else 0) > 0):
                 rec(ev["top_dz"].record, main)
-            if late == "top_dz":
-                top_wgrad(ev["top_dz"])
+            top_wgrad(ev["top_dz"])
         if self.cat:
             # dR is the gradient of the feature block itself; only the bottom MLP's output needs its activation's
             # derivative (the dot path applies it in the interaction backward's epilogue)

@@ -184,14 +184,18 @@ def test_full_size_invariants_and_bitwise_repeat(terabyte_host, config, L, steps
     than the big tables' caches have slots, so full sets, contested slots, evictions and window victims all occur:
     every resident tag in its set and unique, the gather bit-exact against the rows the probe resolved, finite losses
     near ln 2, and a second run from the same state bitwise identical (tags, every parameter, the loss trajectory) --
-    no atomics-order or cross-stream race dependence anywhere in the step.  The first run is the default one (the gather
-    fused into the interaction kernels), the second issues gather + interaction as two launches: the fused kernels are held
-    to the two operators bit for bit at full size, through every step.  (Write-back is off in both runs so that the
-    second run sees the host tables of the first.)"""
+    no atomics-order or cross-stream race dependence anywhere in the step.  Three runs: the default schedule (the gather
+    fused into the interaction kernels) TWICE -- the bitwise repeat of one schedule --, and once with gather + interaction as
+    two launches: the fused kernels are held to the two operators bit for bit at full size, through every step.  (Write-back
+    is off in all runs so that each sees the host tables of the first.)"""
     a = _run_full_size(config, terabyte_host, L, 2, steps)
+    a2 = _run_full_size(config, terabyte_host, L, 2, steps)
+    assert torch.equal(a["losses"], a2["losses"]) and torch.equal(a["tags"], a2["tags"]) and torch.equal(a["params"], a2["params"]) \
+        and a["wsum"] == a2["wsum"], "the same schedule run twice from the same state differs"
+    del a2
     b = _run_full_size(config, terabyte_host, L, 2, steps, fuse_gather=False)
     assert torch.isfinite(a["losses"]).all() and 0.3 < float(a["losses"][-1]) < 2.0
-    assert torch.equal(a["losses"], b["losses"]), "loss trajectory differs between two identical runs"
+    assert torch.equal(a["losses"], b["losses"]), "loss trajectory differs between the fused and the two-launch schedule"
     assert torch.equal(a["tags"], b["tags"])
     assert torch.equal(a["params"], b["params"])
     assert a["wsum"] == b["wsum"] and a["feats"] is None and b["feats"] is not None

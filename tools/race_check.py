@@ -68,7 +68,9 @@ def run(a, knobs, host):
     rows = sum(cg.emb_l[k].weight.data[: cg.num_ways * cg.cache_sizes[k]].sum(dtype=torch.float64).item()
                for k in range(len(cg.cache_sizes)))
     out = (float(eng._buffers(B)["loss"][0]), eng.param_flat.clone(), rows, cg.tags.clone(), eng.stat_acc.clone())
-    del wl, eng, pipe, syn, cg
+    del wl, eng, pipe, syn, cg, rs
+    import gc
+    gc.collect()            # (tapes, resolver rings and plans reference each other: cycles would keep ~10 GB per variant alive)
     torch.cuda.empty_cache()
     return out
 
