@@ -260,7 +260,11 @@ def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, s
             limit = None
     out["host_memory_limit_bytes"] = limit
     refuse = []
-    if limit and host_tables + world * staging > 0.9 * limit:
+    if limit and host_tables > limit // 2 and os.environ.get("CDLRM_ALLOW_HUGE_HOST_TABLES") != "1":
+        # (build_host_tables' own guard: c4 UNCAPPED, 192 GB pinned, has taken a one-GPU box of this pool down twice)
+        refuse.append("host tables of %.0f GB are more than half of the job's memory limit (%.0f GB): --max-ind-range caps them"
+                      % (host_tables / 1e9, limit / 1e9))
+    elif limit and host_tables + world * staging > 0.9 * limit:
         refuse.append("host tables (%.0f GB) + %d x pinned staging (%.1f GB) exceed 90 %% of the job's memory limit (%.0f GB)"
                       % (host_tables / 1e9, world, staging / 1e9, limit / 1e9))
     if hbm["sum_without_growth"] > 280e9:

@@ -51,8 +51,10 @@ typedef struct {
 } cdlrm_geometry;
 
 int cdlrm_abi_version(void);
-/* Development switch (all zero in production): key 0 .. 7 selects a kernel path the current one replaced, so that the two can
- * be timed against each other on one box in one process (tools/ab_step.py --attr debug:<key>). */
+/* DEVELOPMENT EXPORT, not part of the drop-in surface (no reference counterpart; a maintainer binds nothing to it): key 0 .. 7
+ * selects a kernel variant the current one replaced, or a grid size, so that two builds' worth of behaviour can be timed against
+ * each other on one box in one process (tools/ab_step.py --attr debug:<key>, bench.py --debug).  All zero unless a tool sets
+ * them; results never depend on a key (variants are bit-identical, grids only change placement). */
 int cdlrm_debug_set(int32_t key, int32_t value);
 const char* cdlrm_last_error(void);
 
