@@ -707,6 +707,8 @@ class TrainEngine:
         # this batch's embedding update in the step's tail, two aux regions -- measured 0.5669 against 0.5643, 0.1844 / 0.1810 at
         # 1024, and was removed.)
         self.sort_after_fwd = False
+        # (Also measured and removed: the sort in FRONT of the side stream's wait for the previous top-MLP update, two aux
+        #  regions: c3 0.5625 against 0.5608, 2048 0.2392 / 0.2378, 1024 0.1801 / 0.1787, only 4096 gained, 0.3304 / 0.3328.)
         # WindowResolver hands the NEXT step a look-ahead chunk to resolve (`_pending_resolve`, taken when `mark_next` is set): the
         # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
         # stream --, so the resolve (random 128-B tag reads) runs beside the top MLP's GEMMs, which leave HBM idle, instead of
