@@ -90,6 +90,9 @@ def parse():
                          "streams, hardware queues, port) and exit -- no HIP call, no process group")
     ap.add_argument("--engine-attr", default="", help="development: TrainEngine schedule knobs for A/B lines, 'name=value,name=value' "
                                                       "(python literals); reported as config.engine_attr")
+    ap.add_argument("--no-standalone-legs", action="store_true",
+                    help="skip the stand-alone timings behind the timed region (roofline.gather_operator, roofline.alone): the "
+                         "rocprofv3 passes of tools/profile_round.sh, whose kernel statistics should hold the step's launches only")
     ap.add_argument("--no-fuse-gather", action="store_true",
                     help="gather + interaction as two launches (TrainEngine.fuse_gather = False): the schedule up to round 4's "
                          "first session, kept for A/B lines")
@@ -720,7 +723,7 @@ def main():
         slots_l, _, mc_l = _ops.embbag_probe(cg.ctx, idx_l, aux_phase=eng._phase)
         if gpu_regime is not None:      # lookups of the last batch served from the cache (the others read aux rows)
             gpu_regime["hit_rate_last_batch"] = 1.0 - float(mc_l.sum().item()) / float(idx_l.numel())
-    if rank == 0 and fused and a.gather_sample > 0:
+    if rank == 0 and fused and a.gather_sample > 0 and not a.no_standalone_legs:
         feat_l = eng._buffers(lbs)["feat"]
         pairs = [(_ops.TimingEvent(), _ops.TimingEvent()) for _ in range(35)]
         # between two launches 1 GB of scratch is copied: the rows of the launch before (113 MB at c3) would otherwise wait in
@@ -764,7 +767,7 @@ def main():
         traffic = traffic_src = None
         def committed_pmc(cfg_id, alpha):
             t = "%s_a%s.json" % (cfg_id, ("%g" % alpha).replace(".", "p"))
-            for name in ("r04_gather_pmc_" + t, "r03_gather_pmc_" + t, "r02_gather_pmc_" + t):
+            for name in ("r05_gather_pmc_" + t, "r04_gather_pmc_" + t, "r03_gather_pmc_" + t, "r02_gather_pmc_" + t):
                 pp = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pp):
                     doc = json.load(open(pp))
@@ -800,7 +803,9 @@ def main():
         # row a-6 as a whole (per step: the gather, the take of the batch's slot ids / miss rows, and 1/16 of the look-ahead
         # chunk's resolve): from the committed kernel trace of this configuration (tools/a6_summary.py)
         a6 = None
-        a6_path = os.path.join(ROOT, "profiles", "r04_a6_whole_%s.json" % a.config)
+        a6_path = os.path.join(ROOT, "profiles", "r05_a6_whole_%s.json" % a.config)
+        if not os.path.exists(a6_path):
+            a6_path = os.path.join(ROOT, "profiles", "r04_a6_whole_%s.json" % a.config)
         if os.path.exists(a6_path) and a.batch <= 0 and a.max_ind_range <= 0 and a.alpha == 1.05:
             a6 = json.load(open(a6_path))
             a6["source"] = "profiles/" + os.path.basename(a6_path)

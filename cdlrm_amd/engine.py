@@ -492,10 +492,12 @@ class WindowResolver:
         self._started = True
 
     def _long_batch(self) -> bool:
-        """Long local batches on a HIP device with an engine that can place a resolve inside its step: the gather then runs alone
-        on the training queue (the roofline kernel) and a chunk's resolve is worth placing."""
+        """Long local batches on a HIP device with an engine that can place a resolve inside its step (TrainEngine.
+        place_resolve_min): a chunk's resolve issued at once lands on whatever the training queue runs then -- one interaction
+        forward in sixteen took 60 us instead of 23 -- so the step places it behind its interaction forward."""
         eng = self.eng
-        return (hasattr(eng, "_issue_resolve") and S.is_hip(eng.dev) and not eng._side_gather(self.width))
+        return (hasattr(eng, "_issue_resolve") and S.is_hip(eng.dev)
+                and (self.width >= getattr(eng, "place_resolve_min", 1 << 62) or not eng._side_gather(self.width)))
 
     def _prepare(self, c: int):
         ctx = self.ctx
@@ -713,6 +715,8 @@ class TrainEngine:
         # step issues it on the prefetch stream right behind its interaction forward -- in front of its own weight gradients on that
         # stream --, so the resolve (random 128-B tag reads) runs beside the top MLP's GEMMs, which leave HBM idle, instead of
         # behind the weight gradients at the end of the step, where it lands on the next step's gather (the roofline kernel)
+        # local batches from this size on PLACE the resolve (either take schedule); below it a chunk is small and is issued at once
+        self.place_resolve_min = 8192
         self.mark_next = False
         self._mark_this = False
         self._fwd_marked = False

@@ -406,7 +406,10 @@ def _c5_worker(rank, world, port, host_shared, ret):
         eng = engine.TrainEngine(cg, dl, eg, lr=C5["lr"], lr_embeds=C5["lr_emb"], world_size=world, rank=rank,
                                  table_agg_freq=C5["agg"], table_agg_op="mean", defer_top_update=True)
         eng.agg_chunk_rows = 4096           # the touched-row merge in several chunks on the exchange stream
-        assert not eng._side_gather(lbs), "lbs = 8192: the long-batch schedule (gather alone on the training queue)"
+        # the chained-take schedule (c5 on 1 - 4 ranks: local batches >= 16384; since round 5 a local batch of 8192 takes the
+        # two-region schedule by default, which the other multi-rank cases run): forced here at the size this box can check
+        eng.gather_alone_min = lbs
+        assert not eng._side_gather(lbs), "the long-batch schedule (interaction forward alone on the training queue, chained take)"
         pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
         losses, j = [], 0

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Every committed line of a round from ONE box and ONE build (run through gpurun from the repo root):
-#   bash tools/final_profiles.sh r04        -> gpurun_out/final/<tag>_*  (copy what is to be judged into profiles/)
+#   bash tools/final_profiles.sh r05        -> gpurun_out/final/<tag>_*  (copy what is to be judged into profiles/)
 # bench lines (driver's run, default run, per-rank batch, c2, c4 capped, uniform indices), the CLI at c3, then the rocprofv3 passes
 # of tools/profile_round.sh (kernel stats + trace, FETCH_SIZE / WRITE_SIZE of the gather, MFMA busy) with their summaries.
 # The c5 whole-window line (8000 steps, ~2 min) runs with C5=1 only.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -16,8 +16,9 @@ run() { name=$1; shift; echo "== $name: bench.py $*"; python3 bench.py "$@" > $O
 # of a round's profiles go in two calls, on two boxes -- each half is self-consistent); default: both
 if [ "${PART:-all}" != prof ]; then
 run steps20_n1 --steps 20 --warmup 5
-run steps20_two_launches_n1 --steps 20 --warmup 5 --no-fuse-gather --no-cpu-baseline
-run default_n1
+run steps20_two_launches_n1 --steps 20 --warmup 5 --no-fuse-gather --no-cpu-baseline --whole-window off
+run steps20_chained_n1 --steps 20 --warmup 5 --no-cpu-baseline --whole-window on --engine-attr gather_alone_min=8192
+run default_n1 --no-cpu-baseline
 run c3_batch1024_n1 --batch 1024 --steps 1000 --warmup 100 --no-cpu-baseline
 run c2_n1 --config c2 --steps 600 --warmup 50 --no-cpu-baseline
 run c4_capped_n1 --config c4 --max-ind-range 2000000 --steps 300 --warmup 50 --no-cpu-baseline
@@ -52,4 +53,6 @@ fi
 echo "== rocprofv3 kernel trace (per-rank batch 1024)"
 PASSES=stats bash tools/profile_round.sh b1024 --batch 1024
 python3 tools/trace_timeline.py $(ls -t $ROOT/gpurun_out/prof_b1024/stats/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_c3_batch1024_step_timeline.txt
+PASSES=stats bash tools/profile_round.sh b2048 --batch 2048
+python3 tools/trace_timeline.py $(ls -t $ROOT/gpurun_out/prof_b2048/stats/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_c3_batch2048_step_timeline.txt
 ls -la $OUT

@@ -7,7 +7,9 @@
 #   fetch   : --kernel-trace --pmc FETCH_SIZE                          -> HBM read bytes of the gather kernel
 #   write   : --kernel-trace --pmc WRITE_SIZE                          -> HBM write bytes
 #   mfma    : --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
-# (--prewarm-ms 0: the clock pre-warm's scratch GEMMs would otherwise sit in the kernel statistics beside the step's own)
+# (--prewarm-ms 0: the clock pre-warm's scratch GEMMs would otherwise sit in the kernel statistics beside the step's own;
+#  --whole-window off / --no-standalone-legs: the 3000-step leg and the stand-alone operator timings behind the timed region
+#  are not what these passes profile: the kernel statistics hold the step's launches only)
 # Output under gpurun_out/prof_<tag>/{stats,fetch,write,mfma}; summaries are made afterwards by tools/pmc_summary.py,
 # tools/mfma_summary.py and tools/gather_launches.py and committed under profiles/.
 set -e
@@ -25,6 +27,6 @@ for p in $PASSES; do
     mfma)  ARGS="--kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ;;
   esac
   echo "== pass $p"
-  rocprofv3 $ARGS --output-format csv -d $OUT/$p -- python3 $ROOT/bench.py --no-cpu-baseline --prewarm-ms 0 --steps ${STEPS:-50} --warmup ${WARMUP:-10} "$@" > $OUT/$p.log 2>&1
+  rocprofv3 $ARGS --output-format csv -d $OUT/$p -- python3 $ROOT/bench.py --no-cpu-baseline --whole-window off --no-standalone-legs --prewarm-ms 0 --steps ${STEPS:-50} --warmup ${WARMUP:-10} "$@" > $OUT/$p.log 2>&1
   tail -c 400 $OUT/$p.log | tr '\n' ' ' | cut -c1-300; echo
 done
