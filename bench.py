@@ -187,7 +187,7 @@ def config_tables(cfg, max_ind_range=-1):
 
 
 def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, steps=20, warmup=5, prewarm=True, cpus=None,
-                   mem_limit=None):
+                   mem_limit=None, shm_free=None):
     """What ONE rank of `bench.py --gpus world` asks the node for -- computed without a HIP call (`--plan-only` prints it
     for every rank; build_workload() takes its thread counts from here, so the plan and the run cannot disagree).
     cpus: the CPUs the whole job may use (default: the cgroup quota / affinity mask, hostmem.cpu_share())."""
@@ -263,6 +263,26 @@ def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, s
             limit = None
     out["host_memory_limit_bytes"] = limit
     refuse = []
+    if world > 1:
+        from cdlrm_amd.hostmem import shared_table_dir, shared_table_dir_free
+        out["shared_table_dir"], out["shared_table_dir_free_bytes"] = shared_table_dir(), shared_table_dir_free()
+        if shm_free is None:
+            shm_free = out["shared_table_dir_free_bytes"]
+        forced = os.environ.get("CDLRM_HOST_TABLES", "auto")
+        fits_shm = shm_free is None or shm_free >= host_tables + (1 << 30)
+        mode = forced if forced in ("shared", "replicas") else ("shared" if fits_shm else "replicas")
+        out["host_tables_mode"] = mode
+        if mode == "shared" and not fits_shm:
+            refuse.append("the shared host tables (%.0f GB) do not fit %s (%.0f GB free): CDLRM_SHM_DIR=<larger tmpfs>, "
+                          "CDLRM_HOST_TABLES=replicas, or --max-ind-range" % (host_tables / 1e9, out["shared_table_dir"], shm_free / 1e9))
+        if mode == "replicas":
+            out["host_tables_mapping"] = ("a private pinned copy per rank, filled from the same seed; every rank applies the eviction "
+                                          "write-backs to its own (identical on all ranks): %d x %.0f GB" % (world, host_tables / 1e9))
+            notes.append("%s holds %.0f GB, the tables need %.0f: every rank pins its OWN copy (%d x %.0f GB of host memory)"
+                         % (out["shared_table_dir"], (shm_free or 0) / 1e9, host_tables / 1e9, world, host_tables / 1e9))
+            if limit and world * (host_tables + staging) > 0.9 * limit:
+                refuse.append("%d private copies of the host tables (%.0f GB each) exceed 90 %% of the job's memory limit (%.0f GB)"
+                              % (world, host_tables / 1e9, limit / 1e9))
     if limit and host_tables > limit // 2 and os.environ.get("CDLRM_ALLOW_HUGE_HOST_TABLES") != "1":
         # (build_host_tables' own guard: c4 UNCAPPED, 192 GB pinned, has taken a one-GPU box of this pool down twice)
         refuse.append("host tables of %.0f GB are more than half of the job's memory limit (%.0f GB): --max-ind-range caps them"
@@ -278,20 +298,20 @@ def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, s
     return out
 
 
-# DESIGN.md section 6, "projection": one-GPU per-rank steps MEASURED at the per-rank batch + PRICED exchanges (nothing here ran on
-# xGMI).  Printed beside the measured value of an N-rank run (config.projection) so that a SCALE record reads against it.
+# DESIGN.md section 6, "projection" (round 5 numbers): one-GPU per-rank steps MEASURED at the per-rank batch + PRICED exchanges
+# (nothing here ran on xGMI).  Printed beside the measured value of an N-rank run (config.projection) so that a SCALE record reads against it.
 PROJECTION = {
     "assumptions": "per-step bottom-MLP exchange on the critical path 15 / 20 / 25 us at 2 / 4 / 8 ranks; row merge in deadline "
                    "order: its first class (2.3 % of 0.95 GB per 100 steps at c3, 4.5 GB at c5) at 70 / 150 / 170 GB/s in front of "
                    "the next step, the rest in the background; one-GPU step = the N=1 line of the same build",
-    "c3": {1: dict(per_rank_step_ms=0.5952, projected_step_ms=0.5952, projected_scaling=1.0),
-           2: dict(per_rank_step_ms=0.3340, projected_step_ms=0.352, projected_scaling=1.69),
-           4: dict(per_rank_step_ms=0.2389, projected_step_ms=0.260, projected_scaling=2.29),
-           8: dict(per_rank_step_ms=0.1834, projected_step_ms=0.209, projected_scaling=2.84)},
-    "c5": {1: dict(per_rank_step_ms=3.788, projected_step_ms=3.788, projected_scaling=1.0),
+    "c3": {1: dict(per_rank_step_ms=0.5866, projected_step_ms=0.5866, projected_scaling=1.0),
+           2: dict(per_rank_step_ms=0.3343, projected_step_ms=0.352, projected_scaling=1.67),
+           4: dict(per_rank_step_ms=0.2385, projected_step_ms=0.260, projected_scaling=2.26),
+           8: dict(per_rank_step_ms=0.1830, projected_step_ms=0.209, projected_scaling=2.81)},
+    "c5": {1: dict(per_rank_step_ms=3.784, projected_step_ms=3.784, projected_scaling=1.0),
            2: dict(per_rank_step_ms=1.91, projected_step_ms=1.94, projected_scaling=1.95),
-           4: dict(per_rank_step_ms=0.96, projected_step_ms=0.987, projected_scaling=3.84),
-           8: dict(per_rank_step_ms=0.5733, projected_step_ms=0.604, projected_scaling=6.27)},
+           4: dict(per_rank_step_ms=0.96, projected_step_ms=0.987, projected_scaling=3.83),
+           8: dict(per_rank_step_ms=0.5866, projected_step_ms=0.618, projected_scaling=6.12)},
 }
 
 

@@ -121,6 +121,9 @@ class WindowPipeline:
         self.multi = self.world > 1 or bool(force_collectives)
         self.host_ptrs = host_tables.device_pointers()
         self.ctx.bind_host_tables(self.host_ptrs)
+        # every rank holds a private copy of the host tables (hostmem.make_host_tables "replicas"): every rank writes its evictions
+        # back -- identical rows on every rank at a commit (sync_touched_to_rank0 precedes it), so the copies stay identical
+        self.replicated_host = bool(getattr(host_tables, "_replicated", False))
         self.window_no = 0
         self._commits = 0
         self.planned = None          # event: plan of the next window is ready
@@ -397,7 +400,9 @@ class WindowPipeline:
         done.record(main)
         with S.on_stream(self.side):
             self.side.wait_event(done)
-            if self.rank == 0 and self.write_back:   # evictions come from rank 0's copy only (main_no_ddp.py:208, 312-315)
+            # evictions come from rank 0's copy only (main_no_ddp.py:208, 312-315); with private host-table copies every rank
+            # applies them to its own
+            if (self.rank == 0 or self.replicated_host) and self.write_back:
                 self.plan.writeback(self.host_ptrs, self.avg, stream=self.side)
             self.written_back = S.new_event(self.dev)
             self.written_back.record(self.side)

@@ -31,6 +31,20 @@ def cpu_share() -> int:
     return max(1, n)
 
 
+def shared_table_dir() -> str:
+    """Where the one shared mapping of the host tables lives at world > 1 (a tmpfs: /dev/shm unless CDLRM_SHM_DIR says otherwise)."""
+    return os.environ.get("CDLRM_SHM_DIR", "/dev/shm")
+
+
+def shared_table_dir_free():
+    """Bytes free there (None: cannot tell)."""
+    try:
+        st = os.statvfs(shared_table_dir())
+        return int(st.f_bavail) * int(st.f_frsize)
+    except OSError:
+        return None
+
+
 def fill_uniform_from_device(dst: torch.Tensor, n_rows: int, device, seed: int, chunk_rows: int = 1 << 21):
     """dst[n, m] ~ U(-sqrt(1/n), sqrt(1/n)) (the reference's init distribution, model_no_ddp.py:70-73), drawn on
     the GPU and copied down in chunks: fast enough for the 96 GB Terabyte-shape tables."""
@@ -50,19 +64,42 @@ def make_host_tables(ln_emb: Sequence[int], m_spa: int, *, device, seed: int = 1
     """Synthetic host tables for bench / Run on synthetic data."""
     ln = [int(n) for n in ln_emb]
     eg = Embedding_Table_Group(m_spa, np.array(ln), init="empty_meta")
-    if world == 1:
+
+    def private_copy():
         for k, n in enumerate(ln):
             w = torch.empty(n, m_spa, dtype=torch.float32, pin_memory=True)
             fill_uniform_from_device(w, n, device, seed * 1009 + k)
             eg.emb_l[k].weight.data = w
         eg._pinned = True
         return eg
+
+    if world == 1:
+        return private_copy()
     total = sum(ln) * m_spa
+    # Two ways to give W ranks the host tables (CDLRM_HOST_TABLES = shared | replicas | auto):
+    #   shared   -- ONE tmpfs mapping registered by every rank (the reference's emb_tables.share_memory()); rank 0 writes evictions;
+    #   replicas -- every rank pins its OWN copy, filled from the same seed (identical bits), and applies every eviction write-back
+    #               to it: the evicted rows are the same on all ranks (the insert is replicated and sync_touched_to_rank0 has just
+    #               made every touched row rank 0's), so the copies stay identical.  W x the memory, no tmpfs, NUMA-local reads.
+    # auto: shared when the tmpfs has room for the tables, replicas otherwise.  Rank 0 decides, everybody follows.
+    import torch.distributed as dist
+    mode = [os.environ.get("CDLRM_HOST_TABLES", "auto")]
+    if mode[0] not in ("shared", "replicas", "auto"):
+        raise ValueError("CDLRM_HOST_TABLES: shared, replicas or auto")
+    if rank == 0 and mode[0] == "auto":
+        free = shared_table_dir_free()
+        mode[0] = "shared" if (free is None or free >= total * 4 + (1 << 30)) else "replicas"
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast_object_list(mode, src=0)
+    if mode[0] == "replicas":
+        private_copy()
+        eg._replicated = True
+        barrier()
+        return eg
     # The backing file: created by rank 0 under a name nobody can predict, exclusively (O_EXCL: never an existing file),
     # without following a symlink, readable by the owner only; the other ranks learn the name from rank 0.  (A fixed
     # world-writable path could be pre-created or symlinked by another local user.)
     import secrets
-    import torch.distributed as dist
     name = [None]
     if rank == 0:
         name[0] = "%s_%s" % (shm_name, secrets.token_hex(8))
@@ -70,8 +107,15 @@ def make_host_tables(ln_emb: Sequence[int], m_spa: int, *, device, seed: int = 1
         dist.broadcast_object_list(name, src=0)
     elif world > 1:
         raise RuntimeError("make_host_tables(world > 1) needs an initialised process group to share the table file's name")
-    path = os.path.join("/dev/shm", name[0])
+    shm_dir = shared_table_dir()
+    path = os.path.join(shm_dir, name[0])
     if rank == 0:
+        # a tmpfs smaller than the tables does not fail at ftruncate: it kills the process with SIGBUS at the first page it
+        # cannot back, in the middle of the fill.  Say it here instead.
+        free = shared_table_dir_free()
+        if free is not None and free < total * 4 + (1 << 30):
+            raise RuntimeError("host tables of %.1f GB do not fit %s (%.1f GB free): point CDLRM_SHM_DIR at a larger tmpfs, or cap "
+                               "the tables (--max-ind-range)" % (total * 4 / 1e9, shm_dir, free / 1e9))
         fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
         try:
             os.ftruncate(fd, total * 4)

@@ -30,6 +30,7 @@ def test_plan_only_prints_one_record_per_rank_and_touches_no_gpu(n):
     r0 = recs[0]
     assert r0["world"] == n and r0["local_batch"] * n == r0["global_batch"] == 8192 and r0["lookahead"] == 3000
     assert r0["host_tables_bytes_one_mapping_per_node"] == 187767399 * 128 * 4
+    assert n == 1 or r0["host_tables_mode"] in ("shared", "replicas")
     assert r0["gpu_max_hw_queues"] == 4 and len({r["master_port"] for r in recs}) == 1
     assert [r["writes_evictions_back"] for r in recs] == [True] + [False] * (n - 1)
     assert r0["hbm_bytes_per_rank"]["cache_rows"] > 10e9 and r0["hbm_bytes_per_rank"]["sum_without_growth"] < 200e9
@@ -39,20 +40,24 @@ def test_plan_only_prints_one_record_per_rank_and_touches_no_gpu(n):
 
 def test_rank_resources_follow_the_cpu_share():
     import bench
-    roomy = bench.rank_resources("c3", 8, cpus=128, mem_limit=0)
+    roomy = bench.rank_resources("c3", 8, cpus=128, mem_limit=0, shm_free=1 << 40)
     assert roomy["cpus_per_rank"] == 16 and roomy["tape_lanes"] == 3 and roomy["plan_gather_threads"] == 13 and not roomy["notes"]
-    tight = bench.rank_resources("c3", 8, cpus=16, mem_limit=0)
+    tight = bench.rank_resources("c3", 8, cpus=16, mem_limit=0, shm_free=1 << 40)
     assert tight["cpus_per_rank"] == 2 and tight["tape_lanes"] == 1 and tight["plan_gather_threads"] == 1 and len(tight["notes"]) == 2
     one = bench.rank_resources("c3", 1, cpus=16, mem_limit=0)
     assert one["tape_lanes"] == 1 and one["plan_gather_threads"] == 13      # (a local batch of 8192 replays in one lane)
-    assert bench.rank_resources("c3", 8, cpus=128, mem_limit=0)["omp_num_threads"] == 16
+    assert bench.rank_resources("c3", 8, cpus=128, mem_limit=0, shm_free=1 << 40)["omp_num_threads"] == 16
 
 
 def test_rank_resources_refuse_what_cannot_fit():
     import bench
     assert bench.rank_resources("c3", 8, cpus=128, mem_limit=64 << 30)["refused"], "96 GB of host tables in a 64 GB job"
-    assert not bench.rank_resources("c3", 8, cpus=128, mem_limit=512 << 30)["refused"]
-    assert any("divide" in r for r in bench.rank_resources("c3", 3, cpus=128, mem_limit=0)["refused"])
+    assert not bench.rank_resources("c3", 8, cpus=128, mem_limit=512 << 30, shm_free=1 << 40)["refused"]
+    small = bench.rank_resources("c3", 8, cpus=128, mem_limit=0, shm_free=64 << 30)
+    assert small["host_tables_mode"] == "replicas" and not small["refused"], "96 GB of tables, 64 GB of /dev/shm: private copies"
+    assert bench.rank_resources("c3", 8, cpus=128, mem_limit=400 << 30, shm_free=64 << 30)["refused"], "8 x 96 GB in a 400 GB job"
+    assert bench.rank_resources("c3", 8, cpus=128, mem_limit=0, shm_free=1 << 40)["host_tables_mode"] == "shared"
+    assert any("divide" in r for r in bench.rank_resources("c3", 3, cpus=128, mem_limit=0, shm_free=1 << 40)["refused"])
     huge = bench.rank_resources("c4", 1, cpus=16, mem_limit=300 << 30)
     assert huge["refused"], "c4 uncapped pins 192 GB"
     assert not bench.rank_resources("c4", 1, cpus=16, mem_limit=300 << 30, max_ind_range=2000000)["refused"]

@@ -98,6 +98,25 @@ def test_bench_gpus_2_as_typed_runs_two_ranks():
 
 
 @pytest.mark.gpu
+def test_private_host_table_copies_equal_the_shared_mapping():
+    """hostmem.make_host_tables at world > 1: ONE tmpfs mapping registered by every rank (rank 0 writes evictions back), or -- when
+    the tmpfs is too small for the tables -- a private pinned copy per rank to which every rank applies the write-backs.  Same
+    bits either way: 400 steps over 50 small windows of uniform indices (sets fill, rows are evicted and written back, later
+    windows fetch them again), two ranks, final loss equal to the last bit."""
+    losses = {}
+    for mode in ("shared", "replicas"):
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "c1", "--steps", "400", "--warmup", "2",
+                            "--lookahead", "8", "--alpha", "0", "--prewarm-ms", "0"],
+                           env=_env(CDLRM_BENCH_EMULATE="1", CDLRM_HOST_TABLES=mode), capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = _json_line(p.stdout)
+        assert line["n_gpus"] == 2 and line["config"]["refills_in_timed_region"]["window_commits"] >= 40
+        losses[mode] = line["config"]["final_loss"]
+    assert losses["shared"] == losses["replicas"], losses
+
+
+@pytest.mark.gpu
 def test_cli_world_size_2_as_typed_equals_the_torchrun_launch():
     """The README command shape (`python main_no_ddp.py ... --world-size=N`) works as typed and prints what the same ranks
     print under an explicit torchrun."""
