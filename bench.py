@@ -14,6 +14,12 @@ prefetch) that fall into it.  Rank 0 prints ONE JSON line.
 Between the W warm-up steps and the timed region the GPU is kept busy for --prewarm-ms (default 300 ms, scratch GEMMs, no
 training state; reported as config.gpu_prewarm_ms): the part needs that long under load to reach its clocks after set-up, and a
 short timed region would otherwise report the ramp.  --prewarm-ms 0 switches it off.
+
+Behind the K timed steps (whose figure `value` / `ms_per_step` stay) a one-GPU run trains on through ONE WHOLE look-ahead window and
+reports it as config.whole_window: L steps timed on their own with exactly one background plan launched and one window commit
+inside -- the look-ahead side of the path inside a measurement, which 20 steps of a 3000-step window cannot hold.  Then the
+stand-alone legs (roofline.gather_operator, roofline.alone) and, at N = 1, cpu_baseline: the oracle on the host cores in the
+workload's cache regime.  `--gpus N --plan-only` prints what every rank will ask the node for and exits without a HIP call.
 """
 import argparse
 import json
