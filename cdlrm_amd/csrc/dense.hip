@@ -206,6 +206,11 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
         const float4* __restrict__ p4 = reinterpret_cast<const float4*>(partA);
         for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gxa * blockDim.x) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            // (the parameter word of the fused SGD step travels WITH the first slabs, not behind the last: one load latency less
+            //  at the end of a launch that sits on the training queue of every step)
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pA) q = reinterpret_cast<const float4*>(pA)[e];
+            __builtin_amdgcn_sched_barrier(0);
             int z = 0;
             for (; z + 8 <= splitsA; z += 8) {
                 float4 v[8];
@@ -220,7 +225,6 @@ __device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restri
             }
             reinterpret_cast<float4*>(outA)[e] = s;
             if (pA) {
-                float4 q = reinterpret_cast<float4*>(pA)[e];
                 q.x = fmaf(-lr, s.x, q.x); q.y = fmaf(-lr, s.y, q.y); q.z = fmaf(-lr, s.z, q.z); q.w = fmaf(-lr, s.w, q.w);
                 reinterpret_cast<float4*>(pA)[e] = q;
             }

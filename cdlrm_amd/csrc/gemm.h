@@ -34,11 +34,14 @@ struct GemmArgs {
     const float* mask; int64_t ldmask; int mask_act;   // epilogue: C *= act'(mask[m,n]) (1 ReLU output, 2 sigmoid output)
     float* colsum;                            // !A_KC only: colsum[z*M + m] = sum over this split's k of A(m,k)
     int vecC;                                 // 16-byte stores legal (k_gemm_direct)
+    int fastep;                               // epilogue operands fetched ahead of their use: k_gemm2's loads-first epilogue of full
+                                              // tiles, the short-batch kernels' prefetch at kernel start (direct_prefetch)
 };
 
 static inline GemmArgs gemm_args() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.fastep = g_cdlrm_debug[7] == 1 ? 0 : 1;       // (development switch: the epilogues before round 5)
     return g;
 }
 
@@ -364,12 +367,37 @@ __device__ __forceinline__ void direct_mma(const float4 (&a)[8], const float4 (&
     }
 }
 
+// The epilogue's operand words -- this thread's four bias values and four words of the activation mask -- fetched at the START of
+// the kernel (round 5): behind the contraction loop and the LDS exchange they were one more load latency in front of the store,
+// in every one of the 13 GEMM launches of a short-batch step, whose kernels take 7-13 us each.  Same words, same arithmetic.
+// ok: the thread stores a whole float4 inside the matrix and both operands are 16-byte loadable; otherwise direct_finish loads
+// them itself, element by element, as before.  (cdlrm_debug_set(7, 1) -> GemmArgs.fastep = 0: never.)
+struct DirectPre {
+    float4 b, m;
+    bool ok;
+};
+__device__ __forceinline__ DirectPre direct_prefetch(const GemmArgs& g, int64_t m0, int64_t n0) {
+    DirectPre p;
+    p.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.m = p.b;
+    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const int64_t gm = m0 + row, gn = n0 + c4;
+    p.ok = g.fastep && g.vecC && gm < g.M && gn + 3 < (int64_t)g.N &&
+           (g.bias == nullptr || (((uintptr_t)g.bias) & 15) == 0) &&
+           (g.mask_act == 0 || ((((uintptr_t)g.mask) & 15) == 0 && (g.ldmask & 3) == 0));
+    if (p.ok) {
+        if (g.bias) p.b = *reinterpret_cast<const float4*>(g.bias + gn);
+        if (g.mask_act) p.m = *reinterpret_cast<const float4*>(g.mask + gm * g.ldmask + gn);
+    }
+    return p;
+}
+
 // The 4 partial tiles of a workgroup meet in LDS and are summed in wave order (fixed order: reproducible), then bias /
 // activation / mask and a row-contiguous store; the bias-gradient column sums likewise.
 template <bool A_KC>
 __device__ __forceinline__ void direct_finish(const GemmArgs& g, unsigned bx, unsigned bz, int64_t m0, int64_t n0, int wave,
                                               int lr, int lk, const f32x16& acc, float cs, float (*red)[32][33],
-                                              float (*csr)[32]) {
+                                              float (*csr)[32], const DirectPre& pre) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[r];
     if (!A_KC && g.colsum != nullptr && bx == 0) {
@@ -390,11 +418,12 @@ __device__ __forceinline__ void direct_finish(const GemmArgs& g, unsigned bx, un
         const int64_t gn = n0 + c4 + u;
         float x = ((red[0][row][c4 + u] + red[1][row][c4 + u]) + red[2][row][c4 + u]) + red[3][row][c4 + u];
         if (gn < g.N) {
-            if (g.bias) x += g.bias[gn];
+            if (g.bias) x += pre.ok ? (u == 0 ? pre.b.x : u == 1 ? pre.b.y : u == 2 ? pre.b.z : pre.b.w) : g.bias[gn];
             if (g.act == 1) x = x > 0.f ? x : 0.f;
             else if (g.act == 2) x = 1.0f / (1.0f + expf(-x));
             if (g.mask_act) {
-                const float y = g.mask[gm * g.ldmask + gn];
+                const float y = pre.ok ? (u == 0 ? pre.m.x : u == 1 ? pre.m.y : u == 2 ? pre.m.z : pre.m.w)
+                                       : g.mask[gm * g.ldmask + gn];
                 x = g.mask_act == 1 ? (y > 0.f ? x : 0.f) : x * ((1.0f - y) * y);
             }
         }
@@ -419,6 +448,8 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the contraction range is uniform
     const int lr = lane & 31, lk = lane >> 5;
     const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const DirectPre pre = direct_prefetch(g, m0, n0);
+    __builtin_amdgcn_sched_barrier(0);          // (the loads stay HERE: hipcc would sink them to their use behind the loop)
     const int64_t kbeg = (int64_t)bz * g.kchunk;
     const int64_t kend = min(g.K, kbeg + g.kchunk);
     // a quarter of the range: rounded up to 8, or (aligned path) to 32 so that every wave starts on a 32-group
@@ -485,7 +516,7 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g, unsigned bx, unsi
     }
 #undef DIRECT_LOAD_A
 #undef DIRECT_LOAD_B
-    direct_finish<A_KC>(g, bx, bz, m0, n0, wave, lr, lk, acc, cs, red, csr);
+    direct_finish<A_KC>(g, bx, bz, m0, n0, wave, lr, lk, acc, cs, red, csr, pre);
 }
 
 template <bool A_KC, bool B_KC, bool VA, bool VB, int MODE, bool AL>
@@ -590,6 +621,8 @@ __device__ __forceinline__ void staged_body(const GemmArgs& g, unsigned bx, unsi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const DirectPre pre = direct_prefetch(g, m0, n0);
+    __builtin_amdgcn_sched_barrier(0);
     const int64_t kbeg = (int64_t)bz * g.kchunk;
     const int64_t kend = min(g.K, kbeg + g.kchunk);
     const int64_t kq = ((kend - kbeg + 127) / 128) * 32;
@@ -660,7 +693,7 @@ __device__ __forceinline__ void staged_body(const GemmArgs& g, unsigned bx, unsi
     __syncthreads();        // every wave is done with its staging region: the reduction buffers alias it
     float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(lds);
     float (*csr)[32] = reinterpret_cast<float (*)[32]>(lds + 4 * 32 * 33);
-    direct_finish<A_KC>(g, bx, bz, m0, n0, wave, lr, lk, acc, cs, red, csr);
+    direct_finish<A_KC>(g, bx, bz, m0, n0, wave, lr, lk, acc, cs, red, csr, pre);
 }
 
 template <bool A_KC, bool B_KC, int MODE>

@@ -160,6 +160,79 @@ __device__ __forceinline__ void g2_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
     }
 }
 
+// Epilogue of a tile that lies INSIDE the matrix, forward / dgrad layouts (round 5): every operand word it needs (bias: forward;
+// the activation mask: dgrad) is loaded FIRST, then the 4 * TM * TN stores leave back to back -- the generic epilogue above
+// interleaves a load, its wait and a store per register group, and behind a store that wait (vmcnt(0)) is the store's round
+// trip: the "store tail" of 10.5 k cycles per workgroup was eight of those in a row.  Same values, same stores: bit-identical.
+template <int TM, int TN, bool B_KC, int ACT>
+__device__ __forceinline__ void g2_epilogue_full(const GemmArgs& g, f32x16 (&acc)[TM][TN], int64_t m0, int64_t n0, int wm, int wn,
+                                                 int lane) {
+    float4 bv[TN][4];
+    float4 mv[B_KC ? 1 : TM][B_KC ? 1 : TN][4];
+    const int64_t row0 = m0 + wm * (32 * TM) + (lane & 31);
+    const int64_t col0 = n0 + wn * (32 * TN) + 4 * (lane >> 5);
+    if (B_KC) {
+        if (g.bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(g.bias + col0 + j * 32 + 8 * q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mv[i][j][q] = *reinterpret_cast<const float4*>(g.mask + (row0 + i * 32) * g.ldmask + col0 + j * 32 + 8 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (B_KC) {
+                    const float4 b = bv[j][q];
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                    if (ACT == 1) {
+                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    } else if (ACT == 2) {
+                        v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+                        v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+                    }
+                } else {
+                    const float4 x = mv[i][j][q];
+                    if (ACT == 1) {
+                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
+                        v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                    } else if (ACT == 2) {
+                        v.x *= (1.0f - x.x) * x.x; v.y *= (1.0f - x.y) * x.y;
+                        v.z *= (1.0f - x.z) * x.z; v.w *= (1.0f - x.w) * x.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(g.C + (row0 + i * 32) * g.ldc + col0 + j * 32 + 8 * q) = v;
+            }
+}
+
+// what g2_epilogue_full can take: forward = bias (absent or 16-byte loadable) + activation, no mask; dgrad = an activation mask
+// with 16-byte loadable rows (or none), no bias / activation.  `fastep` is set by the host (launch_gemm) from the debug switch.
+template <bool B_KC>
+__device__ __forceinline__ bool g2_full_ok(const GemmArgs& g) {
+    if (!g.fastep) return false;
+    if (B_KC) return g.mask_act == 0 && (g.bias == nullptr || (((uintptr_t)g.bias) & 15) == 0);
+    return g.bias == nullptr && g.act == 0 && (g.mask_act == 0 || ((((uintptr_t)g.mask) & 15) == 0 && (g.ldmask & 3) == 0));
+}
+
 #ifdef GEMM2_STAMP      // diagnostic builds only (tools/gemm2_bench.hip): where a workgroup's time goes, and at what clock
 __device__ unsigned long long g2_stamps[8 * 4096];
 #define G2_STAMP(slot)                                                                            \
@@ -311,7 +384,16 @@ __device__ __forceinline__ void gemm2_tile_body(const GemmArgs& g, unsigned bx, 
             }
         }
     }
-    g2_epilogue<TM, TN>(g, acc, m0, n0, bz, wm, wn, lane);
+    // a tile inside the matrix of an un-split forward / dgrad launch takes the loads-first epilogue (cdlrm_debug_set(7, 1): never)
+    bool fast = A_KC && gridDim.z == 1 && m0 + BM <= g.M && n0 + BN <= (int64_t)g.N && g2_full_ok<B_KC>(g);
+    if (fast) {
+        const int actk = B_KC ? g.act : g.mask_act;
+        if (actk == 1) g2_epilogue_full<TM, TN, B_KC, 1>(g, acc, m0, n0, wm, wn, lane);
+        else if (actk == 2) g2_epilogue_full<TM, TN, B_KC, 2>(g, acc, m0, n0, wm, wn, lane);
+        else g2_epilogue_full<TM, TN, B_KC, 0>(g, acc, m0, n0, wm, wn, lane);
+    } else {
+        g2_epilogue<TM, TN>(g, acc, m0, n0, bz, wm, wn, lane);
+    }
     G2_STAMP(3)
 }
 

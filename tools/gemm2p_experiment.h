@@ -18,69 +18,7 @@
 // 4 * TM * TN of them -- its stores -- when the tile was full]; `vmcnt(4 * TM * TN)` therefore covers the DMA without waiting
 // for the stores.  A tile with clipped stores waits vmcnt(0).  The barrier is a bare s_barrier behind explicit wait counts
 // (__syncthreads()'s fence would wait vmcnt(0)); LDS needs no fence inside a workgroup.
-// Epilogue of a FULL tile in the persistent kernel: every operand word it needs (bias: forward layout; the activation mask:
-// dgrad layout) is loaded FIRST, then the 4 * TM * TN stores leave back to back -- the generic epilogue above interleaves a load,
-// its wait and a store per register group, and behind a store that wait (vmcnt(0)) is the store's round trip.
-template <int TM, int TN, bool B_KC, int ACT>
-__device__ __forceinline__ void g2_epilogue_full(const GemmArgs& g, f32x16 (&acc)[TM][TN], int64_t m0, int64_t n0, int wm, int wn,
-                                                 int lane) {
-    float4 bv[TN][4];
-    float4 mv[B_KC ? 1 : TM][B_KC ? 1 : TN][4];
-    const int64_t row0 = m0 + wm * (32 * TM) + (lane & 31);
-    const int64_t col0 = n0 + wn * (32 * TN) + 4 * (lane >> 5);
-    if (B_KC) {
-        if (g.bias) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(g.bias + col0 + j * 32 + 8 * q);
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    mv[i][j][q] = *reinterpret_cast<const float4*>(g.mask + (row0 + i * 32) * g.ldmask + col0 + j * 32 + 8 * q);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                if (B_KC) {
-                    const float4 b = bv[j][q];
-                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-                    if (ACT == 1) {
-                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                    } else if (ACT == 2) {
-                        v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
-                        v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
-                    }
-                } else {
-                    const float4 x = mv[i][j][q];
-                    if (ACT == 1) {
-                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
-                        v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
-                    } else if (ACT == 2) {
-                        v.x *= (1.0f - x.x) * x.x; v.y *= (1.0f - x.y) * x.y;
-                        v.z *= (1.0f - x.z) * x.z; v.w *= (1.0f - x.w) * x.w;
-                    }
-                }
-                *reinterpret_cast<float4*>(g.C + (row0 + i * 32) * g.ldc + col0 + j * 32 + 8 * q) = v;
-            }
-}
-
+// (g2_epilogue_full, the loads-first epilogue of full tiles, has since moved into gemm_glds.h: the production kernel takes it)
 template <int KEEP>
 __device__ __forceinline__ void g2_wait_keep() {
     if (KEEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");

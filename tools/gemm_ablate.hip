@@ -11,6 +11,11 @@
 #include "gemm.h"
 
 void cdlrm_set_error(const char* fmt, ...) {}
+int g_cdlrm_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+CdlrmStopState* cdlrm_stop_state() {
+    static thread_local CdlrmStopState st{nullptr, nullptr, 0};
+    return &st;
+}
 
 int main(int argc, char** argv) {
     int64_t M = 8192; int N = 512, K = 512;

@@ -52,6 +52,7 @@ static void run(const char* name, int64_t M, int N, int64_t K) {
     g.A = A; g.lda = K; g.B = B; g.ldb = B_KC ? K : N; g.ldc = N; g.slab = (int64_t)M * N; g.M = M; g.N = N; g.K = K; g.kchunk = K;
     g.vecA = g.vecB = 1;
     if (B_KC) { g.bias = bias; g.act = 1; } else { g.mask = mask; g.ldmask = N; g.mask_act = 1; }
+    g.fastep = 0;               // (the reference launch and the plain variants: the epilogue before round 5)
     GemmArgs g0 = g, g1 = g; g0.C = C0; g1.C = C1;
     std::vector<float> h0((size_t)M * N), h1((size_t)M * N);
     launch<A_KC, B_KC, 2, 1>(g0); hipDeviceSynchronize();
@@ -71,6 +72,11 @@ static void run(const char* name, int64_t M, int N, int64_t K) {
         fflush(stdout);
     };
     one("128x64", [&]() { launch<A_KC, B_KC, 2, 1>(g1); });
+    GemmArgs gf = g1;
+    gf.fastep = 1;              // the loads-first epilogue of full tiles (production default)
+    one("128x64 fastep", [&]() { launch<A_KC, B_KC, 2, 1>(gf); });
+    one("64x64", [&]() { launch<A_KC, B_KC, 1, 1>(g1); });
+    one("64x64 fastep", [&]() { launch<A_KC, B_KC, 1, 1>(gf); });
     one("128x128", [&]() { launch<A_KC, B_KC, 2, 2>(g1); });
     one("p128x64 G512", [&]() { launch_p<A_KC, B_KC, 2, 1>(g1, 512); });
     one("p128x64 G768", [&]() { launch_p<A_KC, B_KC, 2, 1>(g1, 768); });

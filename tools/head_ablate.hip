@@ -4,6 +4,11 @@
 #include <stdarg.h>
 #include "dense.hip"
 void cdlrm_set_error(const char* fmt, ...) {}
+int g_cdlrm_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+CdlrmStopState* cdlrm_stop_state() {
+    static thread_local CdlrmStopState st{nullptr, nullptr, 0};
+    return &st;
+}
 
 int main(int argc, char** argv) {
     int64_t B = 8192; int K = 256;
