@@ -143,3 +143,32 @@ def test_cli_without_a_gpu_says_there_is_no_cpu_fallback():
     p = subprocess.run([sys.executable, "bench.py", "--config", "c1", "--steps", "2", "--warmup", "1"], env=_env(),
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert p.returncode != 0 and "no CPU fallback" in p.stderr and "Traceback" not in p.stderr, p.stderr[-800:]
+
+
+@pytest.mark.gpu
+def test_cli_world_size_2_tests_on_rank_0_inside_the_training_loop(tmp_path):
+    """`--test-freq` at world > 1: the test loop runs on rank 0 only (main_no_ddp.py:478-494) while rows of a table-agg merge may
+    still be travelling in deadline order -- every rank drains them (collectives) before rank 0 tests alone; neither rank may
+    hang or issue an exchange the other does not.  Day files in the reference's format, two ranks emulated on the one GPU."""
+    import numpy as np
+    rng = np.random.RandomState(3)
+    counts = np.array([900, 40, 7, 300, 1500])
+    sizes = [64 * 9 + 9, 64 * 8 + 30, 64 * 2]
+    for day, n in enumerate(sizes):
+        np.savez(os.path.join(tmp_path, "day_%d_reordered.npz" % day), X_int=rng.randint(0, 500, size=(n, 13)).astype(np.int32),
+                 X_cat=np.stack([rng.randint(0, c, size=n) for c in counts], axis=1).astype(np.int32),
+                 y=rng.randint(0, 2, size=n).astype(np.int32))
+    np.savez(os.path.join(tmp_path, "day_day_count.npz"), total_per_file=np.array(sizes))
+    np.savez(os.path.join(tmp_path, "day_fea_count.npz"), counts=counts)
+    flags = [f for f in CLI_FLAGS if not f.startswith(("--arch-embedding-size", "--data-generation", "--num-batches",
+                                                       "--table-agg-freq", "--lookahead"))]
+    flags += ["--data-generation=dataset", "--raw-data-file=" + os.path.join(tmp_path, "day"), "--lookahead=8",
+              "--table-agg-freq=3", "--test-freq=4", "--world-size=2"]
+    p = subprocess.run([sys.executable, "-m", "cdlrm_amd.main_no_ddp"] + flags, env=_env(CDLRM_BENCH_EMULATE="1"),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    n_train = (sizes[0] + sizes[1]) // 64
+    assert p.stdout.count("Testing at") == (n_train - 1) // 4 + (0 if (n_train - 1) % 4 == 0 else 1), p.stdout[-2000:]
+    assert p.stdout.count("Test accuracy = ") == p.stdout.count("Testing at")
+    losses = [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", p.stdout)]
+    assert len(losses) == n_train - 1 and all(0.0 < x < 10.0 for x in losses) and losses[-1] < 1.0, losses
