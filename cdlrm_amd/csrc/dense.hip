@@ -291,6 +291,11 @@ static int wgrad_splits(int64_t M, int N, int K) {
     return (int)s;
 }
 
+// (Round 5, measured and removed: a STREAMING kernel for the weight gradient of the 13-wide layer at long batches -- a thread owns
+//  four columns of dZ, 16-byte loads, eight rows in flight, the slab's X rows in LDS, 128-row slabs into the grouped reduction;
+//  correct against fp64 at M = 16384 / 20011 -- because the LDS-free MFMA kernel takes 251 us for it inside a c5 step (134 MB of
+//  dZ, 17 us of HBM time).  In the step: c5 3.7080 against 3.7059 ms, a tie; forced at c3 0.5680 against 0.5599, at 4096 0.3394
+//  against 0.3288.  That launch lies in the half of the step that is bound by the SUM of its work, not by any kernel's length.)
 extern "C" uint64_t cdlrm_linear_bwd_work_bytes(int64_t M, int32_t N, int32_t K) {
     const uint64_t splits = (uint64_t)wgrad_splits(M, N, K);
     const uint64_t slabs = splits * N * K * 4;

@@ -637,10 +637,10 @@ def test_fused_gather_interaction_refuses_other_shapes(ops):
     assert torch.equal(R0, R1)
 
 
-@pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 4096, 8192])
+@pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 4096, 8192, 16384, 20011])
 def test_mlp_wgrad_group(ops, M):
     """All layers' weight + bias gradients in one call (grouped LDS-free launch up to M = 2048, tiled split-M path
-    above) against fp64 torch."""
+    above, up to M = 20011: a ragged last slab) against fp64 torch."""
     rng = np.random.RandomState(M)
     shapes = [(512, 13), (256, 512), (128, 256), (512, 480), (512, 512), (256, 512), (1, 256), (70, 33), (5, 3)]
     Xs, dZs, dWs, dbs = [], [], [], []
@@ -664,7 +664,7 @@ def test_mlp_wgrad_group(ops, M):
                                        atol=1e-5 * scale)
 
 
-@pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 8192])
+@pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 8192, 16500])
 def test_mlp_wgrad_with_fused_sgd_step(ops, M):
     """cdlrm_mlp_wgrad_sgd: the dense SGD step inside the weight-gradient launches (slab reduction; elementwise pass for
     layers without slabs) = cdlrm_mlp_wgrad followed by p -= lr * g, bit for bit, gradients still left in dW / db."""
