@@ -89,8 +89,22 @@ def make_host_tables(ln_emb: Sequence[int], m_spa: int, *, device, seed: int = 1
     if rank == 0 and mode[0] == "auto":
         free = shared_table_dir_free()
         mode[0] = "shared" if (free is None or free >= total * 4 + (1 << 30)) else "replicas"
+    if rank == 0 and mode[0] == "replicas":
+        # W private copies are W x the tables of PINNED host memory: say so before the kernel's OOM killer does
+        limit = None
+        try:
+            txt = open("/sys/fs/cgroup/memory.max").read().strip()
+            limit = int(txt) if txt.isdigit() else None
+        except OSError:
+            pass
+        if limit and world * total * 4 > 0.85 * limit:
+            mode[0] = "error: %d private copies of the host tables (%.0f GB each) exceed this job's memory limit (%.0f GB) and %s " \
+                      "holds %.0f GB: CDLRM_SHM_DIR=<larger tmpfs> or cap the tables (--max-ind-range)" \
+                      % (world, total * 4 / 1e9, limit / 1e9, shared_table_dir(), (shared_table_dir_free() or 0) / 1e9)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast_object_list(mode, src=0)
+    if mode[0].startswith("error"):
+        raise RuntimeError(mode[0])
     if mode[0] == "replicas":
         private_copy()
         eg._replicated = True
