@@ -372,7 +372,7 @@ def _c5_data():
     return ln_emb, wins, dense
 
 
-def _c5_worker(rank, world, port, host_shared, ret):
+def _c5_worker(rank, world, port, host_shared, ret, chained=True):
     import faulthandler
     # a stuck rank says where, well inside the runner's patience -- into a file the GPU runner brings back even if it has to
     # kill the whole run (the parent's captured stderr would be lost with it)
@@ -408,8 +408,13 @@ def _c5_worker(rank, world, port, host_shared, ret):
         eng.agg_chunk_rows = 4096           # the touched-row merge in several chunks on the exchange stream
         # the chained-take schedule (c5 on 1 - 4 ranks: local batches >= 16384; since round 5 a local batch of 8192 takes the
         # two-region schedule by default, which the other multi-rank cases run): forced here at the size this box can check
-        eng.gather_alone_min = lbs
-        assert not eng._side_gather(lbs), "the long-batch schedule (interaction forward alone on the training queue, chained take)"
+        if chained:
+            eng.gather_alone_min = lbs
+            assert not eng._side_gather(lbs), "the long-batch schedule (interaction forward alone on the training queue, chained take)"
+        else:
+            # the production choice at this local batch: two aux regions, the look-ahead resolve PLACED behind the interaction
+            # forward (place_resolve_min) -- at world > 1 behind the row merge's deadline pass as well
+            assert eng._side_gather(lbs) and lbs >= eng.place_resolve_min
         pipe = engine.WindowPipeline(cg, eg, L * B, parity_rng=True, rank=rank, world_size=world)
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
         losses, j = [], 0
@@ -449,7 +454,8 @@ def _c5_worker(rank, world, port, host_shared, ret):
         raise
 
 
-def test_c5_flow_two_ranks_vs_oracle():
+@pytest.mark.parametrize("chained,port", [(True, 29865), (False, 29866)])
+def test_c5_flow_two_ranks_vs_oracle(chained, port):
     """BASELINE configs[4] at world > 1 on its own code path: a local batch of 8192 per rank (the long-batch schedule: gather
     alone on the training queue, chained take, resolve placed inside the step), the window streamed into the plan in chunks, a
     window-resident resolver per chunk, the touched-row merge in chunks on the exchange stream, deferred top-MLP update --
@@ -487,7 +493,7 @@ def test_c5_flow_two_ranks_vs_oracle():
             j += 1
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_c5_worker, args=(r, world, 29865, host, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, port, host, ret, chained)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
