@@ -515,6 +515,12 @@ static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
         // 0.5739 ms per c3 step, six rounds, every round.  (EVERY forward / dgrad on 64x64: 0.5776 against 0.5747; the weight
         // gradients too: 0.5819 / 0.5863 -- the 512-wide layers keep 128x64.)
         if (splits == 1 && g.K <= 256) tm2 = 1;
+        // ... and where a CU gets >= 4 tiles of 128x128 (un-split forward / dgrad at M = 65536: c5) that shape, one workgroup per
+        // CU, a third less LDS fill per MFMA: stand-alone 297.5 against 313.7 us (512 x 512 forward), 283.1 / 297.7 (512 <- 480),
+        // 158.7 / 165.9 (256 <- 512), dgrad 318.0 / 322.5 (profiles/r05_gemm_big_tiles.txt); in the c5 step 3.6927 against
+        // 3.7159 ms, ten rounds (-0.6 %; cdlrm_debug_set(6, 16): 128x64 as before).  Bit-identical (a tile's k order does not
+        // depend on its shape).  At M = 8192 the same shape is one tile per CU and loses (round 2, and again in round 5).
+        if (!(g_cdlrm_debug[6] & 16) && A_KC && splits == 1 && tm2 == 2 && cdiv(g.M, 128) * cdiv(g.N, 128) >= 1024) tn2 = 2;
         launch_gemm2<A_KC, B_KC>(g, tm2, tn2, splits, s);
         CDLRM_LAUNCH_CHECK();
         return 0;
