@@ -521,6 +521,7 @@ static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
         // 3.7159 ms, ten rounds (-0.6 %; cdlrm_debug_set(6, 16): 128x64 as before).  Bit-identical (a tile's k order does not
         // depend on its shape).  At M = 8192 the same shape is one tile per CU and loses (round 2, and again in round 5).
         if (!(g_cdlrm_debug[6] & 16) && A_KC && splits == 1 && tm2 == 2 && cdiv(g.M, 128) * cdiv(g.N, 128) >= 1024) tn2 = 2;
+        // (the same shape for the split-M weight gradients of a long batch: a tie, c5 3.7017 against 3.6995 ms, ten rounds -- not taken)
         launch_gemm2<A_KC, B_KC>(g, tm2, tn2, splits, s);
         CDLRM_LAUNCH_CHECK();
         return 0;
