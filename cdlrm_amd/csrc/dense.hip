@@ -4,7 +4,7 @@
 //
 // fp32 everywhere (1e-5 loss-trajectory parity): v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32
 // fma chain at the fp32 vector peak (MI355X_MICROARCH.md "Matrix cores").
-#include "gemm_glds.h"
+#include "gemm_wide.h"
 
 
 // Linear forward with a short contraction (K <= 32: the first bottom layer reads the 13 dense features).  An MFMA
@@ -124,6 +124,9 @@ __global__ void __launch_bounds__(256) k_linear_smallk_rows(const float* __restr
 extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y, int64_t ld_y,
                                 int64_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     CDLRM_REQUIRE(X && W && Y && M >= 0 && N >= 1 && K >= 1 && ld_x >= K && ld_y >= N, "bad argument");
+    const int alone = (act & CDLRM_GEMM_ALONE) != 0;       // scheduling hint riding on the activation code
+    act &= ~CDLRM_GEMM_ALONE;
+    CDLRM_REQUIRE(act >= 0 && act <= 2, "bad activation code");
     if (M == 0) return 0;
     CDLRM_CLEAR_STALE();
     if (K == 13 && N % 256 == 0 && ld_y % 4 == 0 && aligned16(Y) && (!bias || aligned16(bias)) && M >= 256 &&
@@ -152,6 +155,7 @@ extern "C" int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, co
     g.M = M; g.N = N; g.K = K; g.kchunk = K; g.bias = bias; g.act = act;
     g.vecA = aligned16(X) && ld_x % 4 == 0 && K % 4 == 0;
     g.vecB = aligned16(W) && K % 4 == 0;
+    g.alone = alone;
     return launch_gemm<true, true>(g, 1, (hipStream_t)stream);
 }
 
@@ -323,6 +327,8 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
                                 int64_t ld_dy, float* dX, int64_t ld_dx, float* dW, float* db, int64_t M, int32_t N,
                                 int32_t K, int32_t act, int32_t x_act, void* work, void* stream) {
     CdlrmStopScope stop_scope;          // (first: every exit below flushes an attached completion event)
+    const int alone = (act & CDLRM_GEMM_ALONE) != 0;       // scheduling hint for the dgrad GEMM, riding on the activation code
+    act &= ~CDLRM_GEMM_ALONE;
     CDLRM_REQUIRE(X && W && dY && work && M >= 1 && N >= 1 && K >= 1, "bad argument");
     CDLRM_REQUIRE(dW || !db, "db without dW (the bias gradient is a by-product of the weight-gradient GEMM)");
     CDLRM_REQUIRE(act == 0 || Y, "activation backward needs Y");
@@ -346,6 +352,7 @@ extern "C" int cdlrm_linear_bwd(const float* X, int64_t ld_x, const float* W, co
         g.vecA = aligned16(dY) && ld_dy % 4 == 0 && N % 4 == 0;
         g.vecB = aligned16(W) && K % 4 == 0;
         g.mask = X; g.ldmask = ld_x; g.mask_act = x_act;
+        g.alone = alone;
         int rc = launch_gemm<true, false>(g, 1, s);
         if (rc) return rc;
     }

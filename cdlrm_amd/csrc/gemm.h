@@ -36,6 +36,8 @@ struct GemmArgs {
     int vecC;                                 // 16-byte stores legal (k_gemm_direct)
     int fastep;                               // epilogue operands fetched ahead of their use: k_gemm2's loads-first epilogue of full
                                               // tiles, the short-batch kernels' prefetch at kernel start (direct_prefetch)
+    int alone;                                // the caller's hint CDLRM_GEMM_ALONE: no other GEMM runs beside this launch (the wide
+                                              // kernel of gemm_wide.h wants a whole CU: 96 KB of LDS, one wave per SIMD)
 };
 
 static inline GemmArgs gemm_args() {

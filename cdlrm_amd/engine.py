@@ -672,6 +672,12 @@ class TrainEngine:
         # against 0.68 of 8 TB/s; bench.py reports both, roofline.frac and roofline.alone).  At 65536 the chained take stays
         # (3.718 against 3.741 ms), 4096 is a tie, 2048 / 1024 keep two regions (0.2422 / 0.2433, 0.1798 / 0.1845 the other way).
         self.gather_alone_min = 16384
+        # The top MLP's forward and its input-gradient chain run with no other GEMM beside them in every schedule of the step
+        # (the weight gradients start behind the chain, top_wgrad_after): these launches carry CDLRM_GEMM_ALONE and, where their
+        # 128x128 tiles fill the chip (local batch 8192 x 512-wide layers: 256 tiles on 256 CUs; c5), take the one-workgroup-per-CU
+        # kernel (csrc/gemm_wide.h).  The bottom MLP's backward runs beside the weight gradients and never does (round 6: with
+        # the hint on every GEMM the c3 step took 0.5790 ms against 0.5580 without, with it on these 0.5562).
+        self.wide_gemm = True
         self._gslot = None
         self._res = self._next_res = None
         self._tapes = {}
@@ -1202,7 +1208,7 @@ class TrainEngine:
         for i, (l, act) in enumerate(self.top):
             y = buf["top_y"][i]
             if not (fused_head and i == len(self.top) - 1):
-                ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
+                ops.linear_fwd(cur, self.W[l], l.bias.data, y, act, alone=self.wide_gemm)
             top_acts.append(y)
             cur = y
         Z = cur
@@ -1253,7 +1259,7 @@ class TrainEngine:
                 # a 6-8 us bubble on the training queue
                 ops.event_attach_next(ev["top_dz"], main)
             ops.linear_bwd(top_acts[i], self.W[l], top_acts[i + 1], dY, dX, None, None, act,
-                           buf["lin_work"], x_act=(self.top[i - 1][1] if i > 0 else 0))
+                           buf["lin_work"], x_act=(self.top[i - 1][1] if i > 0 else 0), alone=self.wide_gemm)
             dY = dX
         def top_wgrad(after):
             # Every top-layer dZ is final: the top MLP's weight gradients run on their own stream, beside the bottom MLP's
@@ -1414,7 +1420,7 @@ class TrainEngine:
         cur = R
         for i, (l, act) in enumerate(self.top):
             y = buf["top_y"][i]
-            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
+            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act, alone=self.wide_gemm)
             cur = y
         if self.loss_threshold > 0.0:       # DLRM_Net.forward returns the clamped prediction (model_no_ddp.py:311-314)
             cur = torch.clamp(cur, min=self.loss_threshold, max=1.0 - self.loss_threshold)
@@ -1461,7 +1467,7 @@ class TrainEngine:
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
                self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.top_wgrad_after,
-               self.fuse_gather, self.sort_after_fwd,
+               self.fuse_gather, self.sort_after_fwd, self.wide_gemm,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)

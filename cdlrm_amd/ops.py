@@ -446,12 +446,17 @@ def gather_interact_bwd(ctx: CacheCtx, slots: torch.Tensor, x: torch.Tensor, dR:
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 
 
-def linear_fwd(X: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], Y: torch.Tensor, act: int, stream=None):
+GEMM_ALONE = 0x100        # include/cdlrm_hip.h: CDLRM_GEMM_ALONE
+
+
+def linear_fwd(X: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], Y: torch.Tensor, act: int, stream=None,
+               alone: bool = False):
+    """alone: no other GEMM runs beside this launch (scheduling hint, CDLRM_GEMM_ALONE)."""
     M, K = X.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.is_contiguous() and X.stride(1) == 1 and Y.stride(1) == 1
     check(_lib.lib().cdlrm_linear_fwd(X.data_ptr(), X.stride(0), W.data_ptr(), ptr(b), Y.data_ptr(), Y.stride(0), M, N,
-                                      K, act, stream_ptr(stream)))
+                                      K, act | (GEMM_ALONE if alone else 0), stream_ptr(stream)))
 
 
 def linear_bwd_work(M: int, N: int, K: int, device) -> torch.Tensor:
@@ -459,14 +464,14 @@ def linear_bwd_work(M: int, N: int, K: int, device) -> torch.Tensor:
     return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
 
 
-def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=None, x_act: int = 0):
+def linear_bwd(X, W, Y, dY, dX, dW, db, act: int, work: torch.Tensor, stream=None, x_act: int = 0, alone: bool = False):
     """act: this layer's activation, applied backward to dY in place (0: dY already is the pre-activation
     gradient).  x_act: the activation that produced X; dX then leaves as the layer below's pre-activation gradient."""
     M, K = X.shape
     N = W.shape[0]
     check(_lib.lib().cdlrm_linear_bwd(X.data_ptr(), X.stride(0), W.data_ptr(), ptr(Y), 0 if Y is None else Y.stride(0),
                                       dY.data_ptr(), dY.stride(0), ptr(dX), 0 if dX is None else dX.stride(0),
-                                      ptr(dW), ptr(db), M, N, K, act, int(x_act), work.data_ptr(),
+                                      ptr(dW), ptr(db), M, N, K, act | (GEMM_ALONE if alone else 0), int(x_act), work.data_ptr(),
                                       stream_ptr(stream)))
 
 

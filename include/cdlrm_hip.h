@@ -365,6 +365,11 @@ int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, c
                               void* stream);
 /* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
  * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */
+/* CDLRM_GEMM_ALONE, or-ed into `act` of cdlrm_linear_fwd / cdlrm_linear_bwd: the caller's promise that no other GEMM runs beside
+ * this launch (the training step's top-MLP forward and dgrad chain).  A scheduling hint: long batches whose 128x128 tiles fill
+ * the chip then take the one-workgroup-per-CU kernel (csrc/gemm_wide.h), which must not share its CU.  Same fp32 fma arithmetic;
+ * the contraction order inside a 16-deep group differs from the default kernel's, so results may differ in the last bits. */
+#define CDLRM_GEMM_ALONE 0x100
 int cdlrm_linear_fwd(const float* X, int64_t ld_x, const float* W, const float* bias, float* Y,
                      int64_t ld_y, int64_t M, int32_t N, int32_t K, int32_t act, void* stream);
 /* Backward of the same layer.  act != 0: dY is the gradient w.r.t. the layer's OUTPUT and is overwritten

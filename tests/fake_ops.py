@@ -208,7 +208,7 @@ def interact_bwd(feat, dR, itself, dfeat, stream=None, x_act=0):
     dfeat.copy_(g)
 
 
-def linear_fwd(X, W, b, Y, act, stream=None):
+def linear_fwd(X, W, b, Y, act, stream=None, alone=False):
     y = torch.nn.functional.linear(X, W, b)
     Y.copy_(torch.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y)
 
@@ -217,7 +217,7 @@ def linear_bwd_work(M, N, K, device):
     return torch.empty(1)
 
 
-def linear_bwd(X, W, Y, dY, dX, dW, db, act, work, stream=None, x_act=0):
+def linear_bwd(X, W, Y, dY, dX, dW, db, act, work, stream=None, x_act=0, alone=False):
     if act == 1:
         dY.copy_(dY * (Y > 0))
     elif act == 2:

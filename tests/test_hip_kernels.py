@@ -435,16 +435,28 @@ def test_dense_golden(ops, golden, itself):
                                        # long batches on 16-byte-loadable layers: the LDS-DMA kernel (gemm_glds.h), 128x64 and
                                        # 64x64 tiles, partial tiles in both directions, K = 96 (3 K tiles), sigmoid epilogue
                                        (8192, 512, 512, 1), (8192, 256, 512, 1), (8192, 128, 256, 1), (6400, 512, 480, 2),
-                                       (8256, 264, 96, 0), (8200, 264, 64, 1)])
+                                       (8256, 264, 96, 0), (8200, 264, 64, 1),
+                                       # the wide kernel (gemm_wide.h: one workgroup per CU on 128x128 tiles, taken where they fill
+                                       # the chip): forward N = 512 with K = 480 (15 K tiles, sigmoid) and its dgrad onto 480
+                                       # columns (edge tiles in N, the generic epilogue); K = 256 / 64 (ring run-out: 8 and 2 K
+                                       # tiles); a partial last row panel (16300 = 127 * 128 + 44: clamped source rows)
+                                       (8192, 512, 480, 2), (8192, 512, 256, 0), (16384, 512, 64, 1), (16300, 512, 96, 1)])
 def test_linear_vs_torch_fp32(ops, M, N, K, act):
-    """FP32-MFMA Linear fwd/bwd against a plain torch fp32 reference (CPU, float64 accumulate for the bound)."""
+    """FP32-MFMA Linear fwd/bwd against a plain torch fp32 reference (CPU, float64 accumulate for the bound).  Long batches run
+    a second time with the caller's CDLRM_GEMM_ALONE hint, which routes eligible shapes to the wide kernel."""
+    _linear_vs_torch_fp32(ops, M, N, K, act, False)
+    if M >= 8192:
+        _linear_vs_torch_fp32(ops, M, N, K, act, True)
+
+
+def _linear_vs_torch_fp32(ops, M, N, K, act, alone):
     rng = np.random.RandomState(M + N + K)
     X = torch.from_numpy(rng.randn(M, K).astype(np.float32))
     W = torch.from_numpy((rng.randn(N, K) / np.sqrt(K)).astype(np.float32))
     b = torch.from_numpy(rng.randn(N).astype(np.float32))
     Xd, Wd, bd = X.to(DEV), W.to(DEV), b.to(DEV)
     Y = torch.empty(M, N, device=DEV)
-    ops.linear_fwd(Xd, Wd, bd, Y, act)
+    ops.linear_fwd(Xd, Wd, bd, Y, act, alone=alone)
     pre = X.double() @ W.double().t() + b.double()
     ref = {0: pre, 1: torch.relu(pre), 2: torch.sigmoid(pre)}[act]
     np.testing.assert_allclose(Y.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
@@ -452,7 +464,7 @@ def test_linear_vs_torch_fp32(ops, M, N, K, act):
     dYd = dY.clone().to(DEV)
     dX, dW, db = torch.empty(M, K, device=DEV), torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
     work = ops.linear_bwd_work(M, N, K, DEV)
-    ops.linear_bwd(Xd, Wd, Y, dYd, dX, dW, db, act, work)
+    ops.linear_bwd(Xd, Wd, Y, dYd, dX, dW, db, act, work, alone=alone)
     Yc = Y.cpu().double()
     dZ = {0: dY.double(), 1: dY.double() * (Yc > 0), 2: dY.double() * Yc * (1 - Yc)}[act]
     scale = float(np.sqrt(M))

@@ -460,3 +460,19 @@ def test_roofline_kernel_choice_and_bytes():
     # rows + slot ids, the dense feature, the 479-wide interaction row on its 480-float pitch
     assert survey == 221511680 and own == 8192 * 26 * 516 + 8192 * 512 + 8192 * 480 * 4 == 129826816
     assert rk.bytes_per_launch("fused", 65536, 26, 128)[1] == 1038614528
+
+
+def test_asm_mfma_hazards_in_built_library():
+    """k_gemm3's MFMAs are asm statements the compiler's hazard recognizer does not see (cdlrm_amd/csrc/gemm_wide.h): the built
+    code object must not touch an accumulator within the MFMA's write-back window (tools/mfma_hazard_check.py; the first
+    version of the kernel failed exactly this way -- accumulator copies 8 wait states behind the MFMA)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "cdlrm_amd", "csrc", "libcdlrm_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_check.py"), so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "k_gemm3" in r.stdout and "0 finding(s)" in r.stdout
