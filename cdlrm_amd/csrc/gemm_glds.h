@@ -490,15 +490,17 @@ static void launch_gemm2(const GemmArgs& g, int tm, int tn, int splits, hipStrea
 
 // the wide kernel (gemm_wide.h: k_gemm3, one workgroup per CU on 128x128 tiles) takes the un-split forward / dgrad GEMMs whose
 // tiles fill the chip; defined in gemm_wide.h, which a translation unit that calls launch_gemm includes instead of this file
-template <bool B_KC>
+template <bool A_KC, bool B_KC>
 static bool gemm3_try(const GemmArgs& g, int splits, hipStream_t s);
 
 template <bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs g, int splits, hipStream_t s) {
     if (g.K < 4) g.vecA = g.vecB = 0;
-    if (A_KC && gemm3_try<B_KC>(g, splits, s)) {
-        CDLRM_LAUNCH_CHECK();
-        return 0;
+    if constexpr (A_KC || !B_KC) {
+        if (gemm3_try<A_KC, B_KC>(g, splits, s)) {
+            CDLRM_LAUNCH_CHECK();
+            return 0;
+        }
     }
     // (long batches with a narrow output -- the 256 -> 128 layer at M = 8192, forward: 256 tiles of 64x64, and its weight
     //  gradient: 8 tiles x 32 slabs of the batch -- are better off on the LDS-DMA kernel's 64x64 tile than on the LDS-free

@@ -10,8 +10,9 @@
 // tiles with 2-4x the MFMAs per barrier.  Here a wave issues 128 MFMAs (4096 cycles) per barrier at IM = JN = 4, every LDS
 // read and every DMA piece sits in the shadow of an MFMA (one per MFMA slot), and the ring keeps two K tiles in flight.
 //
-//   C[m,n] = sum_k A(m,k) * B(k,n);  A(m,k) = A[m*lda + k] (contraction contiguous: forward and dgrad layouts)
-//   B_KC: B(k,n) = B[n*ldb + k] (forward: weights [N, K])   else B[k*ldb + n] (dgrad: weights [K, N])
+//   C[m,n] = sum_k A(m,k) * B(k,n)
+//   A_KC: A(m,k) = A[m*lda + k] (forward and dgrad)         else A[k*lda + m] (weight gradient: A = dZ^T, split over the batch)
+//   B_KC: B(k,n) = B[n*ldb + k] (forward: weights [N, K])   else B[k*ldb + n] (dgrad: weights [K, N]; weight gradient: X)
 //
 // Contraction order inside a 16-deep group differs from k_gemm2's (lane quarter kq of a 16x16x4 MFMA holds k = 4*kq + c of
 // MFMA c: 0,4,8,12, 1,5,9,13, ...), so results differ from the 32x32x2 kernels in the last bits (both are exact fp32 fma
@@ -112,13 +113,14 @@ __device__ unsigned long long g3_stamps[8 * 4096];
 #define G3_STAMP_AT(slot)
 #endif
 
-template <bool B_KC, int IM, int JN, int NS>
+template <bool A_KC, bool B_KC, int IM, int JN, int NS>
 __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
     constexpr int BM = 32 * IM, BN = 32 * JN;
     constexpr int A_ST = BM * G3_BK, B_ST = BN * G3_BK, STAGE = A_ST + B_ST;       // floats
-    constexpr int NPA = G3Stage<true, BM>::NP, NPB = G3Stage<B_KC, BN>::NP, NPW = NPA + NPB;
+    constexpr int NPA = G3Stage<A_KC, BM>::NP, NPB = G3Stage<B_KC, BN>::NP, NPW = NPA + NPB;
     constexpr int MG = 4 * IM * JN;                    // MFMAs per 16-deep group and wave
-    constexpr int NRD = IM + (B_KC ? JN : 4 * JN);      // LDS read instructions per group and wave
+    constexpr int NRA = A_KC ? IM : 4 * IM;             // LDS read instructions per group and wave: A fragments ...
+    constexpr int NRD = NRA + (B_KC ? JN : 4 * JN);     // ... and all
     static_assert(NS >= 3 && NS <= 4 && NS * STAGE * 4 <= 160 * 1024, "ring does not fit");
     static_assert(NRD + 4 * NPW <= MG && NRD + 16 <= MG, "schedule does not fit the group");
     // ONE LDS object (a second one beside an LDS-DMA staging array makes hipcc wait vmcnt(0) before every fragment read)
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    G3Stage<true, BM> sa;
+    G3Stage<A_KC, BM> sa;
     G3Stage<B_KC, BN> sb;
     sa.init(g.A, g.lda, m0, g.M, kbeg);
     sb.init(g.B, g.ldb, n0, g.N, kbeg);
@@ -157,9 +159,14 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 
     // per-lane fragment addresses (floats from the start of a stage), see the header comment
     const int sw = lr >> 1;
-    const int fa0 = (wm * 16 * IM + lr) * G3_BK + 4 * (kq ^ sw);
-    const int fa1 = (wm * 16 * IM + lr) * G3_BK + 4 * ((4 + kq) ^ sw);
-    int fb0, fb1;
+    int fa0, fa1, fb0, fb1;
+    if (A_KC) {
+        fa0 = (wm * 16 * IM + lr) * G3_BK + 4 * (kq ^ sw);
+        fa1 = (wm * 16 * IM + lr) * G3_BK + 4 * ((4 + kq) ^ sw);
+    } else {
+        fa0 = 4 * kq * BM + wm * 16 * IM + lr + 16 * (kq & 1);               // even blocks
+        fa1 = 4 * kq * BM + wm * 16 * IM + lr - 16 * (kq & 1);               // odd blocks
+    }
     if (B_KC) {
         fb0 = A_ST + (wn * 16 * JN + lr) * G3_BK + 4 * (kq ^ sw);
         fb1 = A_ST + (wn * 16 * JN + lr) * G3_BK + 4 * ((4 + kq) ^ sw);
@@ -168,24 +175,49 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
         fb1 = A_ST + 4 * kq * BN + wn * 16 * JN + lr - 16 * (kq & 1);        // odd blocks
     }
 
-    float4 fa[2][IM], fb[2][JN];
+    // fragment registers: a contraction-contiguous operand's fragment is one ds_read_b128 (float4: the four MFMAs of a group
+    // take its components), a contraction-strided one's four ds_read_b32 into four scalars (as components of a float4 every
+    // read would redefine the whole vector for the register allocator: copies and spills in the MFMA stream)
+    float4 fa4[2][A_KC ? IM : 1], fb4[2][B_KC ? JN : 1];
+    float fas[2][A_KC ? 1 : IM][4], fbs[2][B_KC ? 1 : JN][4];
     // read instruction q (0 .. NRD-1) of group gsel of the stage whose per-lane addresses are pa / pb into buffer `buf`
     auto rd = [&](const float* pa0, const float* pa1, const float* pb0, const float* pb1, int gsel, int buf, int q) {
-        if (q < IM) {
-            fa[buf][q] = *reinterpret_cast<const float4*>((gsel ? pa1 : pa0) + q * 16 * G3_BK);
-        } else if (B_KC) {
-            const int j = q - IM;
-            fb[buf][j] = *reinterpret_cast<const float4*>((gsel ? pb1 : pb0) + j * 16 * G3_BK);
+        if (q < NRA) {
+            if constexpr (A_KC) {
+                fa4[buf][q] = *reinterpret_cast<const float4*>((gsel ? pa1 : pa0) + q * 16 * G3_BK);
+            } else {
+                const int i = q >> 2, c = q & 3;
+                fas[buf][i][c] = ((i & 1) ? pa1 : pa0)[(16 * gsel + c) * BM + 16 * i];
+            }
+        } else if constexpr (B_KC) {
+            const int j = q - NRA;
+            fb4[buf][j] = *reinterpret_cast<const float4*>((gsel ? pb1 : pb0) + j * 16 * G3_BK);
         } else {
-            const int j = (q - IM) >> 2, c = (q - IM) & 3;
-            const float v = ((j & 1) ? pb1 : pb0)[(16 * gsel + c) * BN + 16 * j];
-            if (c == 0) fb[buf][j].x = v;
-            else if (c == 1) fb[buf][j].y = v;
-            else if (c == 2) fb[buf][j].z = v;
-            else fb[buf][j].w = v;
+            const int j = (q - NRA) >> 2, c = (q - NRA) & 3;
+            fbs[buf][j][c] = ((j & 1) ? pb1 : pb0)[(16 * gsel + c) * BN + 16 * j];
         }
     };
-    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+    auto comp4 = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+    auto afrag = [&](int buf, int i, int c) -> float {
+        if constexpr (A_KC) return comp4(fa4[buf][i], c);
+        else return fas[buf][i][c];
+    };
+    auto bfrag = [&](int buf, int j, int c) -> float {
+        if constexpr (B_KC) return comp4(fb4[buf][j], c);
+        else return fbs[buf][j][c];
+    };
+    // bias gradient fused into the weight-gradient GEMM (A = dZ^T, contraction-strided): the waves of the first column panel
+    // add up the A fragments they read anyway (VALU under the MFMAs); lane (lr, kq) collects its row's sum over the contraction
+    // indices of its quarter, the four quarters are added in a fixed order behind the loop
+    const bool do_colsum = !A_KC && g.colsum != nullptr && bx == 0 && __builtin_amdgcn_readfirstlane(wn) == 0;     // scalar condition
+    float csum[IM];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) csum[i] = 0.f;
+    auto colsum_add = [&](int buf, int i) {
+        if constexpr (!A_KC) {
+            if (do_colsum) csum[i] += (fas[buf][i][0] + fas[buf][i][1]) + (fas[buf][i][2] + fas[buf][i][3]);
+        }
+    };
     auto dma_piece = [&](int p, int stage) {
         if (p < NPA) sa.piece(p, a_dst + stage * (STAGE * 4u));
         else sb.piece(p - NPA, b_dst + stage * (STAGE * 4u));
@@ -286,8 +318,9 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 #pragma unroll
         for (int m = 0; m < MG; ++m) {
             const int c = m / (IM * JN), blk = m % (IM * JN), i = blk / JN, j = blk % JN;
-            if (EDGE && m < IM * JN) g3_mfma_first(acc[i][j], comp(fb[0][j], c), comp(fa[0][i], c));
-            else g3_mfma(acc[i][j], comp(fb[0][j], c), comp(fa[0][i], c));
+            if (EDGE && m < IM * JN) g3_mfma_first(acc[i][j], bfrag(0, j, c), afrag(0, i, c));
+            else g3_mfma(acc[i][j], bfrag(0, j, c), afrag(0, i, c));
+            if (m >= MG - IM) colsum_add(0, m - (MG - IM));
             if (m < NRD) rd(pa0, pa1, pb0, pb1, 1, 1, m);
             if (!(G3_ABL & 1) && m >= NRD && (m - NRD) % 4 == 0 && (m - NRD) / 4 < NPW) {
                 if (issue) dma_piece((m - NRD) / 4, nxt);
@@ -311,8 +344,9 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (EDGE && m == MG - 1) g3_mfma_last(acc[i][j], comp(fb[1][j], c), comp(fa[1][i], c));
-            else g3_mfma(acc[i][j], comp(fb[1][j], c), comp(fa[1][i], c));
+            if (EDGE && m == MG - 1) g3_mfma_last(acc[i][j], bfrag(1, j, c), afrag(1, i, c));
+            else g3_mfma(acc[i][j], bfrag(1, j, c), afrag(1, i, c));
+            if (m < IM) colsum_add(1, m);
             if (m >= MB && m - MB < NRD) rd(qa0, qa1, qb0, qb1, 0, 0, m - MB);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -326,9 +360,10 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 #pragma unroll
         for (int m = 0; m < MG; ++m) {
             const int c = m / (IM * JN), blk = m % (IM * JN), i = blk / JN, j = blk % JN;
-            if (m < IM * JN) g3_mfma_first(acc[i][j], comp(fb[0][j], c), comp(fa[0][i], c));
-            else if (PROG && m == MG - 1) g3_mfma_last(acc[i][j], comp(fb[0][j], c), comp(fa[0][i], c));
-            else g3_mfma(acc[i][j], comp(fb[0][j], c), comp(fa[0][i], c));
+            if (m < IM * JN) g3_mfma_first(acc[i][j], bfrag(0, j, c), afrag(0, i, c));
+            else if (PROG && m == MG - 1) g3_mfma_last(acc[i][j], bfrag(0, j, c), afrag(0, i, c));
+            else g3_mfma(acc[i][j], bfrag(0, j, c), afrag(0, i, c));
+            if (m >= MG - IM) colsum_add(0, m - (MG - IM));
             if (m < NRD) rd(pa0, pa1, pb0, pb1, 1, 1, m);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -342,7 +377,8 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const int c = s8 >> 1, blk = 2 * p + (s8 & 1), i = blk / JN, j = blk % JN;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(fb[1][j], c), comp(fa[1][i], c), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfrag(1, j, c), afrag(1, i, c), acc[i][j], 0, 0, 0);
+                    if (p == 0 && s8 < IM) colsum_add(1, s8);
                     if (p > 0 && s8 == 2) epi_block((2 * p - 2) / JN, (2 * p - 2) % JN);
                     if (p > 0 && s8 == 5) epi_block((2 * p - 1) / JN, (2 * p - 1) % JN);
                     __builtin_amdgcn_sched_barrier(0);
@@ -354,8 +390,9 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 #pragma unroll
             for (int m = 0; m < MG; ++m) {
                 const int c = m / (IM * JN), blk = m % (IM * JN), i = blk / JN, j = blk % JN;
-                if (m == MG - 1) g3_mfma_last(acc[i][j], comp(fb[1][j], c), comp(fa[1][i], c));
-                else g3_mfma(acc[i][j], comp(fb[1][j], c), comp(fa[1][i], c));
+                if (m == MG - 1) g3_mfma_last(acc[i][j], bfrag(1, j, c), afrag(1, i, c));
+                else g3_mfma(acc[i][j], bfrag(1, j, c), afrag(1, i, c));
+                if (m < IM) colsum_add(1, m);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -377,6 +414,17 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
     if (fast) last_tile(std::integral_constant<bool, true>{}, cur);
     else last_tile(std::integral_constant<bool, false>{}, cur);
     G3_STAMP_AT(2)
+    if (!A_KC && g.colsum != nullptr && bx == 0 && wn == 0) {
+        // the four lane quarters of a wave hold four quarters of the contraction range: add them in a fixed order
+#pragma unroll
+        for (int i = 0; i < IM; ++i) {
+            const float q1 = __shfl(csum[i], lr + 16, 64), q2 = __shfl(csum[i], lr + 32, 64), q3 = __shfl(csum[i], lr + 48, 64);
+            const float q0 = __shfl(csum[i], lr, 64);
+            const float sum = (q0 + q1) + (q2 + q3);
+            const int64_t row = m0 + wm * 16 * IM + 16 * i + lr;
+            if (kq == 0 && row < g.M) g.colsum[(int64_t)bz * g.M + row] = sum;
+        }
+    }
     if (!fast) {
         // edge tiles and unaligned operands: the generic form behind the loop (same values)
 #pragma unroll
@@ -418,26 +466,27 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 }
 
 // what k_gemm3 can take: A contraction-contiguous, 16-byte loadable rows, every split's contraction range a multiple of 32
-template <bool B_KC>
+template <bool A_KC, bool B_KC>
 static inline bool gemm3_applies(const GemmArgs& g) {
     if (!g.vecA || !g.vecB) return false;
+    if (!A_KC && g.M < 4) return false;
     const int64_t kc = g.kchunk < g.K ? g.kchunk : g.K;
     if (g.K < G3_BK || g.K % G3_BK != 0 || kc % G3_BK != 0) return false;
     if (g.N < 4 || g.N % 4 != 0 || g.ldc % 4 != 0 || g.slab % 4 != 0 || (((uintptr_t)g.C) & 15) != 0) return false;
-    if (g.colsum != nullptr) return false;
+    if (A_KC && g.colsum != nullptr) return false;
     return true;
 }
 
-template <bool B_KC, int IM, int JN, int NS>
+template <bool A_KC, bool B_KC, int IM, int JN, int NS>
 static void launch_gemm3(const GemmArgs& g, int splits, hipStream_t s) {
     dim3 grid((unsigned)cdiv(g.N, 32 * JN), (unsigned)cdiv(g.M, 32 * IM), (unsigned)splits);
-    CDLRM_LAUNCH_EV((k_gemm3<B_KC, IM, JN, NS>), grid, dim3(256), 0, s, g);
+    CDLRM_LAUNCH_EV((k_gemm3<A_KC, B_KC, IM, JN, NS>), grid, dim3(256), 0, s, g);
 }
 
 // launch_gemm's hook (gemm_glds.h).  Taken where the 128x128 tiles fill whole rounds of one workgroup per CU (>= 90 % of the
 // slots of the last round too: c3's 512-wide layers at M = 8192 are exactly 256 tiles, c5's 2048 and 1024) -- measured against
 // k_gemm2 on one box (tools/gemm3_bench.hip, profiles/r06_gemm3_vs_gemm2.txt).
-template <bool B_KC>
+template <bool A_KC, bool B_KC>
 static bool gemm3_try(const GemmArgs& g, int splits, hipStream_t s) {
     // Only for launches the caller marks as running ALONE (CDLRM_GEMM_ALONE: the top MLP's forward and its dgrad chain in the
     // training step).  Beside the weight-gradient GEMMs of the side queues a workgroup of this kernel (96 KB of LDS, 340
@@ -445,8 +494,13 @@ static bool gemm3_try(const GemmArgs& g, int splits, hipStream_t s) {
     // k_gemm2's 1024 small workgroups, the c3 step 0.5790 against 0.5580 ms (profiles/r06_ab_gemm3_in_step.txt).
     // cdlrm_debug_set(6, 32): never; (6, 256): every eligible launch (the stand-alone benches).
     if (g_cdlrm_debug[6] & 32) return false;
-    if (!g.alone && !(g_cdlrm_debug[6] & 256)) return false;
-    if (splits != 1 || g.K < 2 * G3_BK || !gemm3_applies<B_KC>(g)) return false;
+    if (!A_KC && (g_cdlrm_debug[6] & 512)) {
+        // (A/B: the split-M weight gradients on this kernel)
+    } else if (!A_KC && (g_cdlrm_debug[6] & 1024) && (int64_t)g.M * g.N >= 512 * 480) {
+        // (A/B: the two 512-wide ones only)
+    } else if (!g.alone && !(g_cdlrm_debug[6] & 256)) return false;
+    const int64_t kc = g.kchunk < g.K ? g.kchunk : g.K;
+    if ((A_KC && splits != 1) || kc < 2 * G3_BK || !gemm3_applies<A_KC, B_KC>(g)) return false;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -454,9 +508,9 @@ static bool gemm3_try(const GemmArgs& g, int splits, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int64_t tiles = cdiv(g.M, 128) * cdiv(g.N, 128);
+    const int64_t tiles = cdiv(g.M, 128) * cdiv(g.N, 128) * splits;
     const int64_t rounds = cdiv(tiles, n_cu);
     if (tiles * 10 < rounds * n_cu * 9) return false;
-    launch_gemm3<B_KC, 4, 4, 3>(g, 1, s);
+    launch_gemm3<A_KC, B_KC, 4, 4, 3>(g, splits, s);
     return true;
 }

@@ -676,6 +676,40 @@ def test_mlp_wgrad_group(ops, M):
                                        atol=1e-5 * scale)
 
 
+def test_wide_gemm_weight_gradient_layout(ops):
+    """The wide kernel's third layout (gemm_wide.h: A = dZ^T and B = X both contraction-strided, split over the batch, bias
+    gradient fused): not taken by the training step (beside the other queues' GEMMs it loses, profiles/r06_ab_gemm3_in_step.txt),
+    reachable through the development selector cdlrm_debug_set(6, 512) -- same answers as the default path, against fp64."""
+    from cdlrm_amd import _lib
+    M = 8192
+    rng = np.random.RandomState(7)
+    shapes = [(512, 512), (512, 480), (256, 512)]
+    Xs, dZs, dWs, dbs = [], [], [], []
+    for N, K in shapes:
+        Xs.append(torch.from_numpy(rng.randn(M, K).astype(np.float32)).to(DEV))
+        dZs.append(torch.from_numpy(rng.randn(M, N).astype(np.float32)).to(DEV))
+        dWs.append(torch.empty(N, K, device=DEV))
+        dbs.append(torch.empty(N, device=DEV))
+    plan = ops.WgradPlan(Xs, dZs, dWs, dbs, ops.mlp_wgrad_work(M, [s[0] for s in shapes], [s[1] for s in shapes], DEV))
+    torch.cuda.synchronize()
+    assert _lib.raw().cdlrm_debug_set(6, 512) == 0
+    try:
+        ops.mlp_wgrad(plan)
+        torch.cuda.synchronize()
+    finally:
+        assert _lib.raw().cdlrm_debug_set(6, 0) == 0
+    scale = float(np.sqrt(M))
+    for X, dZ, dW, db in zip(Xs, dZs, dWs, dbs):
+        ref = dZ.cpu().double().t() @ X.cpu().double()
+        np.testing.assert_allclose(dW.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(db.cpu().numpy(), dZ.cpu().double().sum(0).float().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    first = [w.clone() for w in dWs]
+    ops.mlp_wgrad(plan)                 # the default kernel on the same inputs: equal to rounding
+    torch.cuda.synchronize()
+    for a, b in zip(first, dWs):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
 @pytest.mark.parametrize("M", [64, 1000, 2048, 4100, 8192, 16500])
 def test_mlp_wgrad_with_fused_sgd_step(ops, M):
     """cdlrm_mlp_wgrad_sgd: the dense SGD step inside the weight-gradient launches (slab reduction; elementwise pass for

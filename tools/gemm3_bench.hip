@@ -117,11 +117,65 @@ static void run(const char* name, int64_t M, int N, int64_t K) {
     };
     one("gemm2 128x64", [&]() { launch2<true, B_KC, 2, 1>(g1); }, 0);
     one("gemm2 128x128", [&]() { launch2<true, B_KC, 2, 2>(g1); }, 0);
-    one("gemm3 128x128 S3", [&]() { launch_gemm3<B_KC, 4, 4, 3>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 128)));
-    one("gemm3 128x128 S4", [&]() { launch_gemm3<B_KC, 4, 4, 4>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 128)));
+    one("gemm3 128x128 S3", [&]() { launch_gemm3<true, B_KC, 4, 4, 3>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 128)));
+    one("gemm3 128x128 S4", [&]() { launch_gemm3<true, B_KC, 4, 4, 4>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 128)));
     hipFree(A); hipFree(B); hipFree(bias); hipFree(mask); hipFree(C0); hipFree(C1);
 }
+// weight-gradient layout: dW[N, K] = dZ[M, N]^T X[M, K], split over the batch into `splits` slabs (+ the bias gradient's partials)
+static void run_wgrad(const char* name, int64_t M, int N, int K, int splits) {
+    std::vector<float> hZ = host_rand((size_t)M * N, 5), hX = host_rand((size_t)M * K, 6);
+    float *dZ = to_dev(hZ), *X = to_dev(hX);
+    const size_t cnt = (size_t)N * K;
+    float *S0, *S1, *c0, *c1;
+    hipMalloc(&S0, cnt * splits * 4); hipMalloc(&S1, cnt * splits * 4); hipMalloc(&c0, (size_t)splits * N * 4); hipMalloc(&c1, (size_t)splits * N * 4);
+    GemmArgs g = gemm_args();
+    g.A = dZ; g.lda = N; g.B = X; g.ldb = K; g.ldc = K; g.slab = (int64_t)cnt; g.M = N; g.N = K; g.K = M;
+    g.kchunk = cdiv(cdiv(M, splits), 32) * 32; g.vecA = g.vecB = 1;
+    const int zs = (int)cdiv(M, g.kchunk);
+    GemmArgs g0 = g, g1 = g; g0.C = S0; g0.colsum = c0; g1.C = S1; g1.colsum = c1;
+    auto l2 = [&](const GemmArgs& a) {
+        dim3 grid((unsigned)cdiv(a.N, 64), (unsigned)cdiv(a.M, 128), (unsigned)zs);
+        hipLaunchKernelGGL((k_gemm2<false, false, 2, 1>), grid, dim3(256), 0, 0, a);
+    };
+    auto l3 = [&](const GemmArgs& a) { launch_gemm3<false, false, 4, 4, 3>(a, zs, 0); };
+    l2(g0); hipMemset(S1, 0xff, cnt * zs * 4); hipMemset(c1, 0xff, (size_t)zs * N * 4); l3(g1); hipDeviceSynchronize();
+    std::vector<float> h0(cnt * zs), h1(cnt * zs), k0((size_t)zs * N), k1((size_t)zs * N);
+    hipMemcpy(h0.data(), S0, h0.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), S1, h1.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(k0.data(), c0, k0.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(k1.data(), c1, k1.size() * 4, hipMemcpyDeviceToHost);
+    double maxrel = 0, maxcs = 0;
+    for (size_t i = 0; i < h0.size(); ++i) maxrel = std::max(maxrel, fabs((double)h0[i] - h1[i]) / std::max(1.0, fabs((double)h0[i])));
+    for (size_t i = 0; i < k0.size(); ++i) maxcs = std::max(maxcs, fabs((double)k0[i] - k1[i]) / std::max(1.0, fabs((double)k0[i])));
+    // fp64 on sampled elements of the summed slabs
+    double max64 = 0; unsigned s = 7;
+    for (int q = 0; q < 500; ++q) {
+        s = s * 1664525u + 1013904223u; const int n = (s >> 4) % N;
+        s = s * 1664525u + 1013904223u; const int k = (s >> 4) % K;
+        double ref = 0, got = 0;
+        for (int64_t m = 0; m < M; ++m) ref += (double)hZ[m * N + n] * (double)hX[m * K + k];
+        for (int z = 0; z < zs; ++z) got += h1[(size_t)z * cnt + (size_t)n * K + k];
+        max64 = std::max(max64, fabs(ref - got) / std::max(1.0, fabs(ref)));
+    }
+    std::vector<double> t2, t3;
+    for (int r = 0; r < 5; ++r) { t2.push_back(time_us([&]() { l2(g0); }, 30)); t3.push_back(time_us([&]() { l3(g1); }, 30)); }
+    std::sort(t2.begin(), t2.end()); std::sort(t3.begin(), t3.end());
+    const double fl = 2.0 * M * N * K;
+    printf("%-20s M=%6lld N=%4d K=%4d splits %3d  gemm2 128x64 %7.1f us %6.1f TF/s | gemm3 %7.1f us %6.1f TF/s  slabs rel %.2e  colsum rel %.2e  fp64 rel %.2e\n",
+           name, (long long)M, N, K, zs, t2[2], fl / t2[2] / 1e6, t3[2], fl / t3[2] / 1e6, maxrel, maxcs, max64);
+#ifdef G3_STAMP
+    l3(g1); hipDeviceSynchronize(); stamp_report("wgrad gemm3", (unsigned)(cdiv(N, 128) * cdiv(K, 128) * zs));
+#endif
+    fflush(stdout);
+    hipFree(dZ); hipFree(X); hipFree(S0); hipFree(S1); hipFree(c0); hipFree(c1);
+}
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'w') {
+        run_wgrad("wgrad 512x512", 8192, 512, 512, 16);
+        run_wgrad("wgrad 512x480", 8192, 512, 480, 16);
+        run_wgrad("wgrad 256x512", 8192, 256, 512, 32);
+        run_wgrad("wgrad 128x256", 8192, 128, 256, 128);
+        run_wgrad("wgrad 512x512", 65536, 512, 512, 16);
+        return 0;
+    }
     const bool quick = argc > 1;
     for (int64_t M : {(int64_t)8192, (int64_t)65536}) {
         run<true>("forward 512<-512", M, 512, 512);

@@ -71,6 +71,9 @@ def check_function(name, lines):
                 for r in dst:
                     pending[r] = WAIT
             continue
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            pending.clear()             # what follows in the text is not reached by falling through
+            continue
         if op == "s_nop":
             cost = int(ops[0], 0) + 1
         else:
