@@ -260,35 +260,24 @@ def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, s
                                 "by every rank") if world > 1 else "pinned allocations of this process",
         "pinned_staging_bytes_per_rank": staging, "hbm_bytes_per_rank": hbm, "notes": notes,
     }
-    limit = mem_limit
-    if limit is None:
-        try:
-            txt = open("/sys/fs/cgroup/memory.max").read().strip()
-            limit = int(txt) if txt.isdigit() else None
-        except OSError:
-            limit = None
+    from cdlrm_amd import hostmem
+    limit = mem_limit if mem_limit is not None else hostmem.memory_limit()
     out["host_memory_limit_bytes"] = limit
     refuse = []
     if world > 1:
-        from cdlrm_amd.hostmem import shared_table_dir, shared_table_dir_free
-        out["shared_table_dir"], out["shared_table_dir_free_bytes"] = shared_table_dir(), shared_table_dir_free()
+        out["shared_table_dir"], out["shared_table_dir_free_bytes"] = hostmem.shared_table_dir(), hostmem.shared_table_dir_free()
         if shm_free is None:
             shm_free = out["shared_table_dir_free_bytes"]
-        forced = os.environ.get("CDLRM_HOST_TABLES", "auto")
-        fits_shm = shm_free is None or shm_free >= host_tables + (1 << 30)
-        mode = forced if forced in ("shared", "replicas") else ("shared" if fits_shm else "replicas")
+        # ONE decision for the plan and the run: hostmem.host_tables_mode is what make_host_tables' rank 0 calls
+        mode, err = hostmem.host_tables_mode(host_tables, world, staging_bytes=staging, shm_free=shm_free, limit=limit)
         out["host_tables_mode"] = mode
-        if mode == "shared" and not fits_shm:
-            refuse.append("the shared host tables (%.0f GB) do not fit %s (%.0f GB free): CDLRM_SHM_DIR=<larger tmpfs>, "
-                          "CDLRM_HOST_TABLES=replicas, or --max-ind-range" % (host_tables / 1e9, out["shared_table_dir"], shm_free / 1e9))
+        if err:
+            refuse.append(err)
         if mode == "replicas":
             out["host_tables_mapping"] = ("a private pinned copy per rank, filled from the same seed; every rank applies the eviction "
                                           "write-backs to its own (identical on all ranks): %d x %.0f GB" % (world, host_tables / 1e9))
             notes.append("%s holds %.0f GB, the tables need %.0f: every rank pins its OWN copy (%d x %.0f GB of host memory)"
                          % (out["shared_table_dir"], (shm_free or 0) / 1e9, host_tables / 1e9, world, host_tables / 1e9))
-            if limit and world * (host_tables + staging) > 0.9 * limit:
-                refuse.append("%d private copies of the host tables (%.0f GB each) exceed 90 %% of the job's memory limit (%.0f GB)"
-                              % (world, host_tables / 1e9, limit / 1e9))
     if limit and host_tables > limit // 2 and os.environ.get("CDLRM_ALLOW_HUGE_HOST_TABLES") != "1":
         # (build_host_tables' own guard: c4 UNCAPPED, 192 GB pinned, has taken a one-GPU box of this pool down twice)
         refuse.append("host tables of %.0f GB are more than half of the job's memory limit (%.0f GB): --max-ind-range caps them"
@@ -336,8 +325,10 @@ def plan_only(a):
     res = rank_resources(a.config, a.gpus, lookahead=a.lookahead, batch=a.batch, max_ind_range=a.max_ind_range,
                          steps=a.steps, warmup=a.warmup, prewarm=a.prewarm_ms > 0)
     for r in range(a.gpus):
+        # (replicas: every rank applies the write-backs to its own copy of the host tables; shared / one rank: rank 0 does)
         print(json.dumps(dict(res, rank=r, hip_device=r, master_addr="127.0.0.1", master_port=port,
-                              writes_evictions_back=(r == 0), projection=projection_for(a.config, a.gpus))))
+                              writes_evictions_back=(r == 0 or res.get("host_tables_mode") == "replicas"),
+                              projection=projection_for(a.config, a.gpus))))
     if res["refused"]:
         print("bench.py --plan-only: REFUSED -- " + "; ".join(res["refused"]), file=sys.stderr)
         return 1
@@ -354,12 +345,8 @@ def build_host_tables(config, *, seed, dev, rank=0, world=1, barrier=None, max_i
     # (+ up to 30 GB of plan staging), c4 UNCAPPED pins 192 GB and has taken the whole machine down both times it was tried
     # (round 1 and round 4: the box was lost before the first step).  Refuse what exceeds half of the limit unless told otherwise.
     need = int(sum(config_tables(cfg, max_ind_range))) * cfg["D"] * 4
-    limit = None
-    try:
-        txt = open("/sys/fs/cgroup/memory.max").read().strip()
-        limit = int(txt) if txt.isdigit() else None
-    except OSError:
-        pass
+    from cdlrm_amd import hostmem
+    limit = hostmem.memory_limit()
     if limit and need > limit // 2 and os.environ.get("CDLRM_ALLOW_HUGE_HOST_TABLES") != "1":
         raise SystemExit("bench.py: config %s pins %.0f GB of host tables, more than half of this job's memory limit (%.0f GB): "
                          "use --max-ind-range to cap the tables (DESIGN.md section 7), or CDLRM_ALLOW_HUGE_HOST_TABLES=1"
@@ -793,7 +780,7 @@ def main():
         traffic = traffic_src = None
         def committed_pmc(cfg_id, alpha):
             t = "%s_a%s.json" % (cfg_id, ("%g" % alpha).replace(".", "p"))
-            for name in ("r05_gather_pmc_" + t, "r04_gather_pmc_" + t, "r03_gather_pmc_" + t, "r02_gather_pmc_" + t):
+            for name in ("r06_gather_pmc_" + t, "r05_gather_pmc_" + t, "r04_gather_pmc_" + t, "r03_gather_pmc_" + t, "r02_gather_pmc_" + t):
                 pp = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pp):
                     doc = json.load(open(pp))
@@ -829,9 +816,10 @@ def main():
         # row a-6 as a whole (per step: the gather, the take of the batch's slot ids / miss rows, and 1/16 of the look-ahead
         # chunk's resolve): from the committed kernel trace of this configuration (tools/a6_summary.py)
         a6 = None
-        a6_path = os.path.join(ROOT, "profiles", "r05_a6_whole_%s.json" % a.config)
-        if not os.path.exists(a6_path):
-            a6_path = os.path.join(ROOT, "profiles", "r04_a6_whole_%s.json" % a.config)
+        a6_path = os.path.join(ROOT, "profiles", "r06_a6_whole_%s.json" % a.config)
+        for older in ("r05", "r04"):
+            if not os.path.exists(a6_path):
+                a6_path = os.path.join(ROOT, "profiles", "%s_a6_whole_%s.json" % (older, a.config))
         if os.path.exists(a6_path) and a.batch <= 0 and a.max_ind_range <= 0 and a.alpha == 1.05:
             a6 = json.load(open(a6_path))
             a6["source"] = "profiles/" + os.path.basename(a6_path)
@@ -852,6 +840,23 @@ def main():
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "dist_backend": dist.get_backend() if dist.is_initialized() else "none (one process, no collectives)",
                        "final_loss": loss, "setup_s": round(setup_s, 1), "engine_attr": a.engine_attr or None,
+                       # development switches this run set inside the library (--debug; null: none).  The shipped library has no
+                       # switch that skips work (csrc/common.h); kernel-variant selectors are recorded here so that a line
+                       # measured with one is told apart from the default line
+                       "debug": a.debug or None,
+                       # how the window insert draws its ways: bench.py runs perf mode (counter-based Philox on the device,
+                       # property-checked by tests/test_hip_kernels.py::test_device_rng_mode_is_valid_insert); parity mode
+                       # (the reference's host Exp(1) draws, bit-exact ways) is what the golden tests run
+                       "insert_rng": "device-philox",
+                       "wide_gemm": bool(eng.wide_gemm),
+                       # FLAT copies of the figures that matter (the driver's parse keeps scalars only): the whole-window leg --
+                       # L steps with exactly one background plan and one commit inside, the figure that matches the metric's
+                       # "wall incl. refills" -- and the roofline kernel alone / the stand-alone gather operator
+                       "whole_window_ms_per_step": (whole_window or {}).get("ms_per_step"),
+                       "whole_window_samples_per_s": (whole_window or {}).get("samples_per_s"),
+                       "whole_window_commits": (whole_window or {}).get("window_commits"),
+                       "whole_window_plans": (whole_window or {}).get("plans_launched"),
+                       "whole_window_steps": (whole_window or {}).get("steps"),
                        # which take schedule the local batch gets (TrainEngine.gather_alone_min, decided by samples/s)
                        "schedule": ("two aux regions: next batch's take at the head of the step, beside the bottom MLP and the "
                                     "interaction forward" if eng._side_gather(lbs) else
@@ -904,6 +909,13 @@ def main():
                                   "skewed batch are served by L2 / Infinity Cache, so the HBM counters see fewer bytes: "
                                   "traffic, achieved_counter and frac_counter are the same launch time on those",
                          "fused_gather": fused,
+                         # flat copies (see config.whole_window_*): the same kernel with nothing beside it, and the stand-alone
+                         # gather operator on the SURVEY's 8D+16 basis
+                         "frac_alone": (alg_bytes / float(np.mean(alone_us)) / 1e3 / HBM_PEAK_GBS) if alone_us else None,
+                         "gather_operator_frac": gather_operator["frac"] if gather_operator else None,
+                         "headline_is": "frac = the kernel IN the step (it runs beside the next batch's take under the two-region "
+                                        "schedule); frac_alone = the same kernel with nothing beside it; gather_operator_frac = "
+                                        "the stand-alone operator, SURVEY basis",
                          # the same kernel with nothing beside it (after the timed region, cold caches, 30 launches): in the step
                          # it shares the GPU with whatever the schedule places beside it (config.schedule)
                          "alone": ({"avg_launch_us": float(np.mean(alone_us)),

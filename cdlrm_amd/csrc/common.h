@@ -81,6 +81,14 @@ void cdlrm_set_error(const char* fmt, ...);
 //   0: 13-wide forward on the LDS-tiled kernel   1: workgroups per CU of the embedding backward's chunk kernel (0: 12, -1: one per
 //   8 positions)   2: scalar slab reduction   3: per-op host clocks of a tape   4 / 5: workgroups per CU of the fused gather +
 //   interaction forward / backward
+//   6: GEMM kernel selectors (bits): 16 = 128x64 instead of 128x128 k_gemm2 tiles at M >= 65536; 32 = never the wide kernel
+//      (k_gemm3); 256 = the wide kernel for every eligible launch, CDLRM_GEMM_ALONE or not; 512 / 1024 = the split-M weight
+//      gradients (all / the 512-wide ones) on the wide kernel.  Different contraction order inside a 16-deep group than
+//      k_gemm2: equal to fp32 rounding, not bit for bit.
+//      -DCDLRM_DEV builds ONLY (timing experiments that SKIP work; the shipped library refuses them): 1 = no embedding
+//      update, 2 = no slot sort
+//   7: 1 = the epilogues before round 5 (operands fetched behind, not ahead of, their use)
+// No key makes the shipped library skip work: a number measured with any of them set is a number for the same arithmetic.
 extern CDLRM_HIDDEN_DATA int g_cdlrm_debug[8];
 
 // Completion events attached to a launch (cdlrm_event_attach_next).  An event RECORDED on the training queue is a marker

@@ -21,6 +21,9 @@ void cdlrm_set_error(const char* fmt, ...) {
 int g_cdlrm_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int cdlrm_debug_set(int32_t key, int32_t value) {
     CDLRM_REQUIRE(key >= 0 && key < 8, "key: 0 .. 7");
+#ifndef CDLRM_DEV
+    CDLRM_REQUIRE(!(key == 6 && (value & 3)), "work-skipping switches (key 6, bits 1 and 2) exist in -DCDLRM_DEV builds only");
+#endif
     g_cdlrm_debug[key] = value;
     return 0;
 }

@@ -419,7 +419,9 @@ extern "C" int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, in
     CDLRM_REQUIRE(n < ((int64_t)1 << 31) && ctx->T < (1 << 20), "n < 2^31");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
-    if (g_cdlrm_debug[6] & 2) return 0;     // development (tools/ab_step.py --attr debug:6): what the step costs WITHOUT the slot sort
+#ifdef CDLRM_DEV
+    if (g_cdlrm_debug[6] & 2) return 0;     // development build (tools/ab_step.py --attr debug:6): what the step costs WITHOUT the slot sort
+#endif
     const int T = ctx->T;
     BwdWork w = carve(work, T, n, ctx->D);
     const int64_t chunk = sort_chunk(n);
@@ -467,7 +469,9 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     CDLRM_REQUIRE(offsets != nullptr || n_bags == n, "Criteo layout needs n_bags == n");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
-    if (g_cdlrm_debug[6] & 1) return 0;     // development: ... without the embedding update (an upper bound on what moving it buys)
+#ifdef CDLRM_DEV
+    if (g_cdlrm_debug[6] & 1) return 0;     // development build: ... without the embedding update (an upper bound on what moving it buys)
+#endif
     const int T = ctx->T, D4 = ctx->D / 4;
     const int lpr = lanes_per_row_b(D4);
     const int gpb = 256 / lpr;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void g2_epilogue_full(const GemmArgs& g, f32x16 (&acc
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    } else {
+    } else if (ACT != 0) {      // (mask_act == 0: no mask -- g.mask may be null, nothing is loaded)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -192,6 +192,7 @@ __device__ __forceinline__ void g2_epilogue_full(const GemmArgs& g, f32x16 (&acc
                 for (int q = 0; q < 4; ++q)
                     mv[i][j][q] = *reinterpret_cast<const float4*>(g.mask + (row0 + i * 32) * g.ldmask + col0 + j * 32 + 8 * q);
     }
+    const bool has_bias = g.bias != nullptr;        // (no bias: no add -- x + 0.f would turn -0.0 into +0.0, the generic epilogue's values differ)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -202,7 +203,7 @@ __device__ __forceinline__ void g2_epilogue_full(const GemmArgs& g, f32x16 (&acc
                 float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 if (B_KC) {
                     const float4 b = bv[j][q];
-                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                    if (has_bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                     if (ACT == 1) {
                         v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                         v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
@@ -210,7 +211,7 @@ __device__ __forceinline__ void g2_epilogue_full(const GemmArgs& g, f32x16 (&acc
                         v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
                         v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
                     }
-                } else {
+                } else if (ACT != 0) {
                     const float4 x = mv[i][j][q];
                     if (ACT == 1) {
                         v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;

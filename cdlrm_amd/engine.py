@@ -288,6 +288,26 @@ class WindowPipeline:
         again); False: the old ones stay -- the misses that do not fit read the host table, as the reference serves all of them."""
         n_buf = 2 if both else 1
         row = 4 * self.ctx.D + 12                     # row + index + position per entry (ops.Victims)
+        if self.multi:
+            # Several ranks: the capacity has to come out THE SAME on every rank -- with the sharded fetch V = min(victims,
+            # capacity) sets the chunk sizes (and the number) of commit()'s all-gathers, and the bound victim set has to be one
+            # set.  So nothing rank-local enters: `want` derives from the window's victim count (the replicated plan: equal
+            # everywhere) and victim_limit (a fifth of the device's TOTAL memory); this rank's free memory does not, and there is
+            # no smaller-size fallback -- a rank that cannot allocate what the others allocate stops the job here, loudly,
+            # instead of training on a different victim set (ADVICE r5).
+            cap = int(want)
+            if cap <= old_cap:
+                return False
+            slots = [self._vnext, self._vnext ^ 1][:n_buf]
+            for i in slots:
+                self.victims[i] = None
+            try:
+                for i in slots:
+                    self.victims[i] = ops.Victims(self.ctx, cap)
+            except torch.OutOfMemoryError as e:
+                raise RuntimeError("rank %d: victim buffers of %d rows (the capacity every rank allocates) do not fit this "
+                                   "device: lower --lookahead or pass victim_rows" % (self.rank, cap)) from e
+            return True
         free = torch.cuda.mem_get_info(self.dev)[0] if S.is_hip(self.dev) else (1 << 62)
         free += n_buf * old_cap * row                 # what releasing the old buffer(s) gives back
         cap = int(min(want, (free - (4 << 30)) // (n_buf * row)))

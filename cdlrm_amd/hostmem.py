@@ -45,6 +45,49 @@ def shared_table_dir_free():
         return None
 
 
+def memory_limit():
+    """This job's host-memory limit in bytes (cgroup v2 memory.max, else cgroup v1 memory.limit_in_bytes; None: none / unknown)."""
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            txt = open(path).read().strip()
+        except OSError:
+            continue
+        if txt.isdigit() and int(txt) < (1 << 60):
+            return int(txt)
+    return None
+
+
+REPLICA_LIMIT_FRACTION = 0.85       # W private copies + W x pinned staging may take this much of the job's memory limit
+
+
+def host_tables_mode(table_bytes: int, world: int, *, staging_bytes: int = 0, shm_free="ask", limit="ask"):
+    """How `world` ranks of one node get the host tables -- ONE decision for make_host_tables (the run) and bench.py --plan-only
+    (the plan), so the two cannot disagree: returns (mode, error) with mode "private" (one rank), "shared" (one tmpfs mapping,
+    rank 0 writes evictions back) or "replicas" (a private pinned copy per rank, every rank writes back), error a message when the
+    chosen mode cannot hold (else None).  CDLRM_HOST_TABLES = shared | replicas | auto (default) forces or leaves the choice."""
+    if world <= 1:
+        return "private", None
+    forced = os.environ.get("CDLRM_HOST_TABLES", "auto")
+    if forced not in ("shared", "replicas", "auto"):
+        raise ValueError("CDLRM_HOST_TABLES: shared, replicas or auto")
+    if shm_free == "ask":
+        shm_free = shared_table_dir_free()
+    if limit == "ask":
+        limit = memory_limit()
+    fits_shm = shm_free is None or shm_free >= table_bytes + (1 << 30)
+    mode = forced if forced != "auto" else ("shared" if fits_shm else "replicas")
+    err = None
+    if mode == "shared" and not fits_shm:
+        err = ("the shared host tables (%.0f GB) do not fit %s (%.0f GB free): CDLRM_SHM_DIR=<larger tmpfs>, "
+               "CDLRM_HOST_TABLES=replicas, or cap the tables (--max-ind-range)" % (table_bytes / 1e9, shared_table_dir(), shm_free / 1e9))
+    if mode == "replicas" and limit and world * (table_bytes + staging_bytes) > REPLICA_LIMIT_FRACTION * limit:
+        err = ("%d private copies of the host tables (%.0f GB each, + %.1f GB of pinned staging per rank) exceed %d %% of this job's "
+               "memory limit (%.0f GB) and %s holds %.0f GB: CDLRM_SHM_DIR=<larger tmpfs> or cap the tables (--max-ind-range)"
+               % (world, table_bytes / 1e9, staging_bytes / 1e9, int(REPLICA_LIMIT_FRACTION * 100), limit / 1e9, shared_table_dir(),
+                  (shm_free or 0) / 1e9))
+    return mode, err
+
+
 def fill_uniform_from_device(dst: torch.Tensor, n_rows: int, device, seed: int, chunk_rows: int = 1 << 21):
     """dst[n, m] ~ U(-sqrt(1/n), sqrt(1/n)) (the reference's init distribution, model_no_ddp.py:70-73), drawn on
     the GPU and copied down in chunks: fast enough for the 96 GB Terabyte-shape tables."""
@@ -83,24 +126,10 @@ def make_host_tables(ln_emb: Sequence[int], m_spa: int, *, device, seed: int = 1
     #               made every touched row rank 0's), so the copies stay identical.  W x the memory, no tmpfs, NUMA-local reads.
     # auto: shared when the tmpfs has room for the tables, replicas otherwise.  Rank 0 decides, everybody follows.
     import torch.distributed as dist
-    mode = [os.environ.get("CDLRM_HOST_TABLES", "auto")]
-    if mode[0] not in ("shared", "replicas", "auto"):
-        raise ValueError("CDLRM_HOST_TABLES: shared, replicas or auto")
-    if rank == 0 and mode[0] == "auto":
-        free = shared_table_dir_free()
-        mode[0] = "shared" if (free is None or free >= total * 4 + (1 << 30)) else "replicas"
-    if rank == 0 and mode[0] == "replicas":
-        # W private copies are W x the tables of PINNED host memory: say so before the kernel's OOM killer does
-        limit = None
-        try:
-            txt = open("/sys/fs/cgroup/memory.max").read().strip()
-            limit = int(txt) if txt.isdigit() else None
-        except OSError:
-            pass
-        if limit and world * total * 4 > 0.85 * limit:
-            mode[0] = "error: %d private copies of the host tables (%.0f GB each) exceed this job's memory limit (%.0f GB) and %s " \
-                      "holds %.0f GB: CDLRM_SHM_DIR=<larger tmpfs> or cap the tables (--max-ind-range)" \
-                      % (world, total * 4 / 1e9, limit / 1e9, shared_table_dir(), (shared_table_dir_free() or 0) / 1e9)
+    mode = ["auto"]
+    if rank == 0:           # rank 0 decides (host_tables_mode: the same function bench.py --plan-only prints), everybody follows
+        m, err = host_tables_mode(total * 4, world, staging_bytes=int(os.environ.get("CDLRM_PLAN_STAGING_BYTES", "0")))
+        mode[0] = ("error: " + err) if err else m
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast_object_list(mode, src=0)
     if mode[0].startswith("error"):

@@ -53,8 +53,11 @@ typedef struct {
 int cdlrm_abi_version(void);
 /* DEVELOPMENT EXPORT, not part of the drop-in surface (no reference counterpart; a maintainer binds nothing to it): key 0 .. 7
  * selects a kernel variant the current one replaced, or a grid size, so that two builds' worth of behaviour can be timed against
- * each other on one box in one process (tools/ab_step.py --attr debug:<key>, bench.py --debug).  All zero unless a tool sets
- * them; results never depend on a key (variants are bit-identical, grids only change placement). */
+ * each other on one box in one process (tools/ab_step.py --attr debug:<key>, bench.py --debug, which prints what it set in
+ * config.debug).  All zero unless a tool sets them.  No key skips work in the shipped library (the two timing experiments that
+ * do -- key 6, bits 1 and 2 -- are compiled in by -DCDLRM_DEV only and refused here otherwise); variants are bit-identical
+ * except the GEMM kernel selectors of key 6, whose kernels differ in contraction order (equal to fp32 rounding); grid sizes
+ * only change placement.  The list of keys: csrc/common.h. */
 int cdlrm_debug_set(int32_t key, int32_t value);
 const char* cdlrm_last_error(void);
 

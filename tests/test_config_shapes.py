@@ -202,6 +202,120 @@ def test_full_size_invariants_and_bitwise_repeat(terabyte_host, config, L, steps
     assert int((a["tags"] != -1).sum()) > 1_000_000
 
 
+def _run_window_boundary(host, L, gather_alone_min, steps_after=6):
+    """One whole look-ahead window of c3 at full size AS bench.py's whole-window leg trains it: the next window's plan launched
+    in the background at iteration plan_at (least-priority stream + CPU row gather beside the steps), the commit at the
+    boundary with the eviction write-back ON, the look-ahead resolver, the given take schedule.  Returns the end state; the
+    host rows the write-back changed are put back (the module's other cases read the same host tables)."""
+    import bench
+    from cdlrm_amd.engine import WindowResolver
+    w = bench.build_workload("c3", lookahead=L, host=host, seed=123, cache_init="zeros", write_back=True)
+    cg, eng, pipe, syn, B = w["cg"], w["eng"], w["pipe"], w["syn"], w["B"]
+    T = len(cg.cache_sizes)
+    eng.gather_alone_min = gather_alone_min
+    plan_at = max(1, min(L // 2, 64))                   # bench.py's
+    win = syn.window(0, L)
+    pipe.plan_window(win)
+    pipe.commit()
+    rs = WindowResolver(eng, win, B)
+    nxt_win = None
+    losses = []
+    for jj in range(L):
+        if jj == plan_at:
+            pipe.wait_writeback()
+            nxt_win = syn.window(1, L)
+            pipe.plan_window(nxt_win)                   # runs beside the steps that follow
+        idx = win[:, jj * B:(jj + 1) * B]
+        X, Tt = syn.dense(jj)
+        nxt = win[:, (jj + 1) * B:(jj + 2) * B] if (jj + 1 < L and jj + 1 != plan_at) else None
+        lossbuf = eng.step(X, idx, Tt, j=jj, next_idx=nxt, res=rs.batch(jj), next_res=rs.batch(jj + 1) if nxt is not None else None,
+                           loss_sync=False)
+        rs.ensure(jj + rs.CH + 2)
+    # ---- the boundary.  The plan named its evictions at iteration plan_at; the rows they carry to the host tables are the rows
+    #      as the LAST step of the window left them.  Sample up to 4096 evicted tags per table: their cache rows now, their host
+    #      rows now (for the undo) -- then commit + write-back and compare.
+    if pipe._worker is not None:
+        pipe._worker.join()
+    eng.finish()
+    torch.cuda.synchronize()
+    # (the plan holds, per winner of the window, the tag word it will overwrite and the cache row it will take: what the commit
+    #  kernel evicts is whatever VALID tag sits in that word at commit time, main_no_ddp.py:190-199)
+    _, _, wo = pipe.plan.offsets()
+    undo, expect = [], []
+    n_evicted = 0
+    for k in range(T):
+        tp = pipe.plan.win_tag[wo[k]:wo[k + 1]]
+        rows = pipe.plan.win_row[wo[k]:wo[k + 1]]
+        old = cg.tags[tp]
+        valid = old != -1
+        tags = old[valid]
+        n_evicted += int(tags.numel())
+        if tags.numel() == 0:
+            undo.append(None); expect.append(None)
+            continue
+        assert tags.numel() == torch.unique(tags).numel(), "table %d: a tag evicted twice" % k
+        tags_h = tags.cpu()
+        undo.append((tags_h, host.emb_l[k].weight.data[tags_h].clone()))
+        pick = torch.linspace(0, tags.numel() - 1, min(4096, tags.numel())).long().to(tags.device)
+        P = int(cg.cache_sizes[k])
+        sample = tags[pick]
+        assert bool((cg.occupancy_tables[k][sample % P] == sample.view(-1, 1)).any(1).all()), \
+            "table %d: a tag named for eviction is not resident before the commit" % k
+        expect.append((sample.cpu(), cg.weight.data[rows[valid][pick]].clone().cpu()))
+    assert n_evicted > 100_000, "the boundary evicts too little to test anything (%d)" % n_evicted
+    pipe.commit()
+    pipe.wait_writeback()
+    torch.cuda.synchronize()
+    _check_cache_invariants(cg)
+    for k in range(T):
+        if expect[k] is not None:
+            tags_s, rows = expect[k]
+            assert torch.equal(host.emb_l[k].weight.data[tags_s], rows), "table %d: host rows of evicted tags != the cache rows they left" % k
+            # ... and an evicted tag is gone from its set
+            P = int(cg.cache_sizes[k])
+            assert not bool((cg.occupancy_tables[k][tags_s.to(DEV) % P] == tags_s.to(DEV).view(-1, 1)).any())
+    # ---- a few steps into the next window (its resolver against the new tags)
+    rs = WindowResolver(eng, nxt_win, B)
+    for jj in range(steps_after):
+        idx = nxt_win[:, jj * B:(jj + 1) * B]
+        X, Tt = syn.dense(L + jj)
+        nxt = nxt_win[:, (jj + 1) * B:(jj + 2) * B] if jj + 1 < steps_after else None
+        lossbuf = eng.step(X, idx, Tt, j=jj, next_idx=nxt, res=rs.batch(jj), next_res=rs.batch(jj + 1) if nxt is not None else None)
+        rs.ensure(jj + rs.CH + 2)
+        losses.append(lossbuf[0:1].clone())
+    eng.finish()
+    cg.ctx.check()
+    torch.cuda.synchronize()
+    pipe.close()
+    # (the cache rows proper: the aux rows behind them hold the last batches' transient miss rows, in one region or two
+    #  depending on the take schedule)
+    wsum = sum(cg.emb_l[k].weight.data[:cg.num_ways * int(cg.cache_sizes[k])].sum(dtype=torch.float64).item() for k in range(T))
+    out = dict(losses=torch.cat(losses).cpu(), tags=cg.tags.clone(), wsum=wsum, params=eng.param_flat.clone(), n_evicted=n_evicted)
+    for k in range(T):                                  # the host tables as the other cases expect them
+        if undo[k] is not None:
+            host.emb_l[k].weight.data[undo[k][0]] = undo[k][1]
+    del w, cg, eng, pipe, syn
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_whole_window_with_background_plan_commit_and_writeback(terabyte_host):
+    """What bench.py's whole-window leg does (config.whole_window: the figure that matches the metric's "wall incl. refills"),
+    asserted: c3 at full size through ONE window boundary -- L = 200 steps with the next window's plan running in the
+    background from iteration 64, the commit, the eviction write-back ON, then six steps of the next window -- under BOTH
+    take schedules (two aux regions: gather_alone_min above the batch; chained take: at it).  Checked at the boundary: every
+    tag named for eviction is resident before and gone after, the host rows of 4096 evicted tags per table equal the
+    trained cache rows they left, the structure's invariants hold; and the two schedules end on the same bits (tags, every
+    parameter, the loss trajectory): the background plan, the commit and the write-back order with the training step under
+    either."""
+    a = _run_window_boundary(terabyte_host, 200, 16384)
+    b = _run_window_boundary(terabyte_host, 200, 8192)
+    assert torch.isfinite(a["losses"]).all() and 0.3 < float(a["losses"][-1]) < 2.0
+    assert a["n_evicted"] == b["n_evicted"]
+    assert torch.equal(a["tags"], b["tags"]), "tags differ between the take schedules"
+    assert torch.equal(a["losses"], b["losses"]) and torch.equal(a["params"], b["params"]) and a["wsum"] == b["wsum"]
+
+
 def test_c4_capped_invariants_and_bitwise_repeat():
     """BASELINE configs[3] (embed-dim 256, 26 tables x 150 k x 16-way, B = 8192) exactly as `bench.py --config c4
     --max-ind-range 2000000` builds it: tables capped at 2 M rows (the uncapped host tables are 192 GB of pinned memory;

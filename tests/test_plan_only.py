@@ -32,7 +32,9 @@ def test_plan_only_prints_one_record_per_rank_and_touches_no_gpu(n):
     assert r0["host_tables_bytes_one_mapping_per_node"] == 187767399 * 128 * 4
     assert n == 1 or r0["host_tables_mode"] in ("shared", "replicas")
     assert r0["gpu_max_hw_queues"] == 4 and len({r["master_port"] for r in recs}) == 1
-    assert [r["writes_evictions_back"] for r in recs] == [True] + [False] * (n - 1)
+    # shared mapping / one rank: rank 0 writes the evictions back; private replicas: every rank writes to its own copy
+    replicas = n > 1 and r0["host_tables_mode"] == "replicas"
+    assert [r["writes_evictions_back"] for r in recs] == ([True] * n if replicas else [True] + [False] * (n - 1))
     assert r0["hbm_bytes_per_rank"]["cache_rows"] > 10e9 and r0["hbm_bytes_per_rank"]["sum_without_growth"] < 200e9
     assert (r0["projection"] is not None) and r0["projection"]["projected_scaling"] >= 1.0
     assert len(r0["hip_streams"]) == (4 if n == 1 else 6)
@@ -61,3 +63,36 @@ def test_rank_resources_refuse_what_cannot_fit():
     huge = bench.rank_resources("c4", 1, cpus=16, mem_limit=300 << 30)
     assert huge["refused"], "c4 uncapped pins 192 GB"
     assert not bench.rank_resources("c4", 1, cpus=16, mem_limit=300 << 30, max_ind_range=2000000)["refused"]
+
+
+def test_host_tables_mode_is_one_decision_for_plan_and_run(monkeypatch):
+    """hostmem.host_tables_mode is what BOTH make_host_tables (the run) and bench.py --plan-only (the plan) call: the tmpfs
+    decides shared / replicas, the job's memory limit refuses replicas that do not fit (with the staging counted), the
+    environment forces either."""
+    from cdlrm_amd import hostmem
+    GB = 1 << 30
+    monkeypatch.delenv("CDLRM_HOST_TABLES", raising=False)
+    assert hostmem.host_tables_mode(96 * GB, 1) == ("private", None)
+    assert hostmem.host_tables_mode(96 * GB, 8, shm_free=200 * GB, limit=None) == ("shared", None)
+    mode, err = hostmem.host_tables_mode(96 * GB, 8, shm_free=32 * GB, limit=2000 * GB)
+    assert mode == "replicas" and err is None
+    mode, err = hostmem.host_tables_mode(96 * GB, 8, shm_free=32 * GB, limit=800 * GB)
+    assert mode == "replicas" and "exceed" in err
+    mode, err = hostmem.host_tables_mode(96 * GB, 2, staging_bytes=30 * GB, shm_free=1 * GB, limit=int(2 * 126 * GB / 0.85) - GB)
+    assert mode == "replicas" and err is not None          # the staging tips it over
+    monkeypatch.setenv("CDLRM_HOST_TABLES", "shared")
+    mode, err = hostmem.host_tables_mode(96 * GB, 8, shm_free=32 * GB, limit=None)
+    assert mode == "shared" and "do not fit" in err
+    monkeypatch.setenv("CDLRM_HOST_TABLES", "bogus")
+    with pytest.raises(ValueError):
+        hostmem.host_tables_mode(96 * GB, 8, shm_free=32 * GB, limit=None)
+
+
+def test_work_skipping_debug_switches_are_refused_by_the_shipped_library():
+    """cdlrm_debug_set(6, 1 | 2) -- no embedding update / no slot sort, timing experiments -- exist in -DCDLRM_DEV builds only:
+    a bench line cannot have been produced by a library that skipped work."""
+    from cdlrm_amd import _lib
+    r = _lib.raw()
+    assert r.cdlrm_debug_set(6, 1) != 0 and r.cdlrm_debug_set(6, 2) != 0 and r.cdlrm_debug_set(6, 35) != 0
+    assert b"CDLRM_DEV" in r.cdlrm_last_error()
+    assert r.cdlrm_debug_set(6, 32) == 0 and r.cdlrm_debug_set(6, 0) == 0

@@ -1,6 +1,9 @@
-#!/usr/bin/env python3
-"""Which kernels does the vendor library pick for the step's fp32 GEMM shapes?  Run under `rocprofv3 --kernel-trace --stats`
-(tools only: a yardstick, never product); the kernel names carry the macro tile, the MFMA shape and the K depth."""
+"""Which kernels does the vendor library pick for the step's fp32 GEMM shapes?  (tools only: a yardstick, never product); the
+kernel names carry the macro tile, the MFMA shape and the K depth.  Run with the interpreter itself behind `--` -- never through
+a shebang / env hop, which this pool refuses under the profiler:
+
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d <out> -- python3 $GRAFT_REPO_ROOT/tools/vendor_names.py
+"""
 import torch
 torch.backends.cuda.matmul.allow_tf32 = False
 dev = torch.device("cuda:0")
