@@ -59,6 +59,8 @@ PROTOTYPES = {
     "cdlrm_embbag_probe": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, vp, c_i32, vp]),
     "cdlrm_window_resolve": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, c_i64, vp, vp, vp]),
     "cdlrm_embbag_take": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, c_i64, vp, c_i32, vp]),
+    "cdlrm_victim_writeback_work_bytes": (c_u64, [c_i32, c_i64]),
+    "cdlrm_victim_writeback": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i32, vp, vp]),
     "cdlrm_embbag_fwd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, vp]),
     "cdlrm_embbag_bwd_work_bytes": (c_u64, [c_i32, c_i64, c_i32]),
     "cdlrm_embbag_bwd_sgd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),

@@ -591,6 +591,101 @@ extern "C" int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Victim write-back (--evict-victim-cache; model_no_ddp.py:187 records victim_cache_entries = (aux rows, missing indices) per
+// table and main_no_ddp.py:96 parses the flag, neither is ever used: the reference drops the update a MISSED row received).
+// Defined here as what `emb_tables[k].weight[missing] = cache[k].weight[aux_rows]` does behind the step: the trained aux
+// row of every miss goes back to its host row -- and to its copy among the window's resident victim rows, which later
+// misses of the window read instead of the host table.  An index that misses several times in one batch has one aux row
+// per occurrence, each trained on its own gradient; the LAST occurrence (position order) is the one written, as the
+// sequential assignment leaves it.  Two launches: the misses' indices in miss order (miss i of a table sits in aux row i),
+// then one wave per miss that looks for a later occurrence of its index and, finding none, copies the row.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vwb_list(const TableDesc* __restrict__ tab, int ways, int aux_first,
+                                                  const int64_t* __restrict__ idx, int64_t ld_idx,
+                                                  const int32_t* __restrict__ slots, int64_t n,
+                                                  int64_t* __restrict__ m_idx, int32_t* __restrict__ m_pos,
+                                                  int32_t* __restrict__ m_count) {
+    const int t = blockIdx.y;
+    const int32_t first = (int32_t)(tab[t].P * ways) + aux_first;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t sl = slots[(int64_t)t * n + p];
+        if (sl < first) continue;
+        const int32_t i = sl - first;
+        m_idx[(int64_t)t * n + i] = idx[(int64_t)t * ld_idx + p];
+        m_pos[(int64_t)t * n + i] = (int32_t)p;
+        atomicMax(m_count + t, i + 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_vwb_apply(const TableDesc* __restrict__ tab, int ways, int aux_first, int D4,
+                                                   const float4* __restrict__ weight, float* const* __restrict__ host_rows,
+                                                   const int64_t* __restrict__ m_idx, const int32_t* __restrict__ m_pos,
+                                                   const int32_t* __restrict__ m_count, int64_t n,
+                                                   const int32_t* __restrict__ wsrc, int64_t ld_w,
+                                                   const int64_t* __restrict__ v_idx, const int64_t* __restrict__ v_off,
+                                                   float* __restrict__ v_rows) {
+    const int t = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt = m_count[t];
+    const TableDesc d = tab[t];
+    const int64_t* mi = m_idx + (int64_t)t * n;
+    for (int i = blockIdx.x * 4 + wave; i < cnt; i += gridDim.x * 4) {
+        const int64_t key = mi[i];
+        bool later = false;
+        for (int j = i + 1 + lane; j < cnt; j += 64) later |= mi[j] == key;
+        if (__ballot(later)) continue;              // a later occurrence of this index writes the row (wave-uniform)
+        // where the row's copy sits among the window's victim rows (-1: nowhere): the resolver's answer, or a search
+        int64_t vp = -1;
+        if (wsrc) vp = wsrc[(int64_t)t * ld_w + m_pos[(int64_t)t * n + i]];
+        else if (v_idx) {
+            const int64_t lo = v_off[t], hi = v_off[t + 1];
+            const int64_t q = (int64_t)lower_bound_u64(reinterpret_cast<const uint64_t*>(v_idx), lo, hi, (uint64_t)key);
+            if (q < hi && v_idx[q] == key) vp = q;
+        }
+        const float4* from = weight + (d.row_base + d.P * ways + aux_first + i) * D4;
+        float4* host = reinterpret_cast<float4*>(host_rows[t]) + key * D4;
+        float4* vict = vp >= 0 ? reinterpret_cast<float4*>(v_rows) + vp * D4 : nullptr;
+        for (int cc = lane; cc < D4; cc += 64) {
+            const float4 v = from[cc];
+            host[cc] = v;
+            if (vict) vict[cc] = v;
+        }
+    }
+}
+
+extern "C" uint64_t cdlrm_victim_writeback_work_bytes(int32_t T, int64_t n) {
+    return (uint64_t)T * n * 12 + (((uint64_t)T * 4 + 255) & ~(uint64_t)255) + 512;
+}
+
+extern "C" int cdlrm_victim_writeback(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, const int32_t* slots,
+                                      const int32_t* wsrc, int64_t ld_w, int32_t aux_phase, void* work, void* stream) {
+    CDLRM_REQUIRE(ctx && idx && slots && work, "null argument");
+    CDLRM_REQUIRE(aux_phase >= 0 && aux_phase < ctx->aux_phases, "aux_phase outside the geometry's aux_phases");
+    CDLRM_REQUIRE(ctx->tags && ctx->weight, "cdlrm_ctx_bind_cache first");
+    CDLRM_REQUIRE(ctx->h_host_rows[0] != nullptr, "cdlrm_ctx_bind_host_tables first");
+    CDLRM_REQUIRE(n >= 0 && ld_idx >= n && (!wsrc || ld_w >= n) && ((uintptr_t)work & 255) == 0, "bad n / ld / work alignment");
+    if (n == 0 || ctx->aux == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = ctx->T, D4 = ctx->D / 4;
+    char* wp = (char*)work;
+    int32_t* m_count = (int32_t*)wp; wp += (((uint64_t)T * 4 + 255) & ~(uint64_t)255);
+    int64_t* m_idx = (int64_t*)wp; wp += (uint64_t)T * n * 8;
+    int32_t* m_pos = (int32_t*)wp;
+    CDLRM_HIP_CHECK(hipMemsetAsync(m_count, 0, (size_t)T * 4, s));
+    int64_t gx = cdiv(n, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_vwb_list, dim3((unsigned)gx, (unsigned)T), dim3(256), 0, s, ctx->d_tab, ctx->ways, aux_phase * ctx->aux,
+                       idx, ld_idx, slots, n, m_idx, m_pos, m_count);
+    int64_t ga = cdiv(n < ctx->aux ? n : (int64_t)ctx->aux, 4);
+    if (ga > 512) ga = 512;
+    hipLaunchKernelGGL(k_vwb_apply, dim3((unsigned)ga, (unsigned)T), dim3(256), 0, s, ctx->d_tab, ctx->ways, aux_phase * ctx->aux, D4,
+                       reinterpret_cast<const float4*>(ctx->weight), ctx->d_host_rows, m_idx, m_pos, m_count, n, wsrc, ld_w,
+                       ctx->vict_idx, ctx->vict_off, const_cast<float*>(ctx->vict_rows));
+    CDLRM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cdlrm_ctx_time_next_gather(cdlrm_ctx* ctx, void* start_event, void* stop_event) {
     CDLRM_REQUIRE(ctx && start_event && stop_event, "null argument");
     ctx->ev_start = start_event;

@@ -698,6 +698,13 @@ class TrainEngine:
         # kernel (csrc/gemm_wide.h).  The bottom MLP's backward runs beside the weight gradients and never does (round 6: with
         # the hint on every GEMM the c3 step took 0.5790 ms against 0.5580 without, with it on these 0.5562).
         self.wide_gemm = True
+        # --evict-victim-cache (main_no_ddp.py:96, parsed and unused by the reference): behind every step's embedding update
+        # the trained aux rows of the batch's misses go back to their host rows and to their copies among the window's victim
+        # rows (ops.victim_writeback).  One rank only; the step then runs un-pipelined (no take of the next batch ahead of
+        # this batch's write-back, no launch tape) -- an optional mode, not the timed path.  Run() also plans the next window
+        # at the boundary instead of in the background: the plan's row gather has to see the window's last write-back.
+        self.evict_victim = False
+        self._vwb_work = {}
         self._gslot = None
         self._res = self._next_res = None
         self._tapes = {}
@@ -990,6 +997,9 @@ class TrainEngine:
         valid after finish() (bench.py, Run), not right behind step() on the current stream.
         Returns the device loss buffer (element 0 = the loss, 1 = correct predictions, 2 = loss * batch)."""
         B, n = X.shape[0], lS_i.shape[1]
+        if self.evict_victim:
+            assert not self.multi, "--evict-victim-cache is defined for one rank (every rank would write its own misses' rows)"
+            next_idx = next_res = None          # the next batch's take follows this batch's write-back
         self.loss_sync = bool(loss_sync) or not self.fused_head
         self._mark_this = bool(self.mark_next and self._pending_resolve is not None and lS_o is None)
         self.mark_next = False
@@ -1025,10 +1035,16 @@ class TrainEngine:
         if self._next_res is not None and next_res[2] is not (res[2] if res is not None else None):
             # the next batch's take may run on the side stream too (single aux region / chained take): behind ITS chunk
             self.side.wait_event(next_res[2])
-        if self.use_tape and lS_o is None:
+        if self.use_tape and lS_o is None and not self.evict_victim:
             sgd_done = self._step_taped(X, lS_i, T, next_idx)
         else:
             sgd_done = self._fwd_bwd(X, lS_i, T, lS_o, gather_events, next_idx)
+        if self.evict_victim:
+            # on the side stream, behind the embedding update _fwd_bwd issued there and in front of the next step's take
+            if n not in self._vwb_work:
+                self._vwb_work[n] = ops.victim_writeback_work(self.ctx, n)
+            ops.victim_writeback(self.ctx, lS_i, self._last_slots, res[1] if (res is not None and lS_o is None) else None,
+                                 self._last_phase, self._vwb_work[n], stream=self.side)
         if self._mark_this:
             self._pending_resolve = None        # issued by this step
         # ---- dense gradient exchange + SGD ----
@@ -1129,6 +1145,7 @@ class TrainEngine:
             probed = ev["probed_inline"]
             rec(probed.record, side)
         n_bags = B if lS_o is None else lS_o.shape[1]
+        self._last_slots, self._last_phase = slots, self._phase          # (ops.victim_writeback reads them behind the step)
 
         fused = self._fused_gather(lS_o)
 

@@ -400,6 +400,15 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
     # result is the synchronous plan's.  Parity mode draws the way choices in line at the boundary, as the reference does.
     # (`args.plan_at_boundary`: not a CLI flag -- tests set it to compare against planning every window at its boundary)
     lookahead_plan = bool(args.device_rng) and not getattr(args, "plan_at_boundary", False)
+    if args.evict_victim_cache:
+        # --evict-victim-cache (main_no_ddp.py:96: parsed and never used by the reference; here the trained rows of MISSED
+        # lookups are written back to the host tables behind every step, engine.TrainEngine.evict_victim): one rank, and the
+        # next window is planned at the boundary -- its row gather has to see the write-backs of the window's last step
+        if world > 1:
+            sys.exit("ERROR: --evict-victim-cache is defined for --world-size=1 (every rank would write its own misses' rows "
+                     "to the one host table)")
+        lookahead_plan = False
+        eng.evict_victim = True
     pipe = WindowPipeline(cache_group, emb_tables, L * aux_rows * 2, parity_rng=not args.device_rng,
                           seed=args.numpy_rand_seed, average_on_writeback=args.average_on_writeback, rank=rank,
                           world_size=world, host_gather=lookahead_plan)
@@ -415,7 +424,10 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
     total_iter = total_samp = 0
     caching_overhead = []
     print_interval_stats = args.print_freq > 0
+    stop_training = False               # --mlperf-acc-threshold / --mlperf-auc-threshold reached (decided by rank 0's test loop)
     for epoch in range(args.nepochs):
+        if stop_training:
+            break
         it = iter(train_ld)
         window = []
         next_window = None          # look-ahead plan: the window whose plan is already in flight
@@ -538,6 +550,7 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                 print('Testing at {}/{}....'.format(j, len(train_ld)), flush=True)
                 test_samp = 0
                 total_test_acc = 0
+                test_scores, test_targets = [], []
                 for Xt, lS_ot, lS_it, Tt in test_ld:
                     if getattr(test_ld, "multi_hot", False):        # ragged multi-hot test batches
                         Ot, It = square_bags([lS_ot[k] for k in range(len(ln_emb))], lS_it, dev)
@@ -550,9 +563,26 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
                     Tn = Tt.cpu().numpy()
                     total_test_acc += np.sum((np.round(S_, 0) == Tn).astype(np.uint32))
                     test_samp += Tn.shape[0]
+                    test_scores.append(Zt.reshape(-1).clone())
+                    test_targets.append(Tt.reshape(-1).to(dev))
                 print('Test accuracy = {}%'.format(100 * (total_test_acc / test_samp)), flush=True)
+                # the second figure the reference's MLPerf flags speak of (main_no_ddp.py:117-120) and never compute: the AUC of
+                # the test scores, rank-sum on the device (ops.roc_auc; an extra line behind the reference's own)
+                test_auc = ops.roc_auc(torch.cat(test_scores), torch.cat(test_targets)) if test_scores else float("nan")
+                print('Test AUC = {}'.format(test_auc), flush=True)
+                if (args.mlperf_acc_threshold > 0 and total_test_acc / test_samp >= args.mlperf_acc_threshold) or \
+                        (args.mlperf_auc_threshold > 0 and test_auc >= args.mlperf_auc_threshold):
+                    print('MLPerf threshold reached at {}/{}: training stops'.format(j, len(train_ld)), flush=True)
+                    stop_training = True
                 t_excluded += time.time() - t_test
+            if should_test and world > 1 and (args.mlperf_acc_threshold > 0 or args.mlperf_auc_threshold > 0):
+                # rank 0 alone tests: every rank learns whether it said stop (one flag, only when a threshold is set)
+                flag = torch.tensor([1 if stop_training else 0], device=dev)
+                dist.broadcast(flag, src=0)
+                stop_training = bool(int(flag[0]))
             j += 1
+            if stop_training:
+                break
     eng.finish()
     pipe.close()            # a look-ahead plan past the last window may still be in flight
     torch.cuda.synchronize()

@@ -136,6 +136,23 @@ def embbag_take(ctx: CacheCtx, idx: torch.Tensor, wslots: torch.Tensor, wsrc: to
                                        wslots.stride(0), slots_out.data_ptr(), int(aux_phase), stream_ptr(stream)))
 
 
+def victim_writeback_work(ctx: CacheCtx, n: int) -> torch.Tensor:
+    nbytes = int(_lib.lib().cdlrm_victim_writeback_work_bytes(ctx.T, n))
+    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=ctx.device)
+
+
+def victim_writeback(ctx: CacheCtx, idx: torch.Tensor, slots: torch.Tensor, wsrc: Optional[torch.Tensor], aux_phase: int,
+                     work: torch.Tensor, stream=None):
+    """--evict-victim-cache: the batch's trained aux rows (its misses) back to their host rows and to their copies among the
+    window's resident victim rows; behind the step's embedding update, in front of the next batch's take."""
+    n = idx.shape[1]
+    assert idx.dtype == torch.int64 and idx.stride(1) == 1 and slots.dtype == torch.int32 and slots.shape == (ctx.T, n) \
+        and slots.is_contiguous()
+    check(_lib.lib().cdlrm_victim_writeback(ctx.handle, idx.data_ptr(), n, idx.stride(0), slots.data_ptr(),
+                                            0 if wsrc is None else wsrc.data_ptr(), 0 if wsrc is None else wsrc.stride(0),
+                                            int(aux_phase), work.data_ptr(), stream_ptr(stream)))
+
+
 class TimingEvent:
     """A HIP timing event of the library's own (its handle exists from creation on, so a launch tape can hold it)."""
 
@@ -629,3 +646,29 @@ def mark_rows(ctx: CacheCtx, slots: torch.Tensor, touched: torch.Tensor, stream=
 def sgd_step(param: torch.Tensor, grad: torch.Tensor, lr: float, stream=None):
     assert param.is_contiguous() and grad.is_contiguous() and param.numel() == grad.numel()
     check(_lib.lib().cdlrm_sgd_step(param.data_ptr(), grad.data_ptr(), param.numel(), float(lr), stream_ptr(stream)))
+
+
+def roc_auc(scores: torch.Tensor, targets: torch.Tensor) -> float:
+    """Area under the ROC curve of `scores` against binary `targets`, on the device the scores live on: the Mann-Whitney rank
+    sum with average ranks for tied scores (= sklearn.metrics.roc_auc_score), float64 accumulation.  The rank-0 test loop's
+    second figure beside the accuracy (the reference parses --mlperf-auc-threshold, main_no_ddp.py:119-120,
+    and never computes the AUC).  NaN when only one class is present."""
+    s = scores.reshape(-1).to(torch.float32)
+    t = targets.reshape(-1).to(s.device) > 0.5
+    n = s.numel()
+    n_pos = int(t.sum())
+    n_neg = n - n_pos
+    if n_pos == 0 or n_neg == 0:
+        return float("nan")
+    order = torch.argsort(s, stable=True)
+    ss = s[order]
+    # average rank of every run of equal scores: (first + last) / 2 of its 1-based positions
+    new = torch.ones(n, dtype=torch.bool, device=s.device)
+    new[1:] = ss[1:] != ss[:-1]
+    run_id = torch.cumsum(new.to(torch.int64), 0) - 1
+    first = torch.nonzero(new).reshape(-1)
+    last = torch.cat([first[1:], torch.tensor([n], device=s.device)]) - 1
+    avg_rank = ((first + last).to(torch.float64) * 0.5 + 1.0)[run_id]
+    rank_sum_pos = avg_rank[t[order]].sum()
+    u = rank_sum_pos - n_pos * (n_pos + 1) / 2.0
+    return float(u / (float(n_pos) * float(n_neg)))

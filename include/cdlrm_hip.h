@@ -119,6 +119,17 @@ int cdlrm_window_resolve(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t 
 int cdlrm_embbag_take(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, const int32_t* wslots,
                       const int32_t* wsrc, int64_t ld_w, int32_t* slots_out, int32_t aux_phase, void* stream);
 
+/* --evict-victim-cache (main_no_ddp.py:96; victim_cache_entries, model_no_ddp.py:187 -- parsed / recorded by the reference
+ * and never used: the update a MISSED row received is lost there).  Behind the step's embedding update: the trained aux row
+ * of every miss of the batch is written to its host row and to its copy among the bound window victim rows; of several
+ * misses of one index in the batch the LAST (position order) is written -- `emb_tables[k].weight[missing] = cache[k].weight[aux]`.
+ *   idx [T, n] / slots [T, n] the batch's lookups and their slot ids as cdlrm_embbag_probe / _take left them (aux_phase: the
+ *   aux region they used); wsrc [T, n] (row stride ld_w) the resolver's victim positions or NULL (the victim list is searched);
+ *   work: device scratch of cdlrm_victim_writeback_work_bytes(T, n) bytes, 256-byte aligned. */
+uint64_t cdlrm_victim_writeback_work_bytes(int32_t T, int64_t n);
+int cdlrm_victim_writeback(cdlrm_ctx* ctx, const int64_t* idx, int64_t n, int64_t ld_idx, const int32_t* slots,
+                           const int32_t* wsrc, int64_t ld_w, int32_t aux_phase, void* work, void* stream);
+
 /* Fused multi-table sum-pool gather: nn.EmbeddingBag(mode="sum") forward on the cache rows for all
  * T tables in one launch (model_no_ddp.py:200-203).
  *   slots    device int32 [T, n]

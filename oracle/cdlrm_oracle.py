@@ -506,7 +506,7 @@ class OracleTrainer:
                  world_size=1, lr=0.1, lr_embeds=0.3, lookahead=2, table_agg_freq=1,
                  table_agg_op="mean", loss="bce", itself=False, op="dot", seed=123,
                  average_on_writeback=False, host_tables=None, cache_init="normal", loss_weights=None,
-                 loss_threshold=0.0):
+                 loss_threshold=0.0, evict_victim_cache=False):
         self.ln_emb = [int(n) for n in ln_emb]
         self.W = world_size
         self.lr, self.lr_embeds = lr, lr_embeds
@@ -516,6 +516,12 @@ class OracleTrainer:
         self.loss_ws = None if loss_weights is None else torch.tensor([float(w) for w in loss_weights], dtype=torch.float64)
         self.loss_threshold = float(loss_threshold)
         self.avg_wb = average_on_writeback
+        # --evict-victim-cache (main_no_ddp.py:96) is parsed and victim_cache_entries (model_no_ddp.py:187) recorded by the
+        # reference, neither is ever used.  The build's definition (world size 1): behind the embedding SGD of a step,
+        # emb_tables[k].weight[missing_sparse_idxs] = cache[k].weight[aux_storage_idxs] -- assigned in position order, so of
+        # several misses of one index the last one's aux row stays (parity unpinned beyond this restatement).
+        self.evict_victim = bool(evict_victim_cache)
+        assert not (self.evict_victim and world_size != 1)
         self.ways = num_ways
         self.B = mini_batch_size
         self.lbs = math.ceil(mini_batch_size / world_size)
@@ -591,6 +597,13 @@ class OracleTrainer:
             for k in range(len(self.ln_emb)):
                 embbag_bwd_sgd(self.weights[r][k], cg[k].long(), Or[k], ly[k].grad, self.lr_embeds)
             self.touched[r].append(list(cg))      # per-table lists (ragged for multi-hot bags)
+            if self.evict_victim:
+                for k in range(len(self.ln_emb)):
+                    first_aux = int(self.cache_sizes[k]) * self.ways
+                    sl = cg[k].long()
+                    pos = torch.nonzero(sl >= first_aux).flatten()
+                    for p in pos.tolist():          # position order: the last occurrence of an index wins
+                        self.host[k][int(Ir[k][p])] = self.weights[r][k][int(sl[p])]
         # aggregate_gradients (:234-247): weight grads averaged, bias grads NOT reduced
         for li in range(len(params[0][0])):
             g = sum(params[r][0][li].grad / Wn for r in range(Wn))

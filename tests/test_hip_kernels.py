@@ -1178,3 +1178,36 @@ def test_smallk_rows_kernel_equals_the_tiled_one(ops, act):
     pre = X.cpu().double() @ W.cpu().double().t()
     ref = {0: pre, 1: torch.relu(pre), 2: torch.sigmoid(pre)}[act]
     np.testing.assert_allclose(Yn.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_victim_writeback_last_occurrence_wins(ops):
+    """cdlrm_victim_writeback on an EMPTY cache (every lookup misses): every distinct index's host row becomes the aux row of
+    its LAST occurrence in the batch (position order), rows of indices not in the batch stay; no victim rows bound (the
+    victim-list search is skipped), wsrc = NULL."""
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Cache_Group, Embedding_Table_Group
+    ln = np.array([500, 37])
+    D, n = 16, 96
+    rng = np.random.RandomState(5)
+    host = Embedding_Table_Group(D, ln, init="empty_meta")
+    for k in range(2):
+        host.emb_l[k].weight.data = torch.from_numpy(rng.randn(int(ln[k]), D).astype(np.float32))
+    host.pin()
+    cg = Embedding_Table_Cache_Group(D, ln, 16, n, 2, device=DEV).to(DEV)
+    cg.ctx.bind_host_tables(host.device_pointers())
+    idx = torch.stack([torch.from_numpy(rng.randint(0, 40, size=n)), torch.from_numpy(rng.randint(0, 37, size=n))]).to(DEV)
+    slots, miss_pos, miss_count = ops.embbag_probe(cg.ctx, idx)
+    torch.cuda.synchronize()
+    assert miss_count.tolist() == [n, n]                    # empty cache: all misses, aux row i = position i
+    before = [host.emb_l[k].weight.data.clone() for k in range(2)]
+    for k in range(2):                                      # "training": every aux row gets a value that names its position
+        first_aux = cg.num_ways * int(cg.cache_sizes[k])
+        cg.emb_l[k].weight.data[first_aux:first_aux + n] += torch.arange(1, n + 1, device=DEV, dtype=torch.float32).view(-1, 1)
+    aux_rows = [cg.emb_l[k].weight.data[cg.num_ways * int(cg.cache_sizes[k]):][:n].clone().cpu() for k in range(2)]
+    work = ops.victim_writeback_work(cg.ctx, n)
+    ops.victim_writeback(cg.ctx, idx, slots, None, 0, work)
+    torch.cuda.synchronize()
+    for k in range(2):
+        want = before[k].clone()
+        for p, i in enumerate(idx[k].cpu().tolist()):
+            want[i] = aux_rows[k][p]
+        assert torch.equal(host.emb_l[k].weight.data, want), k

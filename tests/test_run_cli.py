@@ -46,7 +46,7 @@ def test_run_matches_oracle_trainer(capsys):
     ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
     batches = _Loader(_loader(ln_emb, B, nb, 5))
     test_batches = _loader(ln_emb, B, 3, 77)              # the rank-0 test loop (main_no_ddp.py:478-494)
-    want_acc = []
+    want_acc, want_auc = [], []
     # oracle
     torch.set_num_threads(1)
     np.random.seed(seed)
@@ -68,6 +68,8 @@ def test_run_matches_oracle_trainer(capsys):
                 ok += int((torch.round(Z) == Tt).sum())
                 tot += Tt.shape[0]
             want_acc.append(100 * ok / tot)
+            from sklearn.metrics import roc_auc_score
+            want_auc.append(roc_auc_score(torch.cat([b[3] for b in test_batches]).numpy().ravel(), torch.cat(Zs).numpy().ravel()))
             # a sample whose score sits within ~1e-5 of 0.5 could round either way on the GPU
             assert min(float((Z - 0.5).abs().min()) for Z in Zs) > 2e-5
     # Run
@@ -88,6 +90,9 @@ def test_run_matches_oracle_trainer(capsys):
     got_acc = [float(x) for x in re.findall(r"Test accuracy = ([0-9.eE+-]+)%", printed)]
     assert printed.count("Testing at") == 3 and len(want_acc) == 3          # j = 5, 10 and the last iteration
     np.testing.assert_allclose(got_acc, want_acc, rtol=0, atol=1e-9)
+    # ... and the AUC of the same scores (ops.roc_auc: device-side rank sum) against sklearn on the oracle's scores
+    got_auc = [float(x) for x in re.findall(r"Test AUC = ([0-9.eE+-]+)", printed)]
+    np.testing.assert_allclose(got_auc, want_auc, rtol=0, atol=2e-4)        # (192 test samples: one swapped pair moves it 1e-4)
     eng.cg.ctx.check()
     for k in range(len(ln_emb)):
         assert torch.equal(eng.cg.occupancy_tables[k].cpu(), otr.occ[k]), k
@@ -311,3 +316,105 @@ def test_run_device_rng_lookahead_plan_equals_boundary_plan(capsys, monkeypatch)
     assert torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, b)
+
+
+def test_roc_auc_rank_sum_against_sklearn():
+    """ops.roc_auc on the device = sklearn.metrics.roc_auc_score, ties included (scores quantised to 64 levels), and NaN for a
+    one-class target."""
+    from sklearn.metrics import roc_auc_score
+    from cdlrm_amd import ops
+    rng = np.random.RandomState(3)
+    for n, levels in ((10, 0), (4097, 0), (20000, 64), (20000, 2)):
+        s = rng.rand(n).astype(np.float32)
+        if levels:
+            s = np.round(s * levels) / levels
+        t = (rng.rand(n) < 0.3 + 0.4 * s).astype(np.float32)
+        got = ops.roc_auc(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda())
+        assert abs(got - roc_auc_score(t, s)) < 1e-9, (n, levels)
+    assert np.isnan(ops.roc_auc(torch.rand(8).cuda(), torch.ones(8).cuda()))
+
+
+def test_mlperf_auc_threshold_stops_training(capsys):
+    """--mlperf-auc-threshold (parsed and unused by the reference, main_no_ddp.py:119-120): training stops at the first test
+    whose AUC reaches it."""
+    from cdlrm_amd.main_no_ddp import ProcessArgs, Run
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    args = ProcessArgs(FLAGS + ["--test-freq=3", "--mlperf-auc-threshold=0.01"])
+    ln_emb = np.array([3000, 50, 7, 1200, 40000])
+    m_spa, B = 16, 64
+    ln_bot = np.array([13, 32, 16])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+    batches = _Loader(_loader(ln_emb, B, 12, 5))
+    test_batches = _loader(ln_emb, B, 2, 77)
+    np.random.seed(11)
+    torch.manual_seed(11)
+    host = O.init_host_tables([int(n) for n in ln_emb], m_spa)
+    eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+    for k in range(len(ln_emb)):
+        eg.emb_l[k].weight.data = host[k].clone()
+    eg.pin()
+    capsys.readouterr()
+    Run(0, m_spa, ln_emb, ln_bot, ln_top, batches, test_batches, None, None, None, eg, args)
+    printed = capsys.readouterr().out
+    assert printed.count("Testing at") == 1 and "MLPerf threshold reached at 3/12" in printed
+    assert len(re.findall(r"Loss = ", printed)) == 3        # iterations 1, 2, 3 printed, nothing after the stop
+
+
+def test_evict_victim_cache_matches_oracle(capsys):
+    """--evict-victim-cache (main_no_ddp.py:96 parses it, model_no_ddp.py:187 records victim_cache_entries, nothing uses
+    either): here the trained aux rows of a batch's MISSES go back to their host rows (and to their copies among the window's
+    victim rows) behind every step -- `emb_tables[k].weight[missing] = cache[k].weight[aux]`, last occurrence of an index
+    wins.  Run against the oracle's arm of the same definition: loss per iteration 1e-5, tags bit-exact, host tables equal;
+    and the flag changes the result (without it the host rows of missed indices keep their initial values)."""
+    from cdlrm_amd.main_no_ddp import ProcessArgs, Run
+    from cdlrm_amd.model_no_ddp import Embedding_Table_Group
+    ln_emb = np.array([3000, 50, 7, 1200, 40000])
+    m_spa, B, L, nb, seed = 16, 64, 4, 14, 11
+    ln_bot = np.array([13, 32, 16])
+    nf = len(ln_emb) + 1
+    ln_top = np.array([m_spa + nf * (nf - 1) // 2, 32, 1])
+    batches = _Loader(_loader(ln_emb, B, nb, 5))
+    torch.set_num_threads(1)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    host_o = O.init_host_tables([int(n) for n in ln_emb], m_spa)
+    otr = O.OracleTrainer([int(n) for n in ln_emb], m_spa, ln_bot, ln_top, cache_size=40, num_ways=4, mini_batch_size=B,
+                          lr=0.1, lr_embeds=0.3, lookahead=L, table_agg_freq=5, seed=seed,
+                          host_tables=[h.clone() for h in host_o], evict_victim_cache=True)
+    n_dup = 0
+    for j, (X, lS_o, idx, T) in enumerate(batches):
+        if j % L == 0:
+            otr.refill(torch.cat([b[2] for b in batches[j:j + L]], dim=1))
+        otr.step(j, X, lS_o, idx, T)
+    changed = sum(int((otr.host[k] != host_o[k]).any(1).sum()) for k in range(len(ln_emb)))
+    assert changed > 100            # the arm does something: rows of missed indices were written
+
+    def run(flags):
+        args = ProcessArgs(FLAGS + flags)
+        eg = Embedding_Table_Group(m_spa, ln_emb, init="empty_meta")
+        for k in range(len(ln_emb)):
+            eg.emb_l[k].weight.data = host_o[k].clone()
+        eg.pin()
+        capsys.readouterr()
+        eng = Run(0, m_spa, ln_emb, ln_bot, ln_top, batches, None, None, None, None, eg, args)
+        printed = capsys.readouterr().out
+        return eng, eg, [float(x) for x in re.findall(r"Loss = ([0-9.eE+-]+),", printed)]
+
+    eng, eg, got = run(["--evict-victim-cache"])
+    want = np.array([l[0] for l in otr.losses])
+    expect = np.concatenate([[(want[0] + want[1]) / 2], want[2:]])
+    np.testing.assert_allclose(np.array(got), expect, rtol=1e-5)
+    eng.cg.ctx.check()
+    for k in range(len(ln_emb)):
+        assert torch.equal(eng.cg.occupancy_tables[k].cpu(), otr.occ[k]), k
+        np.testing.assert_allclose(eg.emb_l[k].weight.data.numpy(), otr.host[k].numpy(), rtol=1e-5, atol=1e-6)
+    _, eg0, got0 = run([])
+    assert sum(int((eg0.emb_l[k].weight.data != eg.emb_l[k].weight.data).any(1).sum()) for k in range(len(ln_emb))) > 100
+    assert not np.allclose(got0, got, rtol=1e-7, atol=0)
+
+
+def test_evict_victim_cache_refuses_more_than_one_rank():
+    from cdlrm_amd.main_no_ddp import ProcessArgs
+    args = ProcessArgs(FLAGS + ["--evict-victim-cache"])
+    assert args.evict_victim_cache is True
