@@ -122,7 +122,12 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
     constexpr int NRA = A_KC ? IM : 4 * IM;             // LDS read instructions per group and wave: A fragments ...
     constexpr int NRD = NRA + (B_KC ? JN : 4 * JN);     // ... and all
     static_assert(NS >= 3 && NS <= 4 && NS * STAGE * 4 <= 160 * 1024, "ring does not fit");
-    static_assert(NRD + 4 * NPW <= MG && NRD + 16 <= MG, "schedule does not fit the group");
+    // the schedule of a 16-deep group (MG MFMA slots): the NRD reads of the next group behind the first MFMAs, then one DMA piece
+    // every PSTEP-th MFMA; in the second group the wait + barrier sit TAILC + NRD MFMAs before its end (the next tile's first
+    // reads behind them, the last TAILC MFMAs cover the reads' latency)
+    constexpr int PSTEP = (MG - NRD) / NPW >= 4 ? 4 : (MG - NRD) / NPW;
+    constexpr int TAILC = MG - NRD >= 16 ? 16 : (MG - NRD) / 2;
+    static_assert(PSTEP >= 1 && NRD + PSTEP * (NPW - 1) < MG && TAILC >= 4, "schedule does not fit the group");
     // ONE LDS object (a second one beside an LDS-DMA staging array makes hipcc wait vmcnt(0) before every fragment read)
     __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
 
@@ -322,14 +327,14 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
             else g3_mfma(acc[i][j], bfrag(0, j, c), afrag(0, i, c));
             if (m >= MG - IM) colsum_add(0, m - (MG - IM));
             if (m < NRD) rd(pa0, pa1, pb0, pb1, 1, 1, m);
-            if (!(G3_ABL & 1) && m >= NRD && (m - NRD) % 4 == 0 && (m - NRD) / 4 < NPW) {
-                if (issue) dma_piece((m - NRD) / 4, nxt);
+            if (!(G3_ABL & 1) && m >= NRD && (m - NRD) % PSTEP == 0 && (m - NRD) / PSTEP < NPW) {
+                if (issue) dma_piece((m - NRD) / PSTEP, nxt);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- group 1: MFMAs on fragment buffer 1; in front of its last NRD + 16 MFMAs the wait + barrier that publish tile
         //      t+1, then the reads of tile t+1's first group (fragment buffer 0 is free)
-        constexpr int MB = MG - NRD - 16;
+        constexpr int MB = MG - NRD - TAILC;
 #pragma unroll
         for (int m = 0; m < MG; ++m) {
             const int c = m / (IM * JN), blk = m % (IM * JN), i = blk / JN, j = blk % JN;
@@ -508,9 +513,14 @@ static bool gemm3_try(const GemmArgs& g, int splits, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int64_t tiles = cdiv(g.M, 128) * cdiv(g.N, 128) * splits;
-    const int64_t rounds = cdiv(tiles, n_cu);
-    if (tiles * 10 < rounds * n_cu * 9) return false;
-    launch_gemm3<A_KC, B_KC, 4, 4, 3>(g, splits, s);
+    // 128x128 tiles where they fill whole rounds of one workgroup per CU (>= 90 % of the last round's slots), else 64x128 tiles
+    // under the same rule (M = 8192 x 256-wide layers, per-rank batches of 4096 x 512-wide: 256 tiles)
+    auto fills = [&](int64_t tiles) { return tiles * 10 >= cdiv(tiles, n_cu) * n_cu * 9; };
+    const int64_t t128 = cdiv(g.M, 128) * cdiv(g.N, 128) * splits, t64 = cdiv(g.M, 64) * cdiv(g.N, 128) * splits;
+    // (short contractions, K <= 256, on k_gemm2's 64x64 tiles instead: c3 step 0.5594 against 0.5558 ms; on the 64x128 tiles: a tie)
+    const bool big = fills(t128);
+    if (big) launch_gemm3<A_KC, B_KC, 4, 4, 3>(g, splits, s);
+    else if (A_KC && fills(t64)) launch_gemm3<A_KC, B_KC, 2, 4, 3>(g, splits, s);
+    else return false;
     return true;
 }

@@ -698,6 +698,9 @@ class TrainEngine:
         # kernel (csrc/gemm_wide.h).  The bottom MLP's backward runs beside the weight gradients and never does (round 6: with
         # the hint on every GEMM the c3 step took 0.5790 ms against 0.5580 without, with it on these 0.5562).
         self.wide_gemm = True
+        # ... and the bottom MLP's forward (it runs at the end of the previous step, beside the next batch's take and slot sort:
+        # small kernels that fit beside a wide workgroup): its 512 -> 256 layer on 64x128 tiles, c3 0.5495 against 0.5522 ms
+        self.wide_gemm_bottom = True
         # --evict-victim-cache (main_no_ddp.py:96, parsed and unused by the reference): behind every step's embedding update
         # the trained aux rows of the batch's misses go back to their host rows and to their copies among the window's victim
         # rows (ops.victim_writeback).  One rank only; the step then runs un-pipelined (no take of the next batch ahead of
@@ -1175,7 +1178,7 @@ class TrainEngine:
         bot_acts = [X]
         for i, (l, act) in enumerate(self.bot):
             y = feat[:, 0, :] if i == len(self.bot) - 1 else buf["bot_y"][i]
-            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act)
+            ops.linear_fwd(cur, self.W[l], l.bias.data, y, act, alone=self.wide_gemm_bottom)
             bot_acts.append(y)
             cur = y
         if side_gather:
@@ -1504,7 +1507,7 @@ class TrainEngine:
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
                self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.top_wgrad_after,
-               self.fuse_gather, self.sort_after_fwd, self.wide_gemm,
+               self.fuse_gather, self.sort_after_fwd, self.wide_gemm, self.wide_gemm_bottom,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)

@@ -119,6 +119,9 @@ static void run(const char* name, int64_t M, int N, int64_t K) {
     one("gemm2 128x128", [&]() { launch2<true, B_KC, 2, 2>(g1); }, 0);
     one("gemm3 128x128 S3", [&]() { launch_gemm3<true, B_KC, 4, 4, 3>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 128)));
     one("gemm3 128x128 S4", [&]() { launch_gemm3<true, B_KC, 4, 4, 4>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 128)));
+    one("gemm2 64x64", [&]() { launch2<true, B_KC, 1, 1>(g1); }, 0);
+    one("gemm3 64x128 S3", [&]() { launch_gemm3<true, B_KC, 2, 4, 3>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 64)));
+    one("gemm3 64x128 S4", [&]() { launch_gemm3<true, B_KC, 2, 4, 4>(g1, 1, 0); }, (unsigned)(cdiv(N, 128) * cdiv(M, 64)));
     hipFree(A); hipFree(B); hipFree(bias); hipFree(mask); hipFree(C0); hipFree(C1);
 }
 // weight-gradient layout: dW[N, K] = dZ[M, N]^T X[M, K], split over the batch into `splits` slabs (+ the bias gradient's partials)
@@ -168,6 +171,14 @@ static void run_wgrad(const char* name, int64_t M, int N, int K, int splits) {
     hipFree(dZ); hipFree(X); hipFree(S0); hipFree(S1); hipFree(c0); hipFree(c1);
 }
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'n') {       // the narrow layers: 64x128 tiles
+        run<true>("forward 256<-512", 8192, 256, 512);
+        run<false>("dgrad 256<-128", 8192, 256, 128);
+        run<true>("forward 128<-256", 8192, 128, 256);
+        run<true>("forward 512<-512", 4096, 512, 512);
+        run<false>("dgrad 512<-512", 4096, 512, 512);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'w') {
         run_wgrad("wgrad 512x512", 8192, 512, 512, 16);
         run_wgrad("wgrad 512x480", 8192, 512, 480, 16);
