@@ -540,7 +540,10 @@ def main():
     # and the queue handles it before the next packet: measured on one box, 1500 steps, sampling EVERY launch costs the step
     # 0.007 ms (0.6473 / 0.6464 against 0.6397 / 0.6401 untimed).  So every SECOND launch of the timed region is sampled (10 of
     # the driver's 20 steps); runs beyond 4096 steps keep every --gather-sample'th
-    sample_every = min(2, max(1, a.gather_sample)) if a.steps <= 4096 else max(1, a.gather_sample)
+    # (round 6: every FOURTH launch of a short timed region -- 5 of the driver's 20 steps --: a sampled launch's completion
+    #  signal holds the training queue ~5-7 us in front of the next GEMM (visible as a gap in the kernel trace), and the line's
+    #  value should not pay for its own roofline measurement more than it must; the 3000-step default keeps every 4th as well)
+    sample_every = min(4, max(1, a.gather_sample)) if a.steps <= 4096 else max(1, a.gather_sample)
     if world > 1:       # a per-rank step is 3x shorter and latency-bound: the same 7 us weigh 3x more there
         sample_every = max(sample_every, min(8, max(1, a.gather_sample)))
     # the events exist before the timed region starts; their handles are cells of the engine's launch tape

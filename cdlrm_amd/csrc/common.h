@@ -87,7 +87,8 @@ void cdlrm_set_error(const char* fmt, ...);
 //      k_gemm2: equal to fp32 rounding, not bit for bit.
 //      -DCDLRM_DEV builds ONLY (timing experiments that SKIP work; the shipped library refuses them): 1 = no embedding
 //      update, 2 = no slot sort
-//   7: 1 = the epilogues before round 5 (operands fetched behind, not ahead of, their use)
+//   7: bits: 1 = the epilogues before round 5 (operands fetched behind, not ahead of, their use); 2 = the fused gather +
+//      interaction forward on ONE slab slice (before round 6's double buffering) -- both bit-identical to the default
 // No key makes the shipped library skip work: a number measured with any of them set is a number for the same arithmetic.
 extern CDLRM_HIDDEN_DATA int g_cdlrm_debug[8];
 

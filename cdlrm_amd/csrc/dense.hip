@@ -872,15 +872,23 @@ struct IaGather {
     int64_t ldx4;               // pitch of the dense-feature rows, float4 words
 };
 
-template <int D4, int NS, bool G>
+// DB (round 6): the slab slice is DOUBLE-BUFFERED and the fragment reads run one 16-deep group ahead of the MFMAs.  With ONE
+// slice a wave -- one per SIMD, in-order -- stages slab s, waits out the LDS round trip, reads the first fragments, waits again and
+// only then issues MFMAs: ~250 cycles per slab in which its SIMD's matrix pipe idles, and with every row already on the die the
+// kernel still took 22.7 us for 10.7 us of MFMA time (tools/gather_warm_cold.py).  Here slab s+1 (the NEXT sample's slab 0 behind
+// the last one) is staged into the other slice in front of slab s's MFMAs and its first fragments are read behind slab s's last
+// group: no LDS latency is left in the MFMA stream.  Same operands in the same lanes, same MFMA order: bit-identical.
+template <int D4, int NS, bool G, bool DB = false>
 __global__ void __launch_bounds__(256) k_interact_fwd_s(const float* __restrict__ feat, IaGather ga, int64_t B, int F,
                                                         int itself, float* __restrict__ R, int64_t ld_r) {
     constexpr int D = 4 * D4, CS = D4 / NS, DS = 4 * CS, PITCH = DS + 4, NR = CS / 2;
     constexpr int OSW = D + 532;                    // output staging row: D + up to 528 pairs + the pad word
+    constexpr int TSW = (DB ? 2 : 1) * 32 * PITCH;  // slab slice(s) of a wave
+    static_assert(!DB || (NS % 2 == 0 && DS / 16 >= 1), "double buffering alternates two slices over an even number of slabs");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* Ts = smem + wave * (32 * PITCH + OSW);
-    float* Os = Ts + 32 * PITCH;
+    float* Ts = smem + wave * (TSW + OSW);
+    float* Os = Ts + TSW;
     const int64_t nw = (int64_t)gridDim.x * 4;
     int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= B) return;
@@ -933,6 +941,95 @@ __global__ void __launch_bounds__(256) k_interact_fwd_s(const float* __restrict_
 #pragma unroll
     for (int s = 0; s < NS; ++s) prefetch(s, b);
     if constexpr (G) load_slots(min(b + nw, B - 1));
+    if constexpr (DB) {
+        // ---- the double-buffered form (see above).  Slices Ts (even slabs) and Ts + 32 * PITCH (odd slabs).
+        float* const T0 = Ts;
+        float* const T1 = Ts + 32 * PITCH;
+        constexpr int NG = DS / 16;                 // 16-deep groups per slab
+#pragma unroll
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<v4f*>(T0 + doff[i]) = nxt[0][i];      // the first sample's slab 0
+        const int toff = l16 * PITCH + 4 * g4;
+        float4 fa0 = *reinterpret_cast<const float4*>(T0 + toff);                              // fragments of (slab 0, group 0)
+        float4 fa1 = *reinterpret_cast<const float4*>(T0 + toff + 16 * PITCH);
+        auto one_db = [&](int64_t b) __attribute__((always_inline)) {
+            const int64_t bn = min(b + nw, B - 1);
+            if constexpr (G) {
+                make_ptrs(bn);
+                load_slots(min(bn + nw, B - 1));
+            }
+            prefetch(0, bn);                            // nxt[0] is free: this sample's slab 0 is staged
+            if (lane < CS) *reinterpret_cast<v4f*>(Os + 4 * lane) = *reinterpret_cast<const v4f*>(T0 + 4 * lane);    // row 0 of slab 0
+            v4f acc00 = {0.f, 0.f, 0.f, 0.f}, acc10 = acc00, acc11 = acc00;
+            // the j-th MFMA of a 16-deep group (the order of k_interact_fwd_p / the single-slice form)
+            auto mf = [&](int j, const float4& a0, const float4& a1) __attribute__((always_inline)) {
+                const int c = j / 3, w = j % 3;
+                const float x0 = c == 0 ? a0.x : c == 1 ? a0.y : c == 2 ? a0.z : a0.w;
+                const float x1 = c == 0 ? a1.x : c == 1 ? a1.y : c == 2 ? a1.z : a1.w;
+                if (w == 0) acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x0, acc00, 0, 0, 0);
+                else if (w == 1) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, x0, acc10, 0, 0, 0);
+                else acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, x1, acc11, 0, 0, 0);
+            };
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float* cur = (s & 1) ? T1 : T0;
+                float* oth = (s & 1) ? T0 : T1;
+                // Slab s: NG groups of 12 MFMAs.  In their shadows, ONE instruction per MFMA slot (the wave is alone on its SIMD and
+                // in order: whatever is not placed between two MFMAs is paid in full): the next group's two fragment reads, then --
+                // first group only -- the next slab's staging into the other slice (its last readers, slab s-1's MFMAs, are done),
+                // the dense part of the output row and the register refill with the next sample's slab.
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float4 a0 = fa0, a1 = fa1;
+                    const float* np_ = (g + 1 < NG) ? cur + toff + 16 * (g + 1) : oth + toff;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) {
+                        mf(j, a0, a1);
+                        const int k = g * 12 + j;           // slot inside the slab
+                        if (k >= 0 && k < NR) {
+                            const int sn = s + 1 < NS ? s + 1 : 0;       // the slab being staged (the NEXT sample's slab 0 behind the last)
+                            *reinterpret_cast<v4f*>(oth + doff[k]) = nxt[sn][k];
+                        }
+                        if (k == NR && s + 1 < NS && lane < CS) *reinterpret_cast<v4f*>(Os + (s + 1) * DS + 4 * lane) = nxt[s + 1][0];
+                        if (k == NR + 1 && s + 1 < NS) prefetch(s + 1, bn);
+                        // (with one group per slab the reads follow the staging; else they go first in the LAST group)
+                        if (j == (NG == 1 ? NR + 2 : 0) && g == NG - 1) {
+                            fa0 = *reinterpret_cast<const float4*>(np_);
+                            fa1 = *reinterpret_cast<const float4*>(np_ + 16 * PITCH);
+                        }
+                        if (j == 0 && g + 1 < NG) {
+                            fa0 = *reinterpret_cast<const float4*>(np_);
+                            fa1 = *reinterpret_cast<const float4*>(np_ + 16 * PITCH);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            // the output row: accumulators -> staging row -> whole 16-byte words.  (Deferred into the next sample's first slab --
+            // a second staging row, the accumulators parked in 12 more registers, its LDS writes / reads / stores one per MFMA
+            // slot -- it measured SLOWER: 21.1 / 24.2 us warm / cold against 20.3 / 23.5, tools/gather_warm_cold.py; removed.)
+            float* out = R + b * ld_r;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i0 = 4 * g4 + r, i1 = 16 + 4 * g4 + r;
+                if (i0 < F && l16 < i0 + off) Os[D + pair_base(i0, itself) + l16] = acc00[r];
+                if (i1 < F) Os[D + pair_base(i1, itself) + l16] = acc10[r];
+                if (i1 < F && 16 + l16 < i1 + off) Os[D + pair_base(i1, itself) + 16 + l16] = acc11[r];
+            }
+            const int width = D + pair_base(F, itself);
+            if (lane < 4) Os[width + lane] = 0.f;
+            const int W4 = (width + 3) >> 2;
+            constexpr int NST = (D4 + 132 + 63) / 64;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int e = min(64 * k + lane, W4 - 1);
+                *reinterpret_cast<v4f*>(out + 4 * e) = *reinterpret_cast<const v4f*>(Os + 4 * e);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        one_db(b);
+        for (b += nw; b < B; b += nw) one_db(b);
+        return;
+    }
     auto one = [&](int64_t b) __attribute__((always_inline)) {
         const int64_t bn = min(b + nw, B - 1);
         if constexpr (G) {
@@ -1411,10 +1508,22 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     } while (0)
     // (slabs of 256 or 512 B instead of 128 -- NS = 2, 1 at D = 128 -- measured the same in the step and 24.6-25.8 / 26.6-28.3 against
     //  27.2 us stand-alone; the variants were removed)
-    if (D == 32) GIFWD(8, s32);
-    else if (D == 64) GIFWD(16, s64);
-    else if (D == 128) GIFWD(32, s128);
-    else GIFWD(64, s256);
+    // the double-buffered form (round 6; cdlrm_debug_set(7, 2): the single-slice form, for A/Bs -- bit-identical)
+    static size_t d64 = 0, d128 = 0, d256 = 0;
+    const size_t lds_d = (size_t)4 * (2 * 32 * 36 + D + 532) * sizeof(float);
+#define GIFWD_DB(D4_, A_)                                                                                             \
+    do {                                                                                                              \
+        int rc = interact_set_lds(k_interact_fwd_s<D4_, D4_ / 8, true, true>, lds_d, &A_);                            \
+        if (rc) return rc;                                                                                            \
+        hipExtLaunchKernelGGL((k_interact_fwd_s<D4_, D4_ / 8, true, true>), dim3((unsigned)gp), dim3(256), lds_d,     \
+                              (hipStream_t)stream, ev0, ev1, 0, x, ga, B, F, itself, R, ld_r);                        \
+    } while (0)
+    const bool db = !(g_cdlrm_debug[7] & 2);
+    if (D == 32) GIFWD(8, s32);                    // (one slab per sample: nothing to alternate)
+    else if (D == 64) { if (db) GIFWD_DB(16, d64); else GIFWD(16, s64); }
+    else if (D == 128) { if (db) GIFWD_DB(32, d128); else GIFWD(32, s128); }
+    else { if (db) GIFWD_DB(64, d256); else GIFWD(64, s256); }
+#undef GIFWD_DB
 #undef GIFWD
     if (se) CDLRM_HIP_CHECK(hipEventRecord(se, (hipStream_t)stream));
     CDLRM_LAUNCH_CHECK();

@@ -43,7 +43,7 @@ struct GemmArgs {
 static inline GemmArgs gemm_args() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.fastep = g_cdlrm_debug[7] == 1 ? 0 : 1;       // (development switch: the epilogues before round 5)
+    g.fastep = (g_cdlrm_debug[7] & 1) ? 0 : 1;       // (development switch: the epilogues before round 5)
     return g;
 }
 
