@@ -113,6 +113,9 @@ __device__ unsigned long long g3_stamps[8 * 4096];
 #define G3_STAMP_AT(slot)
 #endif
 
+// (Round 6, measured and not kept: NS = 2 -- a 64 KB ring, TWO workgroups per CU at 256 registers each, one's prologue / store
+//  tail under the other's MFMAs -- for batches with many tiles per CU: 281 / 290 us against 286 / 304 at M = 65536, scratch
+//  spills in the tail tiles; a persistent tile loop would be the real remedy for the ~3 us between a CU's workgroups there.)
 template <bool A_KC, bool B_KC, int IM, int JN, int NS>
 __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
     constexpr int BM = 32 * IM, BN = 32 * JN;

@@ -276,6 +276,9 @@ def main():
                 reps = 10 if M > 8192 else 30
                 r = dict(M=M, N=N, K=K, gflop=fl / 1e9)
                 r["fwd_ours_us"] = timeit(lambda: ops.linear_fwd(X, W, b, Y, 1), reps)                     # bias + ReLU fused
+                # ... and as the training step launches its top MLP (CDLRM_GEMM_ALONE: the wide kernel where its tiles fill the chip)
+                r["fwd_ours_alone_us"] = timeit(lambda: ops.linear_fwd(X, W, b, Y, 1, alone=True), reps)
+                r["dgrad_ours_alone_us"] = timeit(lambda: ops.linear_bwd(X, W, Y, dY, dX, None, None, 0, work, x_act=1, alone=True), reps)
                 r["fwd_vendor_us"] = timeit(lambda: torch.addmm(b, X, Wt, out=Y), reps)                    # bias, no activation
                 r["fwd_vendor_relu_us"] = timeit(lambda: torch.relu_(torch.addmm(b, X, Wt, out=Y)), reps)
                 r["dgrad_ours_us"] = timeit(lambda: ops.linear_bwd(X, W, Y, dY, dX, None, None, 0, work, x_act=1), reps)  # act' fused
@@ -283,12 +286,15 @@ def main():
                 r["wgrad_ours_us"] = timeit(lambda: ops.mlp_wgrad(plan), reps)                             # dW + db (+ slab reduce)
                 r["wgrad_vendor_us"] = timeit(lambda: torch.mm(dYt, X, out=dW), reps)
                 r["wgrad_vendor_db_us"] = timeit(lambda: (torch.mm(dYt, X, out=dW), torch.sum(dY, 0, out=db)), reps)
-                for k in ("fwd_ours", "fwd_vendor", "dgrad_ours", "dgrad_vendor", "wgrad_ours", "wgrad_vendor"):
+                for k in ("fwd_ours", "fwd_ours_alone", "fwd_vendor", "dgrad_ours", "dgrad_ours_alone", "dgrad_vendor", "wgrad_ours", "wgrad_vendor"):
                     r[k + "_tflops"] = fl / r[k + "_us"] / 1e6
                 rows.append(r)
-                print("M=%6d N=%4d K=%4d | fwd ours %7.1f us (%5.1f TF) vendor %7.1f (+relu %7.1f) | dgrad ours %7.1f vendor %7.1f | "
-                      "wgrad ours %7.1f vendor %7.1f (+db %7.1f)" % (M, N, K, r["fwd_ours_us"], r["fwd_ours_tflops"], r["fwd_vendor_us"],
-                                                                    r["fwd_vendor_relu_us"], r["dgrad_ours_us"], r["dgrad_vendor_us"],
+                print("M=%6d N=%4d K=%4d | fwd ours %7.1f us (%5.1f TF; alone-hint %7.1f) vendor %7.1f (+relu %7.1f) | dgrad ours %7.1f "
+                      "(alone-hint %7.1f) vendor %7.1f | "
+                      "wgrad ours %7.1f vendor %7.1f (+db %7.1f)" % (M, N, K, r["fwd_ours_us"], r["fwd_ours_tflops"], r["fwd_ours_alone_us"],
+                                                                    r["fwd_vendor_us"],
+                                                                    r["fwd_vendor_relu_us"], r["dgrad_ours_us"], r["dgrad_ours_alone_us"],
+                                                                    r["dgrad_vendor_us"],
                                                                     r["wgrad_ours_us"], r["wgrad_vendor_us"], r["wgrad_vendor_db_us"]),
                       flush=True)
                 del X, W, Y, dY, dX, work, plan

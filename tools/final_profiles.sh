@@ -5,7 +5,7 @@
 # of tools/profile_round.sh (kernel stats + trace, FETCH_SIZE / WRITE_SIZE of the gather, MFMA busy) with their summaries.
 # The c5 whole-window line (8000 steps, ~2 min) runs with C5=1 only.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
