@@ -521,6 +521,9 @@ static bool gemm3_try(const GemmArgs& g, int splits, hipStream_t s) {
     auto fills = [&](int64_t tiles) { return tiles * 10 >= cdiv(tiles, n_cu) * n_cu * 9; };
     const int64_t t128 = cdiv(g.M, 128) * cdiv(g.N, 128) * splits, t64 = cdiv(g.M, 64) * cdiv(g.N, 128) * splits;
     // (short contractions, K <= 256, on k_gemm2's 64x64 tiles instead: c3 step 0.5594 against 0.5558 ms; on the 64x128 tiles: a tie)
+    // (ragged tiles -- N = 480: a quarter of the tiles take the generic epilogue behind the loop -- only where every CU has ONE
+    //  tile: at M = 65536 the 480 <- 512 dgrad took 333 us here against 304 on k_gemm2, at M = 8192 44.4 against 47.2)
+    if ((g.N % 128 != 0 || g.M % 64 != 0) && t128 > n_cu) return false;
     const bool big = fills(t128);
     if (big) launch_gemm3<A_KC, B_KC, 4, 4, 3>(g, splits, s);
     else if (A_KC && fills(t64)) launch_gemm3<A_KC, B_KC, 2, 4, 3>(g, splits, s);
