@@ -473,6 +473,16 @@ __global__ void __launch_bounds__(256) k_gemm3(GemmArgs g) {
 #endif
 }
 
+// (Round 6, built, measured and removed -- tools/gemm3_bench.hip p, profiles/r06_gemm3_vs_gemm2.txt: a PERSISTENT form for batches
+//  with several tiles per CU (c5: 8 per CU at M = 65536) -- one workgroup per CU walking its tiles, the K-tile ring running on
+//  across output tiles, the next tile's first fragments read behind a barrier in front of the progressive epilogue, the
+//  accumulators restarted by an init-form MFMA (SrcC = 0) instead of VALU moves; bit-identical, correct on every shape tried
+//  (K = 64 ... 512, N = 128 ... 512, ragged workgroup counts) -- 281.0 / 306.5 us against 285.2 / 301.3 for this kernel at
+//  65536 x 512 x 512 forward / dgrad: no gain.  A tile takes ~35 us either way (81 k cycles at 2.3 GHz where prologue + loop +
+//  tail of ONE workgroup are 77 k at M = 8192): at this size the part is clock-limited under the MFMA stream, and what the
+//  vendor library's kernel has is less LDS traffic per MFMA (128x128 accumulators per wave).  A 256x128 tile (128x64 per wave)
+//  of THIS kernel does not fit 256 VGPRs beside the asm MFMAs' "+v" accumulators (scratch spills in the MFMA stream).)
+
 // what k_gemm3 can take: A contraction-contiguous, 16-byte loadable rows, every split's contraction range a multiple of 32
 template <bool A_KC, bool B_KC>
 static inline bool gemm3_applies(const GemmArgs& g) {

@@ -16,6 +16,7 @@ import subprocess
 import sys
 
 WAIT = 12
+VALU_TO_MFMA = 3     # wait states between a VALU write of a register and an asm MFMA that reads it as its accumulator
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 OFFLOAD = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
 
@@ -38,7 +39,8 @@ def split_ops(rest):
 
 
 def check_function(name, lines):
-    pending = {}        # reg -> wait states still required
+    pending = {}        # reg -> wait states still required (written by an asm MFMA)
+    vwritten = {}       # reg -> wait states since a VALU instruction wrote it (an asm MFMA reading it as SrcC needs VALU_TO_MFMA)
     findings = []
     for ln, text in lines:
         ins = text.split("//")[0].split(";")[0].strip()
@@ -60,19 +62,30 @@ def check_function(name, lines):
                 bad |= {r for r in (srcc | dst) if pending.get(r, 0) > 0}
             if bad:
                 findings.append((ln, ins, sorted(bad)))
+            # the asm forms of gemm_wide.h: VGPR accumulator tied in place, or SrcC the inline constant 0 (g3_mfma_init)
+            asm_form = all(r < 1000 for r in dst) and (srcc == dst or (len(ops) > 3 and ops[3] == "0"))
+            if asm_form and srcc == dst:
+                late = {r for r in dst if r in vwritten and vwritten[r] < VALU_TO_MFMA}
+                if late:
+                    findings.append((ln, ins + "    [a VALU write of the accumulator too close in front]", sorted(late)))
             cost = 8
+            for r in list(vwritten):
+                vwritten[r] += cost
+                if vwritten[r] > 16:
+                    del vwritten[r]
             for r in list(pending):
                 pending[r] -= cost
                 if pending[r] <= 0:
                     del pending[r]
             # only the asm form (VGPR accumulator tied in place) is unknown to the compiler; an MFMA it emitted itself
             # (the progressive epilogue's builtin: AGPR accumulators, dst != SrcC) is covered by its own hazard recognizer
-            if srcc == dst and all(r < 1000 for r in dst):
+            if asm_form:
                 for r in dst:
                     pending[r] = WAIT
             continue
         if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
             pending.clear()             # what follows in the text is not reached by falling through
+            vwritten.clear()
             continue
         if op == "s_nop":
             cost = int(ops[0], 0) + 1
@@ -84,6 +97,14 @@ def check_function(name, lines):
             pending[r] -= cost
             if pending[r] <= 0:
                 del pending[r]
+        for r in list(vwritten):
+            vwritten[r] += cost
+            if vwritten[r] > 16:
+                del vwritten[r]
+        if op.startswith("v_") and ops:
+            for r in regs_of(ops[0]):
+                if r < 1000:
+                    vwritten[r] = 0
     return findings
 
 
