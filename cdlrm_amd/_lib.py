@@ -66,6 +66,12 @@ PROTOTYPES = {
     "cdlrm_embbag_bwd_sgd": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),
     "cdlrm_embbag_bwd_prepare": (C.c_int, [vp, vp, c_i64, vp, vp]),
     "cdlrm_embbag_bwd_apply": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),
+    "cdlrm_embbag_bwd_apply_rest": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp]),
+    "cdlrm_embbag_bwd_once_flags": (C.c_int, [vp, vp, c_i64, vp]),
+    "cdlrm_embbag_bwd_sorted_bytes": (C.c_uint64, [c_i32, c_i32, c_i64]),
+    "cdlrm_embbag_bwd_prepare_window": (C.c_int, [vp, vp, c_i64, c_i64, c_i32, c_i64, c_i32, c_i32, vp, vp]),
+    "cdlrm_embbag_bwd_sorted_views": (C.c_int, [vp, vp, c_i32, c_i64, c_i32, vp, vp, vp]),
+    "cdlrm_embbag_bwd_apply_sorted": (C.c_int, [vp, c_i64, vp, c_i64, c_i64, c_f32, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp]),
     "cdlrm_qr_embbag_fwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "cdlrm_qr_embbag_bwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp]),
     "cdlrm_bag_fwd": (C.c_int, [vp, vp, c_i64, c_i64, vp, c_i64, c_i32, vp, vp, vp]),
@@ -94,6 +100,7 @@ PROTOTYPES = {
     "cdlrm_gather_interact_supported": (C.c_int, [vp]),
     "cdlrm_gather_interact_fwd": (C.c_int, [vp, vp, c_i64, vp, c_i64, c_i64, c_i32, vp, c_i64, vp]),
     "cdlrm_gather_interact_bwd": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i32, c_i32, vp, vp]),
+    "cdlrm_gather_interact_bwd_sgd": (C.c_int, [vp, vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i32, c_i32, vp, vp, c_i64, c_f32, vp]),
     "cdlrm_linear_fwd": (C.c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i32, vp]),
     "cdlrm_linear_bwd_work_bytes": (c_u64, [c_i64, c_i32, c_i32]),
     "cdlrm_linear_bwd": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i32, c_i32,

@@ -873,6 +873,9 @@ struct IaGather {
     const int32_t* slots;       // [T, n] slot ids of the batch (cdlrm_embbag_probe / cdlrm_embbag_take)
     int64_t n;
     int64_t ldx4;               // pitch of the dense-feature rows, float4 words
+    const uint8_t* once;        // backward, ONCE: lookups whose slot occurs once in the batch (embbag_bwd.hip: the slot sort),
+    int64_t ld_once;            //                 table t's flags at once + t * ld_once
+    float lr;                   //                 learning rate of the embedding rows
 };
 
 // DB (round 6): the slab slice is DOUBLE-BUFFERED and the fragment reads run one 16-deep group ahead of the MFMAs.  With ONE
@@ -1176,7 +1179,14 @@ __global__ void __launch_bounds__(256) k_interact_bwd_p(const float* __restrict_
 // Needs F > 16, a 16-byte aligned dfeat / dR and ld_r % 4 == 0.
 // G (cdlrm_gather_interact_bwd): as in the forward kernel -- the rows are read again from the cache (they are still the
 // forward's: the embedding update of this batch runs behind this kernel), `feat` is the dense feature alone.
-template <int D4, int NS, bool G>
+// ONCE (cdlrm_gather_interact_bwd_sgd, round 6): a lookup whose slot no other lookup of the batch shares (flagged by the
+// backward's slot sort) gets its row's SGD update HERE: the lane that holds 16 B of the row's gradient holds the same 16 B of the
+// row in the slab slice (the operand it was staged as), so W[slot] = fma(-lr, 0 + g, W[slot]) -- exactly what the sorted path
+// computes for a run of one: a single addend has no order -- leaves as the one store that used to carry the gradient.  The
+// gradient row is NOT written (cdlrm_embbag_bwd_apply_rest never reads it): per such lookup 4D bytes written instead of 4D written
+// + 4D + 4D read + 4D written, and no work for it in the sorted path.  Nobody else reads that row in this batch (that is what
+// "once" means), the forward has read it, the next reader is ordered behind the embedding update as before.
+template <int D4, int NS, bool G, bool ONCE = false>
 __global__ void __launch_bounds__(256, (G && D4 <= 32) ? 2 : 1) k_interact_bwd_s(const float* __restrict__ feat, IaGather ga,
                                                         const float* __restrict__ dR, int64_t ld_r, int64_t B, int F,
                                                         int itself, int x_act, float* __restrict__ dfeat) {
@@ -1198,6 +1208,7 @@ __global__ void __launch_bounds__(256, (G && D4 <= 32) ? 2 : 1) k_interact_bwd_s
     if (b >= B) return;
     int soff[NR], doff[NR];
     int srow[G ? NR : 1];
+    int orow[ONCE ? NR : 1];
     const v4f* wbase[G ? NR : 1];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -1207,21 +1218,33 @@ __global__ void __launch_bounds__(256, (G && D4 <= 32) ? 2 : 1) k_interact_bwd_s
         if constexpr (G) {
             const int t = max(min(row, F - 1) - 1, 0);
             srow[i] = t * (int)ga.n;
+            if constexpr (ONCE) orow[i] = t * (int)ga.ld_once;
             wbase[i] = ga.weight + (ga.tab[t].row_base * D4 + c);
         }
     }
+    static_assert(!ONCE || (G && CS == 8 && DS == 32), "the output store's lane -> (row, word) map is the staging map");
     v4f nxt[NS][NR], gn[NG];
     const v4f* pn[G ? NR : 1];
     int32_t sl[G ? NR : 1];
+    // ONCE: the row pointers and flags of the sample being worked (pn / fn are the next sample's by then; fl: two ahead)
+    const v4f* pc[ONCE ? NR : 1];
+    uint8_t fl[ONCE ? NR : 1], fn[ONCE ? NR : 1], fc[ONCE ? NR : 1];
     auto load_slots = [&](int64_t bb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) sl[i] = ga.slots[srow[i] + bb];
+        for (int i = 0; i < NR; ++i) {
+            sl[i] = ga.slots[srow[i] + bb];
+            if constexpr (ONCE) fl[i] = ga.once[orow[i] + bb];
+        }
     };
     auto make_ptrs = [&](int64_t bb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const v4f* p = wbase[i] + (int64_t)sl[i] * D4;
-            if (i == 0 && lane < CS) p = reinterpret_cast<const v4f*>(feat) + bb * ga.ldx4 + soff[i];
+            if constexpr (ONCE) fn[i] = fl[i];
+            if (i == 0 && lane < CS) {
+                p = reinterpret_cast<const v4f*>(feat) + bb * ga.ldx4 + soff[i];
+                if constexpr (ONCE) fn[i] = 0;      // row 0 is the dense feature
+            }
             pn[i] = p;
         }
     };
@@ -1247,6 +1270,10 @@ __global__ void __launch_bounds__(256, (G && D4 <= 32) ? 2 : 1) k_interact_bwd_s
     auto one = [&](int64_t b) __attribute__((always_inline)) {
         const int64_t bn = min(b + nw, B - 1);
         if constexpr (G) {
+            if constexpr (ONCE) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) { pc[i] = pn[i]; fc[i] = fn[i]; }
+            }
             make_ptrs(bn);
             load_slots(min(bn + nw, B - 1));
         }
@@ -1300,8 +1327,20 @@ __global__ void __launch_bounds__(256, (G && D4 <= 32) ? 2 : 1) k_interact_bwd_s
                     for (int k = 0; k < 2; ++k) {
                         const int idx = min(64 * k + lane, nvalid - 1);     // clamped: spare lanes repeat the last word
                         const int row = idx >> 3, c4 = idx & 7;
-                        *reinterpret_cast<v4f*>(out + (16 * h + row) * D + n0 + 4 * c4) =
-                            *reinterpret_cast<const v4f*>(Os + row * 32 + 4 * c4);
+                        const v4f gv = *reinterpret_cast<const v4f*>(Os + row * 32 + 4 * c4);
+                        if constexpr (ONCE) {
+                            // (row, c4) of an unclamped lane is the (row, word) it staged as piece 2h + k: pc / fc are this row's
+                            if (64 * k + lane < nvalid && fc[2 * h + k]) {
+                                v4f w = *reinterpret_cast<const v4f*>(Ts + (16 * h + row) * PITCH + nl + 4 * c4);
+                                v4f a = {0.f, 0.f, 0.f, 0.f};
+                                a += gv;                    // the sorted path's sum of one addend (0 + g: -0 becomes +0 there too)
+                                w.x = fmaf(-ga.lr, a.x, w.x); w.y = fmaf(-ga.lr, a.y, w.y);
+                                w.z = fmaf(-ga.lr, a.z, w.z); w.w = fmaf(-ga.lr, a.w, w.w);
+                                *const_cast<v4f*>(pc[2 * h + k] + s * CS) = w;
+                                continue;
+                            }
+                        }
+                        *reinterpret_cast<v4f*>(out + (16 * h + row) * D + n0 + 4 * c4) = gv;
                     }
                 }
             }
@@ -1533,9 +1572,9 @@ extern "C" int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, i
     return 0;
 }
 
-extern "C" int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
-                                         const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act,
-                                         float* dfeat, void* stream) {
+static int cdlrm_gather_interact_bwd_core(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                               const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act,
+                               float* dfeat, const uint8_t* once, int64_t ld_once, float lr, void* stream) {
     CdlrmStopScope stop_scope;          // (first: every exit below flushes an attached completion event)
     CDLRM_REQUIRE(ctx && slots && x && dR && dfeat, "null argument");
     CDLRM_REQUIRE(ctx->weight, "cdlrm_ctx_bind_cache first");
@@ -1546,26 +1585,50 @@ extern "C" int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, i
                   "slot pitch / dense-feature rows");
     CDLRM_REQUIRE(ld_r % 4 == 0 && aligned16(dR) && ld_r >= ((D + npairs + 3) & ~3) && aligned16(dfeat), "whole-float4 gradient rows");
     if (B == 0) return 0;
-    IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4};
+    IaGather ga{ctx->d_tab, reinterpret_cast<const v4f*>(ctx->weight), slots, n, ld_x / 4, once, ld_once, lr};
     const size_t lds_s = (size_t)4 * (32 * 36 + D + 528) * sizeof(float);
     int64_t gp = cdiv(B, 4);
     const int per_cu = g_cdlrm_debug[5] > 0 ? g_cdlrm_debug[5] : (D == 256 ? 1 : 2);
     if (gp > 256 * per_cu) gp = 256 * per_cu;
-    static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0;
-#define GIBWD(D4_, A_)                                                                                                \
+    static size_t s32 = 0, s64 = 0, s128 = 0, s256 = 0, o32 = 0, o64 = 0, o128 = 0, o256 = 0;
+#define GIBWD(D4_, A_, ONCE_)                                                                                         \
     do {                                                                                                              \
-        int rc = interact_set_lds(k_interact_bwd_s<D4_, D4_ / 8, true>, lds_s, &A_);                                  \
+        int rc = interact_set_lds(k_interact_bwd_s<D4_, D4_ / 8, true, ONCE_>, lds_s, &A_);                           \
         if (rc) return rc;                                                                                            \
-        CDLRM_LAUNCH_EV((k_interact_bwd_s<D4_, D4_ / 8, true>), dim3((unsigned)gp), dim3(256), lds_s,                 \
+        CDLRM_LAUNCH_EV((k_interact_bwd_s<D4_, D4_ / 8, true, ONCE_>), dim3((unsigned)gp), dim3(256), lds_s,          \
                         (hipStream_t)stream, x, ga, dR, ld_r, B, F, itself, x_act, dfeat);                            \
     } while (0)
-    if (D == 32) GIBWD(8, s32);
-    else if (D == 64) GIBWD(16, s64);
-    else if (D == 128) GIBWD(32, s128);
-    else GIBWD(64, s256);
+    if (once) {
+        if (D == 32) GIBWD(8, o32, true);
+        else if (D == 64) GIBWD(16, o64, true);
+        else if (D == 128) GIBWD(32, o128, true);
+        else GIBWD(64, o256, true);
+    } else {
+        if (D == 32) GIBWD(8, s32, false);
+        else if (D == 64) GIBWD(16, s64, false);
+        else if (D == 128) GIBWD(32, s128, false);
+        else GIBWD(64, s256, false);
+    }
 #undef GIBWD
     CDLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                                         const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act,
+                                         float* dfeat, void* stream) {
+    return cdlrm_gather_interact_bwd_core(ctx, slots, n, x, ld_x, dR, ld_r, B, itself, x_act, dfeat, nullptr, 0, 0.f, stream);
+}
+
+extern "C" int cdlrm_gather_interact_bwd_sgd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                                             const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act,
+                                             float* dfeat, const uint8_t* once, int64_t ld_once, float lr, void* stream) {
+    if (!(ctx && once && ld_once >= B && (int64_t)ctx->T * ld_once < INT32_MAX)) {
+        CdlrmStopScope stop_scope;      // (an attached completion event must not outlive a refused call)
+        CDLRM_REQUIRE(ctx && once, "null argument");
+        CDLRM_REQUIRE(ld_once >= B && (int64_t)ctx->T * ld_once < INT32_MAX, "flag pitch");
+    }
+    return cdlrm_gather_interact_bwd_core(ctx, slots, n, x, ld_x, dR, ld_r, B, itself, x_act, dfeat, once, ld_once, lr, stream);
 }
 
 // =================================================================================================

@@ -37,10 +37,15 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
 template <int E>
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __restrict__ slots, int64_t n,
                                                               uint64_t* __restrict__ keys, int32_t* __restrict__ meta,
-                                                              int npow2, int write_meta, int32_t* __restrict__ longcount) {
+                                                              int npow2, int write_meta, int32_t* __restrict__ longcount,
+                                                              uint8_t* __restrict__ once, int nb, int64_t ld_in,
+                                                              int64_t batch_len, int nbt, int j0) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
     __shared__ int wmax[16];
     const int t = blockIdx.y;
+    // output list of input list t: a SLICE of a window chunk (nb of its nbt batches, from batch j0 on) lands in the chunk's
+    // [T, nbt] lists; a batch's own sort and a whole chunk: ol == t
+    const int ol = (t / nb) * nbt + j0 + t % nb;
     // the long-run list of THIS work buffer starts empty: cleared here, by the first kernel of every prepare (an apply always
     // follows a prepare on the same buffer, in stream order), so no clearing launch sits on the queue (a 4-byte hipMemsetAsync
     // is a 5.4 us kernel of its own) and two backward passes in flight on different work buffers share nothing
@@ -60,7 +65,9 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __r
         k[e] = ~0ull;
         if (i < cnt) {
             const int64_t p = base + i;
-            k[e] = ((uint64_t)(uint32_t)slots[(int64_t)t * n + p] << 32) | (uint64_t)p;
+            // (window form, cdlrm_embbag_bwd_prepare_window: list t = batch t % nb of table t / nb, read out of the resolver's
+            //  [T, ld_in] slot ids; one batch: nb = 1, ld_in = n)
+            k[e] = ((uint64_t)(uint32_t)slots[(int64_t)(t / nb) * ld_in + (int64_t)(t % nb) * batch_len + p] << 32) | (uint64_t)p;
         }
     }
     // 1. wave-local bitonic sort; the key with wave-local index g = lane * E + e lives in register e of lane `lane`
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __r
         for (int e = 0; e < E; ++e) sk[pos[e]] = k[e];
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[(int64_t)t * n + base + i] = sk[i];
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[(int64_t)ol * n + base + i] = sk[i];
     if (!write_meta) return;
     // run starts by an inclusive max-scan of head positions: thread owns E consecutive sorted keys
     const int i0 = threadIdx.x * E;
@@ -164,16 +171,20 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunks(const int32_t* __r
         const int i = i0 + e;
         if (i >= cnt) break;
         if (i == 0 || (uint32_t)(sk[i] >> 32) != (uint32_t)(sk[i - 1] >> 32)) run = i;
-        meta[(int64_t)t * n + base + i] = i - run;
+        meta[(int64_t)ol * n + base + i] = i - run;
+        // a slot this batch reads ONCE (a run of one lookup), flagged at the lookup's position in the batch
+        const bool last = i + 1 >= cnt || (uint32_t)(sk[i + 1] >> 32) != (uint32_t)(sk[i] >> 32);
+        once[(int64_t)ol * n + (uint32_t)sk[i]] = (run == i && last) ? 1 : 0;
     }
 }
 
 // merge sorted runs of length `run` pairwise by ranking (keys are unique: position is part of the key)
 __global__ void __launch_bounds__(256) k_merge_pass(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                    int64_t n, int64_t run) {
+                                                    int64_t n, int64_t run, int nb, int nbt, int j0) {
     const int t = blockIdx.y;
-    const uint64_t* a = in + (int64_t)t * n;
-    uint64_t* o = out + (int64_t)t * n;
+    const int ol = (t / nb) * nbt + j0 + t % nb;
+    const uint64_t* a = in + (int64_t)ol * n;
+    uint64_t* o = out + (int64_t)ol * n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pair = i / (2 * run);
         const int64_t s0 = pair * 2 * run;
@@ -187,14 +198,20 @@ __global__ void __launch_bounds__(256) k_merge_pass(const uint64_t* __restrict__
 }
 
 // meta for tables sorted in several chunks: distance to the run start by binary search
-__global__ void __launch_bounds__(256) k_seg_meta(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ meta) {
+__global__ void __launch_bounds__(256) k_seg_meta(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ meta,
+                                                  uint8_t* __restrict__ once, int nb, int nbt, int j0) {
     const int t = blockIdx.y;
-    const uint64_t* kt = keys + (int64_t)t * n;
+    const int ol = (t / nb) * nbt + j0 + t % nb;
+    const uint64_t* kt = keys + (int64_t)ol * n;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t s = kt[p] >> 32;
+        const uint64_t key = kt[p];
+        const uint64_t s = key >> 32;
         int32_t r = 0;
         if (p > 0 && (kt[p - 1] >> 32) == s) r = (int32_t)(p - lower_bound_u64(kt, 0, p, s << 32));
-        meta[(int64_t)t * n + p] = r;
+        meta[(int64_t)ol * n + p] = r;
+        // a slot this batch reads ONCE, flagged at the lookup's position in the batch (see k_sort_chunks)
+        const bool last = p + 1 >= n || (kt[p + 1] >> 32) != s;
+        once[(int64_t)ol * n + (uint32_t)key] = (r == 0 && last) ? 1 : 0;
     }
 }
 
@@ -207,7 +224,8 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
                                                     int64_t ld_table, float lr, float4* __restrict__ partials,
                                                     int64_t pstride, int64_t* __restrict__ longlist,
                                                     int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
-                                                    int64_t aux_total, int32_t* __restrict__ runend) {
+                                                    int64_t aux_total, int32_t* __restrict__ runend, int64_t kstride,
+                                                    int ways, int aux_add) {
     constexpr int KM = (SEG_CH + LPR - 1) / LPR;
     const int t = blockIdx.y;
     const int64_t row_base = tab[t].row_base;
@@ -218,15 +236,19 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
     const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
-    const uint64_t* kt = keys + (int64_t)t * n;
-    const int32_t* mt = meta + (int64_t)t * n;
+    // (kstride: elements between two tables' sorted lists -- n, or nb * n inside a window's sorted chunk; aux_add: the sorted
+    //  chunk holds phase-0 aux slots, the batch trains on aux region aux_add / aux)
+    const uint64_t* kt = keys + (int64_t)t * kstride;
+    const int32_t* mt = meta + (int64_t)t * kstride;
+    const uint32_t aux0 = (uint32_t)(tab[t].P * ways);
     const float* g = grad + (int64_t)t * ld_table;
     const int64_t* off = ARANGE ? nullptr : offsets + (int64_t)t * ld_off;
     for (int64_t p = (int64_t)blockIdx.x * gpb + gid; p < n; p += (int64_t)gridDim.x * gpb) {
         const int r0 = mt[p];
         if (r0 % SEG_CH) continue;               // chunk interior: some other group owns this position
         const bool head = r0 == 0;
-        const uint32_t slot = (uint32_t)(kt[p] >> 32);
+        uint32_t slot = (uint32_t)(kt[p] >> 32);
+        if (slot >= aux0) slot += aux_add;
         // first position after p (within the chunk window) that starts another run, found by the group at once
         int jstop = SEG_CH;                      // SEG_CH: the run continues past this chunk
 #pragma unroll
@@ -289,13 +311,226 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
     }
 }
 
+// The same sums in the same order (bit-identical to k_bwd_chunks), laid out for memory-level parallelism.  k_bwd_chunks gives a
+// lane group ONE sorted position per trip: meta -> look-ahead meta -> key -> gradient / row loads are four dependent global
+// reads, and a group makes ~9 such trips at c3 -- the kernel is a chain of latencies (52 us alone for 166 MB of traffic).
+// Here a lane group owns a BLOCK of SEG_CH consecutive sorted positions: one coalesced read brings the keys and run distances of
+// the block and of the SEG_CH positions behind it (a chunk that starts in the block ends at most there), run starts and chunk
+// heads become two bit masks (a ballot), and the heads of the block are worked FOUR AT A TIME with four gradient rows each in
+// flight (16 rows when the block holds one head: the inside of a long run).  Two dependent reads per block instead of four per
+// position.
+template <int LPR, bool ARANGE>
+__global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict__ tab, int D4,
+                                                    float4* __restrict__ weight, const uint64_t* __restrict__ keys,
+                                                    const int32_t* __restrict__ meta,
+                                                    const int64_t* __restrict__ offsets, int64_t n, int64_t n_bags,
+                                                    int64_t ld_off, const float* __restrict__ grad, int64_t ld_bag,
+                                                    int64_t ld_table, float lr, float4* __restrict__ partials,
+                                                    int64_t pstride, int64_t* __restrict__ longlist,
+                                                    int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
+                                                    int64_t aux_total, int32_t* __restrict__ runend, int skip_once,
+                                                    int64_t kstride, int ways, int aux_add) {
+    constexpr int GPB = 256 / LPR;
+    constexpr int SPAN = 2 * SEG_CH;                // positions a block's chunks can reach
+    constexpr int NL = SPAN / LPR;                  // span positions per lane
+    static_assert(SEG_CH == 32 && SPAN % LPR == 0, "masks below are 32 / 64 bits wide");
+    __shared__ uint32_t s_pos[GPB][SPAN];           // low half of the key: the lookup's position in the batch
+    __shared__ uint32_t s_slot[GPB][SEG_CH];
+    __shared__ int32_t s_r0[GPB][SEG_CH];
+    const int t = blockIdx.y;
+    const int64_t row_base = tab[t].row_base;
+    const uint32_t first_aux = (uint32_t)(tab[t].rows - aux_total);
+    const int c = threadIdx.x % LPR;
+    const int gid = threadIdx.x / LPR;
+    const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
+    const uint64_t* kt = keys + (int64_t)t * kstride;
+    const int32_t* mt = meta + (int64_t)t * kstride;
+    const uint32_t aux0 = (uint32_t)(tab[t].P * ways);
+    const float* g = grad + (int64_t)t * ld_table;
+    const int64_t* off = ARANGE ? nullptr : offsets + (int64_t)t * ld_off;
+    const int64_t nblk = (n + SEG_CH - 1) / SEG_CH;
+    for (int64_t blk = (int64_t)blockIdx.x * GPB + gid; blk < nblk; blk += (int64_t)gridDim.x * GPB) {
+        const int64_t p0 = blk * SEG_CH;
+        uint64_t S = 0;                              // bit j: position p0 + j starts a run (or lies past the end)
+        uint32_t H = 0;                              // bit j < SEG_CH: position p0 + j is a chunk head
+        __builtin_amdgcn_wave_barrier();             // the previous block's LDS reads are issued before these writes
+#pragma unroll
+        for (int m = 0; m < NL; ++m) {
+            const int j = c + m * LPR;
+            const int64_t q = p0 + j;
+            const bool in = q < n;
+            const uint64_t key = in ? kt[q] : 0ull;
+            const int32_t r = in ? mt[q] : 0;
+            s_pos[gid][j] = (uint32_t)key;
+            if (j < SEG_CH) {
+                uint32_t slot = (uint32_t)(key >> 32);
+                if (slot >= aux0) slot += aux_add;
+                s_slot[gid][j] = slot;
+                s_r0[gid][j] = r;
+            }
+            const unsigned long long b = __ballot(r == 0);
+            const unsigned long long bits = LPR == 64 ? b : ((b >> gshift) & ((1ull << LPR) - 1));
+            S |= bits << (m * LPR);
+            if (m * LPR < SEG_CH) {
+                const unsigned long long hb = __ballot(in && j < SEG_CH && (r % SEG_CH) == 0);
+                const unsigned long long hbits = LPR == 64 ? hb : ((hb >> gshift) & ((1ull << LPR) - 1));
+                H |= (uint32_t)(hbits << (m * LPR));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (skip_once) {
+            // runs of ONE lookup were updated by the interaction backward itself (cdlrm_gather_interact_bwd_sgd): a start
+            // followed by a start.  Only their touched flags are left to set.
+            const uint32_t one = (uint32_t)(S & (S >> 1)) & H;
+            H &= ~one;
+            if (touched) {
+#pragma unroll
+                for (int m = 0; m * LPR < SEG_CH; ++m) {
+                    const int j = c + m * LPR;
+                    if (j < SEG_CH && ((one >> j) & 1)) {
+                        const uint32_t slot = s_slot[gid][j];
+                        if (slot < first_aux) touched[row_base + slot] = 1;
+                    }
+                }
+            }
+        }
+        const int64_t pbucket = (int64_t)t * pstride + 2 * blk;
+        while (H) {
+            const bool alone = (H & (H - 1)) == 0;
+            if (alone) {
+                // one head: 16 gradient rows in flight
+                const int j = __ffs((int)H) - 1;
+                H = 0;
+                const uint64_t rest = S >> (j + 1);
+                const int nxt = rest ? (__ffsll((long long)rest) - 1) : 64;
+                const bool more = nxt >= SEG_CH;
+                const int len = more ? SEG_CH : nxt + 1;
+                const bool head = (S >> j) & 1;
+                const bool single = head && !more;
+                const uint32_t slot = s_slot[gid][j];
+                for (int cc = c; cc < D4; cc += LPR) {
+                    float4 w;
+                    if (single) w = weight[(row_base + slot) * D4 + cc];
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int q = 0; q < len; q += 16) {
+                        float4 v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            if (q + u < len) {
+                                const int64_t pos = s_pos[gid][j + q + u];
+                                const int64_t bag = ARANGE ? pos : bag_of(off, n_bags, pos);
+                                v[u] = *reinterpret_cast<const float4*>(g + bag * ld_bag + cc * 4);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            if (q + u < len) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                    }
+                    if (single) {
+                        w.x = fmaf(-lr, acc.x, w.x); w.y = fmaf(-lr, acc.y, w.y);
+                        w.z = fmaf(-lr, acc.z, w.z); w.w = fmaf(-lr, acc.w, w.w);
+                        weight[(row_base + slot) * D4 + cc] = w;
+                    } else {
+                        partials[(pbucket + (head ? 1 : 0)) * D4 + cc] = acc;
+                    }
+                }
+                if (c == 0) {
+                    const int64_t p = p0 + j;
+                    if (single) {
+                        if (touched && slot < first_aux) touched[row_base + slot] = 1;
+                    } else if (head) {
+                        const int li = atomicAdd(longcount, 1);
+                        longlist[li] = ((int64_t)t << 40) | p;
+                    }
+                    if (!single && !more) runend[(int64_t)t * n + (p - s_r0[gid][j])] = (int32_t)(p + len);
+                }
+                continue;
+            }
+            // up to four heads, four gradient rows of each in flight
+            int hj[4], hlen[4];
+            bool hhead[4], hsingle[4], hmore[4];
+            uint32_t hslot[4];
+            int maxlen = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                hlen[u] = 0; hj[u] = 0; hhead[u] = false; hsingle[u] = false; hmore[u] = false; hslot[u] = 0;
+                if (H) {
+                    const int j = __ffs((int)H) - 1;
+                    H &= H - 1;
+                    const uint64_t rest = S >> (j + 1);
+                    const int nxt = rest ? (__ffsll((long long)rest) - 1) : 64;
+                    hmore[u] = nxt >= SEG_CH;
+                    hlen[u] = hmore[u] ? SEG_CH : nxt + 1;
+                    hhead[u] = (S >> j) & 1;
+                    hsingle[u] = hhead[u] && !hmore[u];
+                    hj[u] = j;
+                    hslot[u] = s_slot[gid][j];
+                    maxlen = max(maxlen, hlen[u]);
+                }
+            }
+            for (int cc = c; cc < D4; cc += LPR) {
+                float4 w[4], acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (hsingle[u]) w[u] = weight[(row_base + hslot[u]) * D4 + cc];
+                }
+                for (int q = 0; q < maxlen; q += 4) {
+                    float4 v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (q + k < hlen[u]) {
+                                const int64_t pos = s_pos[gid][hj[u] + q + k];
+                                const int64_t bag = ARANGE ? pos : bag_of(off, n_bags, pos);
+                                v[u][k] = *reinterpret_cast<const float4*>(g + bag * ld_bag + cc * 4);
+                            }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (q + k < hlen[u]) {
+                                acc[u].x += v[u][k].x; acc[u].y += v[u][k].y; acc[u].z += v[u][k].z; acc[u].w += v[u][k].w;
+                            }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (hlen[u] == 0) continue;
+                    if (hsingle[u]) {
+                        w[u].x = fmaf(-lr, acc[u].x, w[u].x); w[u].y = fmaf(-lr, acc[u].y, w[u].y);
+                        w[u].z = fmaf(-lr, acc[u].z, w[u].z); w[u].w = fmaf(-lr, acc[u].w, w[u].w);
+                        weight[(row_base + hslot[u]) * D4 + cc] = w[u];
+                    } else {
+                        partials[(pbucket + (hhead[u] ? 1 : 0)) * D4 + cc] = acc[u];
+                    }
+                }
+            }
+            if (c == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (hlen[u] == 0) continue;
+                    const int64_t p = p0 + hj[u];
+                    if (hsingle[u]) {
+                        if (touched && hslot[u] < first_aux) touched[row_base + hslot[u]] = 1;
+                    } else if (hhead[u]) {
+                        const int li = atomicAdd(longcount, 1);
+                        longlist[li] = ((int64_t)t << 40) | p;
+                    }
+                    if (!hsingle[u] && !hmore[u]) runend[(int64_t)t * n + (p - s_r0[gid][hj[u]])] = (int32_t)(p + hlen[u]);
+                }
+            }
+        }
+    }
+}
+
 template <int LPR>
 __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ tab, int D4,
                                                   float4* __restrict__ weight, const uint64_t* __restrict__ keys,
                                                   int64_t n, float lr, const float4* __restrict__ partials,
                                                   int64_t pstride, const int64_t* __restrict__ longlist,
                                                   int32_t* __restrict__ longcount, uint8_t* __restrict__ touched,
-                                                  int64_t aux_total, const int32_t* __restrict__ runend) {
+                                                  int64_t aux_total, const int32_t* __restrict__ runend, int64_t kstride,
+                                                  int ways, int aux_add) {
     const int c = threadIdx.x % LPR;
     const int gpb = blockDim.x / LPR;
     const int gid = threadIdx.x / LPR;
@@ -315,15 +550,28 @@ __global__ void __launch_bounds__(256) k_bwd_long(const TableDesc* __restrict__ 
         const int64_t e = longlist[li];
         const int t = (int)(e >> 40);
         const int64_t p0 = e & (((int64_t)1 << 40) - 1);
-        const uint64_t* kt = keys + (int64_t)t * n;
-        const uint32_t slot = (uint32_t)(kt[p0] >> 32);
+        const uint64_t* kt = keys + (int64_t)t * kstride;
+        uint32_t slot = (uint32_t)(kt[p0] >> 32);
+        if (slot >= (uint32_t)(tab[t].P * ways)) slot += aux_add;
         const int64_t end = runend[(int64_t)t * n + p0];
         const int64_t row = tab[t].row_base + slot;
         for (int cc = c; cc < D4; cc += LPR) {
             float4 w = weight[row * D4 + cc];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            // chunk partials in chunk order (a fixed order: reproducible), four loads in flight
+            // chunk partials in chunk order (a fixed order: reproducible), sixteen then four loads in flight (a tiny table's run is
+            // thousands of lookups = a hundred partials behind ONE lane group: at four in flight the kernel was its latency chain)
             int64_t p = p0;
+            for (; p + 15 * SEG_CH < end; p += 16 * SEG_CH) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int64_t q = p + u * SEG_CH;
+                    const int64_t pi = 2 * (q / SEG_CH) + (q == p0 ? 1 : 0);
+                    v[u] = partials[((int64_t)t * pstride + pi) * D4 + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
             for (; p + 3 * SEG_CH < end; p += 4 * SEG_CH) {
                 float4 v[4];
 #pragma unroll
@@ -363,7 +611,8 @@ static int lanes_per_row_b(int D4) { int l = pow2ceil(D4); return l > 64 ? 64 : 
     }
 
 // work layout: keys A [T*n] u64 | keys B [T*n] u64 | meta [T*n] i32 | partials [T*pstride*D] f32 |
-//              longlist [T*(n/SEG_CH+2)] i64 | long-run counter | runend [T*n] i32 (end of a long run, at its head)
+//              longlist [T*(n/SEG_CH+2)] i64 | long-run counter | runend [T*n] i32 (end of a long run, at its head) |
+//              once [T*n] u8 (by position in the batch: the lookup's slot occurs once in the batch)
 static int64_t bwd_pstride(int64_t n) { return 2 * (cdiv(n, SEG_CH) + 1); }
 static uint64_t align256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
 
@@ -374,6 +623,7 @@ struct BwdWork {
     int64_t* longlist;
     int32_t* longcount;
     int32_t* runend;
+    uint8_t* once;          // [T*n] by position in the batch: this lookup's slot occurs once in the batch
     int64_t pstride;
 };
 
@@ -387,14 +637,15 @@ static BwdWork carve(void* work, int T, int64_t n, int D) {
     w.partials = (float4*)wp; wp += align256((uint64_t)T * w.pstride * D * 4);
     w.longlist = (int64_t*)wp; wp += align256((uint64_t)T * (n / SEG_CH + 2) * 8);
     w.longcount = (int32_t*)wp; wp += 256;
-    w.runend = (int32_t*)wp;
+    w.runend = (int32_t*)wp; wp += align256((uint64_t)T * n * 4);
+    w.once = (uint8_t*)wp;
     return w;
 }
 
 extern "C" uint64_t cdlrm_embbag_bwd_work_bytes(int32_t T, int64_t n, int32_t dim) {
     return 2 * align256((uint64_t)T * n * 8) + align256((uint64_t)T * n * 4) +
            align256((uint64_t)T * bwd_pstride(n) * dim * 4) + align256((uint64_t)T * (n / SEG_CH + 2) * 8) + 256 +
-           align256((uint64_t)T * n * 4);
+           align256((uint64_t)T * n * 4) + align256((uint64_t)T * n);
 }
 
 // Keys per sorting workgroup.  The in-LDS sort is bound by vector-instruction issue on ONE CU (measured: 9 / 16 / 33 / 83 us
@@ -413,17 +664,9 @@ static bool sorted_in_B(int64_t n) {
     return passes & 1;
 }
 
-extern "C" int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, void* work, void* stream) {
-    CDLRM_REQUIRE(ctx && slots && work, "null argument");
-    CDLRM_REQUIRE(((uintptr_t)work & 255) == 0, "work must be 256-byte aligned");
-    CDLRM_REQUIRE(n < ((int64_t)1 << 31) && ctx->T < (1 << 20), "n < 2^31");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) return 0;
-#ifdef CDLRM_DEV
-    if (g_cdlrm_debug[6] & 2) return 0;     // development build (tools/ab_step.py --attr debug:6): what the step costs WITHOUT the slot sort
-#endif
-    const int T = ctx->T;
-    BwdWork w = carve(work, T, n, ctx->D);
+// the sort of `lists` lists of n slot ids each (a batch: one list per table; a window chunk: one per table and batch)
+static int bwd_sort(int lists, int64_t n, const int32_t* slots, int nb, int64_t ld_in, int64_t batch_len, int nbt, int j0,
+                    uint64_t* keysA, uint64_t* keysB, int32_t* meta, uint8_t* once, int32_t* longcount, hipStream_t s) {
     const int64_t chunk = sort_chunk(n);
     const int64_t nchunks = cdiv(n, chunk);
     const int npow2 = (int)chunk;
@@ -435,33 +678,103 @@ extern "C" int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, in
     }
     // keys per thread: the chunk spread over the 1024 threads
     const int E = (int)(chunk / SORT_THREADS);
-    const dim3 sgrid((unsigned)nchunks, (unsigned)T);
+    const dim3 sgrid((unsigned)nchunks, (unsigned)lists);
     const size_t slds = (size_t)SORT_THREADS * E * 8;
     const int wm = nchunks == 1 ? 1 : 0;
-    if (E == 1) hipLaunchKernelGGL(k_sort_chunks<1>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
-    else if (E == 2) hipLaunchKernelGGL(k_sort_chunks<2>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
-    else if (E == 4) hipLaunchKernelGGL(k_sort_chunks<4>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
-    else hipLaunchKernelGGL(k_sort_chunks<8>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, w.keysA, w.meta, npow2, wm, w.longcount);
-    uint64_t* cur = w.keysA;
-    uint64_t* alt = w.keysB;
+#define SORT_CALL(E_) hipLaunchKernelGGL(k_sort_chunks<E_>, sgrid, dim3(SORT_THREADS), slds, s, slots, n, keysA, meta, npow2, wm, longcount, once, nb, ld_in, batch_len, nbt, j0)
+    if (E == 1) SORT_CALL(1);
+    else if (E == 2) SORT_CALL(2);
+    else if (E == 4) SORT_CALL(4);
+    else SORT_CALL(8);
+#undef SORT_CALL
+    uint64_t* cur = keysA;
+    uint64_t* alt = keysB;
     for (int64_t run = chunk; run < n; run *= 2) {
         int64_t gx = cdiv(n, 256);
         if (gx > 4096) gx = 4096;
-        hipLaunchKernelGGL(k_merge_pass, dim3((unsigned)gx, (unsigned)T), dim3(256), 0, s, cur, alt, n, run);
+        hipLaunchKernelGGL(k_merge_pass, dim3((unsigned)gx, (unsigned)lists), dim3(256), 0, s, cur, alt, n, run, nb, nbt, j0);
         uint64_t* tmp = cur; cur = alt; alt = tmp;
     }
     if (nchunks > 1) {
         int64_t gx = cdiv(n, 256);
         if (gx > 4096) gx = 4096;
-        hipLaunchKernelGGL(k_seg_meta, dim3((unsigned)gx, (unsigned)T), dim3(256), 0, s, cur, n, w.meta);
+        hipLaunchKernelGGL(k_seg_meta, dim3((unsigned)gx, (unsigned)lists), dim3(256), 0, s, cur, n, meta, once, nb, nbt, j0);
     }
     CDLRM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, int64_t n_bags, int64_t ld_off,
-                                      const float* grad, int64_t ld_bag, int64_t ld_table, float lr, void* work,
-                                      uint8_t* touched, void* stream) {
+extern "C" int cdlrm_embbag_bwd_prepare(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, void* work, void* stream) {
+    CDLRM_REQUIRE(ctx && slots && work, "null argument");
+    CDLRM_REQUIRE(((uintptr_t)work & 255) == 0, "work must be 256-byte aligned");
+    CDLRM_REQUIRE(n < ((int64_t)1 << 31) && ctx->T < (1 << 20), "n < 2^31");
+    if (n == 0) return 0;
+#ifdef CDLRM_DEV
+    if (g_cdlrm_debug[6] & 2) return 0;     // development build (tools/ab_step.py --attr debug:6): what the step costs WITHOUT the slot sort
+#endif
+    BwdWork w = carve(work, ctx->T, n, ctx->D);
+    return bwd_sort(ctx->T, n, slots, 1, n, 0, 1, 0, w.keysA, w.keysB, w.meta, w.once, w.longcount, (hipStream_t)stream);
+}
+
+// ---- a window chunk's batches sorted at once (the look-ahead resolver's slot ids: cdlrm_window_resolve) ----------------------
+// sorted layout: keys A [T*nb*n] u64 | keys B | meta [T*nb*n] i32 | once [T*nb*n] u8 | 256 B; list t * nb + j = table t, batch j
+struct SortedWin {
+    uint64_t *keysA, *keysB;
+    int32_t* meta;
+    uint8_t* once;
+    int32_t* pad;
+};
+static SortedWin carve_sorted(void* sorted, int T, int nb, int64_t n) {
+    SortedWin w;
+    char* wp = (char*)sorted;
+    const uint64_t e = (uint64_t)T * nb * n;
+    w.keysA = (uint64_t*)wp; wp += align256(e * 8);
+    w.keysB = (uint64_t*)wp; wp += align256(e * 8);
+    w.meta = (int32_t*)wp; wp += align256(e * 4);
+    w.once = (uint8_t*)wp; wp += align256(e);
+    w.pad = (int32_t*)wp;
+    return w;
+}
+
+extern "C" uint64_t cdlrm_embbag_bwd_sorted_bytes(int32_t num_tables, int32_t nb, int64_t n) {
+    const uint64_t e = (uint64_t)num_tables * nb * n;
+    return 2 * align256(e * 8) + align256(e * 4) + align256(e) + 256;
+}
+
+extern "C" int cdlrm_embbag_bwd_prepare_window(cdlrm_ctx* ctx, const int32_t* wslots, int64_t ld_w, int64_t batch_len,
+                                               int32_t nb, int64_t n, int32_t j0, int32_t count, void* sorted, void* stream) {
+    CDLRM_REQUIRE(ctx && wslots && sorted, "null argument");
+    CDLRM_REQUIRE(((uintptr_t)sorted & 255) == 0, "sorted must be 256-byte aligned");
+    CDLRM_REQUIRE(nb >= 1 && n >= 1 && n < ((int64_t)1 << 31) && (int64_t)ctx->T * nb < 65536, "1 <= nb, T * nb < 65536, n < 2^31");
+    CDLRM_REQUIRE(j0 >= 0 && count >= 1 && j0 + count <= nb, "0 <= j0, 1 <= count, j0 + count <= nb");
+    CDLRM_REQUIRE(batch_len >= n && ld_w >= (int64_t)(nb - 1) * batch_len + n, "a batch's n slot ids lie inside its batch_len columns");
+    SortedWin w = carve_sorted(sorted, ctx->T, nb, n);
+    return bwd_sort(ctx->T * count, n, wslots + (int64_t)j0 * batch_len, count, ld_w, batch_len, nb, j0, w.keysA, w.keysB, w.meta,
+                    w.once, w.pad, (hipStream_t)stream);
+}
+
+extern "C" int cdlrm_embbag_bwd_sorted_views(cdlrm_ctx* ctx, void* sorted, int32_t nb, int64_t n, int32_t j,
+                                             const uint64_t** keys, const int32_t** meta, const uint8_t** once) {
+    CDLRM_REQUIRE(ctx && sorted && keys && meta && once && nb >= 1 && j >= 0 && j < nb && n >= 1, "bad argument");
+    SortedWin w = carve_sorted(sorted, ctx->T, nb, n);
+    *keys = (sorted_in_B(n) ? w.keysB : w.keysA) + (int64_t)j * n;
+    *meta = w.meta + (int64_t)j * n;
+    *once = w.once + (int64_t)j * n;
+    return 0;
+}
+
+extern "C" int cdlrm_embbag_bwd_once_flags(cdlrm_ctx* ctx, void* work, int64_t n, const uint8_t** once) {
+    CDLRM_REQUIRE(ctx && work && once && n >= 1, "bad argument");
+    *once = carve(work, ctx->T, n, ctx->D).once;
+    return 0;
+}
+
+// sums + row updates over sorted lists: `cur` / `meta` are table 0's list, table t's lies kstride elements further (a batch's own
+// sort: n; a window chunk's: nb * n); aux_phase: the sorted slots are phase-0 aux slots (0 for a batch's own sort: k_take has
+// added the phase); scratch: partials, long-run list and run ends of `work`
+static int cdlrm_embbag_bwd_apply_core(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, int64_t n_bags, int64_t ld_off,
+                     const float* grad, int64_t ld_bag, int64_t ld_table, float lr, void* work, const uint64_t* cur,
+                     const int32_t* meta, int64_t kstride, int aux_phase, uint8_t* touched, void* stream, int skip_once) {
     CDLRM_REQUIRE(ctx && grad && work, "null argument");
     CDLRM_REQUIRE(ctx->weight, "cdlrm_ctx_bind_cache first");
     CDLRM_REQUIRE(((uintptr_t)grad & 15) == 0 && ld_bag % 4 == 0 && ld_table % 4 == 0 && ((uintptr_t)work & 255) == 0,
@@ -476,10 +789,38 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
     const int lpr = lanes_per_row_b(D4);
     const int gpb = 256 / lpr;
     BwdWork w = carve(work, T, n, ctx->D);
-    const uint64_t* cur = sorted_in_B(n) ? w.keysB : w.keysA;
-    int64_t gx = cdiv(n, gpb);
-    if (gx > 65535) gx = 65535;
-    {
+    if (!cur) {
+        cur = sorted_in_B(n) ? w.keysB : w.keysA;
+        meta = w.meta;
+        kstride = n;
+    }
+    const int ways = ctx->ways, aux_add = aux_phase * ctx->aux;
+    float4* wt = reinterpret_cast<float4*>(ctx->weight);
+    const int64_t aux_total = (int64_t)ctx->aux * ctx->aux_phases;
+    if (skip_once || (g_cdlrm_debug[6] & 64)) {
+        // a lane group per block of SEG_CH sorted positions (k_bwd_blocks): the form for the runs of >= 2 lookups that
+        // cdlrm_embbag_bwd_apply_rest is left with (few heads per block).  With every run of one lookup in the list it is slower
+        // than a lane group per position (c3: 48.8 against 44.0 us alone, 144 against 105 us inside the step: a block of a large
+        // table holds 30 heads = 8 trips); cdlrm_debug_set(6, 64) selects it there too
+        int64_t bx = cdiv(cdiv(n, SEG_CH), gpb);
+        const int per_cu = g_cdlrm_debug[1] > 0 ? g_cdlrm_debug[1] : 12;
+        const int64_t cap = cdiv((int64_t)256 * per_cu, T);
+        if (g_cdlrm_debug[1] >= 0 && bx > cap) bx = cap;
+        dim3 bgrid((unsigned)bx, (unsigned)T);
+#define BLK_CALL(L)                                                                                                \
+    if (offsets)                                                                                                   \
+        hipLaunchKernelGGL((k_bwd_blocks<L, false>), bgrid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,   \
+                           n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
+                           touched, aux_total, w.runend, skip_once, kstride, ways, aux_add);                       \
+    else                                                                                                           \
+        hipLaunchKernelGGL((k_bwd_blocks<L, true>), bgrid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,    \
+                           n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
+                           touched, aux_total, w.runend, skip_once, kstride, ways, aux_add)
+        DISPATCH_LPR_B(lpr, BLK_CALL)
+#undef BLK_CALL
+    } else {
+        int64_t gx = cdiv(n, gpb);
+        if (gx > 65535) gx = 65535;
         // at most 12 workgroups per CU (the position loop strides): the kernel runs on a side queue beside the weight-gradient and
         // bottom-MLP GEMMs, and an unbounded grid (26 624 workgroups at c3, 213 k at c5) takes every free wave slot between their
         // launches.  Same box, same process, 6 x 90 steps each (tools/ab_step.py --attr debug:1): uncapped / 12 / 8 / 6 / 4 per CU
@@ -489,28 +830,52 @@ extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, in
         const int per_cu = g_cdlrm_debug[1] > 0 ? g_cdlrm_debug[1] : 12;
         const int64_t cap = cdiv((int64_t)256 * per_cu, T);
         if (g_cdlrm_debug[1] >= 0 && gx > cap) gx = cap;
-    }
-    dim3 grid((unsigned)gx, (unsigned)T);
-    float4* wt = reinterpret_cast<float4*>(ctx->weight);
-    const int64_t aux_total = (int64_t)ctx->aux * ctx->aux_phases;
+        dim3 grid((unsigned)gx, (unsigned)T);
 #define BWD_CALL(L)                                                                                                \
     if (offsets)                                                                                                   \
-        hipLaunchKernelGGL((k_bwd_chunks<L, false>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, w.meta, offsets, n, \
+        hipLaunchKernelGGL((k_bwd_chunks<L, false>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,    \
                            n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
-                           touched, aux_total, w.runend);                                                          \
+                           touched, aux_total, w.runend, kstride, ways, aux_add);                                  \
     else                                                                                                           \
-        hipLaunchKernelGGL((k_bwd_chunks<L, true>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, w.meta, offsets, n,  \
+        hipLaunchKernelGGL((k_bwd_chunks<L, true>), grid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,     \
                            n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,  \
-                           touched, aux_total, w.runend)
-    DISPATCH_LPR_B(lpr, BWD_CALL)
+                           touched, aux_total, w.runend, kstride, ways, aux_add)
+        DISPATCH_LPR_B(lpr, BWD_CALL)
 #undef BWD_CALL
+    }
     int64_t lx = cdiv((int64_t)T * (n / SEG_CH + 1), gpb);
     if (lx > 1024) lx = 1024;
-#define LONG_CALL(L) hipLaunchKernelGGL(k_bwd_long<L>, dim3((unsigned)lx), dim3(256), 0, s, ctx->d_tab, D4, wt, cur, n, lr, w.partials, w.pstride, w.longlist, w.longcount, touched, aux_total, w.runend)
+#define LONG_CALL(L) hipLaunchKernelGGL(k_bwd_long<L>, dim3((unsigned)lx), dim3(256), 0, s, ctx->d_tab, D4, wt, cur, n, lr, w.partials, w.pstride, w.longlist, w.longcount, touched, aux_total, w.runend, kstride, ways, aux_add)
     DISPATCH_LPR_B(lpr, LONG_CALL)
 #undef LONG_CALL
     CDLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, int64_t n_bags, int64_t ld_off,
+                                      const float* grad, int64_t ld_bag, int64_t ld_table, float lr, void* work,
+                                      uint8_t* touched, void* stream) {
+    return cdlrm_embbag_bwd_apply_core(ctx, offsets, n, n_bags, ld_off, grad, ld_bag, ld_table, lr, work, nullptr, nullptr, 0, 0, touched, stream, 0);
+}
+
+// The apply behind cdlrm_gather_interact_bwd_sgd: slots the batch reads once were updated there (their gradient rows were
+// never written); what is left are the runs of two and more lookups.
+extern "C" int cdlrm_embbag_bwd_apply_rest(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, int64_t n_bags, int64_t ld_off,
+                                           const float* grad, int64_t ld_bag, int64_t ld_table, float lr, void* work,
+                                           uint8_t* touched, void* stream) {
+    return cdlrm_embbag_bwd_apply_core(ctx, offsets, n, n_bags, ld_off, grad, ld_bag, ld_table, lr, work, nullptr, nullptr, 0, 0, touched, stream, 1);
+}
+
+// The apply over a window chunk's sorted lists (cdlrm_embbag_bwd_prepare_window; keys / meta: batch j's views, tstride = nb * n):
+// no per-batch sort.  `work` only lends its scratch (partial sums, long-run list); its long-run counter must be zero -- every
+// apply leaves it zero, a fresh buffer is zero-filled by the caller.  One lookup per bag (the Criteo layout).
+extern "C" int cdlrm_embbag_bwd_apply_sorted(cdlrm_ctx* ctx, int64_t n, const float* grad, int64_t ld_bag, int64_t ld_table,
+                                             float lr, void* work, const uint64_t* keys, const int32_t* meta, int64_t tstride,
+                                             int32_t aux_phase, int32_t rest, uint8_t* touched, void* stream) {
+    CDLRM_REQUIRE(ctx && keys && meta && tstride >= n, "null argument / tstride");
+    CDLRM_REQUIRE(aux_phase >= 0 && aux_phase < (ctx->aux_phases > 0 ? ctx->aux_phases : 1), "aux_phase outside the geometry's aux_phases");
+    return cdlrm_embbag_bwd_apply_core(ctx, nullptr, n, n, 0, grad, ld_bag, ld_table, lr, work, keys, meta, tstride, aux_phase, touched, stream,
+                     rest ? 1 : 0);
 }
 
 extern "C" int cdlrm_embbag_bwd_sgd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,

@@ -99,7 +99,9 @@ extern "C" int cdlrm_tape_probe_log(int64_t tag, int64_t spin);
 static const std::vector<TapeEntry>& tape_registry() {
     static const std::vector<TapeEntry> reg = {
         TAPE_FN(cdlrm_embbag_probe), TAPE_FN(cdlrm_embbag_take), TAPE_FN(cdlrm_embbag_fwd), TAPE_FN(cdlrm_embbag_bwd_sgd),
-        TAPE_FN(cdlrm_embbag_bwd_prepare), TAPE_FN(cdlrm_embbag_bwd_apply), TAPE_FN(cdlrm_window_resolve),
+        TAPE_FN(cdlrm_embbag_bwd_prepare), TAPE_FN(cdlrm_embbag_bwd_apply), TAPE_FN(cdlrm_embbag_bwd_apply_rest),
+        TAPE_FN(cdlrm_gather_interact_bwd_sgd), TAPE_FN(cdlrm_embbag_bwd_prepare_window), TAPE_FN(cdlrm_embbag_bwd_apply_sorted),
+        TAPE_FN(cdlrm_window_resolve),
         TAPE_FN(cdlrm_mark_rows), TAPE_FN(cdlrm_interact_fwd), TAPE_FN(cdlrm_interact_bwd), TAPE_FN(cdlrm_gather_interact_fwd),
         TAPE_FN(cdlrm_gather_interact_bwd), TAPE_FN(cdlrm_linear_fwd),
         TAPE_FN(cdlrm_linear_bwd), TAPE_FN(cdlrm_mlp_wgrad), TAPE_FN(cdlrm_mlp_wgrad_sgd), TAPE_FN(cdlrm_bce_fwd_bwd),

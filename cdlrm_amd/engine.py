@@ -508,6 +508,28 @@ class WindowResolver:
                     e.record(S.current_stream(engine.dev))
             engine._bufs[("wres_ev",)] = evs
         self._ring_ev = engine._bufs[("wres_ev",)]
+        # The embedding backward's slot sort, per CHUNK instead of per step (round 6): a window's slot ids are final once its
+        # chunk is resolved, so the lists of SL batches x T tables are sorted by ONE set of launches (four launches for four
+        # batches instead of four per batch, 416 instead of 104 sorting workgroups each), on the side stream behind a step's
+        # embedding update, batches ahead of their use.  A step whose batch has its lists sorted issues no sort, and its
+        # interaction backward finds the once-only flags there (TrainEngine.fuse_once) without waiting for anything: the
+        # slice's event is waited for by the stream that runs the batch's take, which the step's gather waits for anyway.
+        self.sort_chunks = bool(getattr(engine, "sort_chunks", False)) and S.is_hip(engine.dev) and self.width > 0
+        self.SL = max(1, min(int(getattr(engine, "sort_slice", 4)), self.CH))
+        self.sorted_upto = 0        # batches [0, sorted_upto) of the window have had their slice's turn
+        self._sorted_at = {}        # first batch of a slice whose sort was issued -> batches in it (engine.sort_chunks at that time)
+        engine._sev_waited = None   # (the slice events are shared by every resolver of the engine)
+        if self.sort_chunks:
+            skey = ("wsorted", self.CH, self.width)
+            if skey not in engine._bufs:
+                engine._bufs[skey] = [ops.embbag_bwd_sorted(self.ctx, self.CH, self.width, window_idx.device)
+                                      for _ in range(self.RING)]
+            self._sorted_ring = engine._bufs[skey]
+            nsl = -(-self.CH // self.SL)
+            ekey = ("wsorted_ev", self.CH, self.SL)
+            if ekey not in engine._bufs:
+                engine._bufs[ekey] = [[S.new_event(engine.dev) for _ in range(nsl)] for _ in range(self.RING)]
+            self._sorted_ev = engine._bufs[ekey]
         self._armed = None          # chunk handed to the engine, to be placed by its next step
         if getattr(engine, "_pending_resolve", None) is not None:
             # a chunk of the window this one replaces that no step has placed: its ring slot belongs to this window now
@@ -564,6 +586,53 @@ class WindowResolver:
                 eng._issue_resolve(pr, lambda fn, *a: fn(*a), S.current_stream(eng.dev), placed=False)
             else:                   # (host-logic tests: a bare engine stand-in)
                 ops.window_resolve(self.ctx, pr["cols"], self.lbs, pr["ws"], pr["wsrc"], stream=eng.pref, batch_len=self.B)
+        if not urgent:
+            # (callers pass the batch just trained + CH + 2) the slice that holds the batch after next: the next step issues that
+            # batch's take, and the take's stream waits for the slice
+            self.ensure_sorted(int(upto_batch) - self.CH - 2 + 3)
+
+    def _chunk_nb(self, c: int) -> int:
+        return min(self.nb, (c + 1) * self.CH) - c * self.CH
+
+    def ensure_sorted(self, upto_batch: int):
+        """Issue the slot sort of every slice that holds a batch < upto_batch (side stream, behind whatever the last step put
+        there; no host wait).  A slice of a chunk whose resolve has not been ISSUED yet stays for a later call."""
+        if not self.sort_chunks:
+            return
+        eng = self.eng
+        upto = min(int(upto_batch), self.nb)
+        while self.sorted_upto < upto:
+            b0 = self.sorted_upto
+            c = b0 // self.CH
+            if c >= self.done or c not in self.chunks:
+                break
+            if self._armed is not None and c >= self._armed and getattr(eng, "_pending_resolve", None) is not None:
+                break               # handed to the engine, not yet issued
+            ws, _, ev = self.chunks[c]
+            nbc = self._chunk_nb(c)
+            j0 = b0 - c * self.CH
+            cnt = min(self.SL, nbc - j0)
+            if getattr(eng, "sort_chunks", True):       # (switched per slice by tools/ab_step.py)
+                eng.side.wait_event(ev)                 # the chunk's resolve (prefetch stream)
+                ops.embbag_bwd_prepare_window(self.ctx, ws[:, self.col0:], self.B, nbc, self.width,
+                                              self._sorted_ring[c % self.RING], stream=eng.side, j0=j0, count=cnt)
+                self._sorted_ev[c % self.RING][j0 // self.SL].record(eng.side)
+                self._sorted_at[b0] = cnt
+            self.sorted_upto = b0 + cnt
+            self._sorted_at.pop(b0 - 3 * self.CH, None)
+
+    def sorted_views(self, j: int):
+        """(keys, meta, once addresses of batch j's sorted lists, elements between two tables' lists, the slice's event) -- or
+        None: not sorted (yet)."""
+        if not self.sort_chunks or j >= self.sorted_upto:
+            return None
+        c = j // self.CH
+        nbc = self._chunk_nb(c)
+        jl = j - c * self.CH
+        if (j - jl % self.SL) not in self._sorted_at:
+            return None
+        k, m, o = ops.embbag_bwd_sorted_views(self.ctx, self._sorted_ring[c % self.RING], nbc, self.width, jl)
+        return k, m, o, nbc * self.width, self._sorted_ev[c % self.RING][jl // self.SL]
 
     def batch(self, j: int):
         """(wslots view, wsrc view, ready event) of this rank's lookups of batch j of the window."""
@@ -701,6 +770,16 @@ class TrainEngine:
         # ... and the bottom MLP's forward (it runs at the end of the previous step, beside the next batch's take and slot sort:
         # small kernels that fit beside a wide workgroup): its 512 -> 256 layer on 64x128 tiles, c3 0.5495 against 0.5522 ms
         self.wide_gemm_bottom = True
+        # the SGD step of the slots a batch reads ONCE rides in the fused interaction backward (cdlrm_gather_interact_bwd_sgd):
+        # those lookups' gradient rows are never written or read back, the sorted path is left with the repeated slots.
+        # Bit-identical (a single addend has no order); costs the training queue one wait for the slot sort
+        self.fuse_once = True
+        # the slot sort of the embedding backward per look-ahead chunk slice instead of per step (WindowResolver.ensure_sorted);
+        # steps of batches without sorted lists (no resolver, multi-hot bags) sort their own
+        self.sort_chunks = True
+        self.sort_slice = 4
+        self._cur_sorted = self._next_sorted = None
+        self._sev_waited = None
         # --evict-victim-cache (main_no_ddp.py:96, parsed and unused by the reference): behind every step's embedding update
         # the trained aux rows of the batch's misses go back to their host rows and to their copies among the window's victim
         # rows (ops.victim_writeback).  One rank only; the step then runs un-pipelined (no take of the next batch ahead of
@@ -1032,6 +1111,18 @@ class TrainEngine:
                 self._pump_finish()
         if self._pump is not None:
             self._pump_wait()       # rows of an earlier merge that THIS step uses have landed
+        self._cur_sorted = self._next_sorted = None
+        if lS_o is None and not self.evict_victim:
+            if res is not None and len(res) > 3:
+                self._cur_sorted = res[3][0].sorted_views(res[3][1])
+            if self._next_res is not None and len(next_res) > 3:
+                self._next_sorted = next_res[3][0].sorted_views(next_res[3][1])
+                if self._next_sorted is not None and self._next_sorted[4] is not self._sev_waited:
+                    # the next batch's take (two aux regions: prefetch stream; else the side stream, where the sort ran) waits
+                    # for its slice's sort: this step's successor -- gather, interaction backward (the once-only flags),
+                    # embedding update -- is ordered behind that take
+                    self.pref.wait_event(self._next_sorted[4])
+                    self._sev_waited = self._next_sorted[4]
         if res is not None:
             # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
             self.side.wait_event(res[2])
@@ -1219,7 +1310,15 @@ class TrainEngine:
         attach = self.attach_events and S.is_hip(self.dev)
         # the sort behind the interaction forward (sort_after_fwd): issued below, behind that launch
         defer_sort = bool(self.sort_after_fwd and fused and attach and not prepared)
-        if not prepared and not defer_sort:     # (prepared: a chained take sorted this batch's slots right behind itself)
+        # sv: this batch's slot lists were sorted with its look-ahead chunk (WindowResolver.ensure_sorted): no sort here, and the
+        # once-only slots can be updated by the interaction backward (it reads the sort's flags)
+        # (the flags of a batch's OWN sort would cost the training queue a wait for the side stream in front of the interaction
+        #  backward: measured 21 us, three times what the folding saves)
+        sv = self._cur_sorted if (lS_o is None and n == B) else None
+        once = bool(self.fuse_once and fused and sv is not None)
+        if sv is not None:
+            defer_sort = False
+        elif not prepared and not defer_sort:     # (prepared: a chained take sorted this batch's slots right behind itself)
             ops.embbag_bwd_prepare(ctx, slots, emb_work, stream=side)
         if self.defer_top and not self.cat and not top_waited:
             # the previous step's top-MLP update (weight gradients read R / top_y / top_dy, then all-reduce and SGD on
@@ -1331,7 +1430,10 @@ class TrainEngine:
         else:
             if attach:
                 ops.event_attach_next(ev["interacted"], main)      # completes with the interaction backward's launch
-            if fused:
+            if once:
+                ops.gather_interact_bwd_sgd(ctx, slots, feat[:, 0, :], dR, self.itself, dfeat, sv[2], sv[3], self.lr_embeds,
+                                            x_act=self.bot[-1][1])
+            elif fused:
                 ops.gather_interact_bwd(ctx, slots, feat[:, 0, :], dR, self.itself, dfeat, x_act=self.bot[-1][1])
             else:
                 ops.interact_bwd(feat, dR, self.itself, dfeat, x_act=self.bot[-1][1])
@@ -1346,8 +1448,12 @@ class TrainEngine:
             # the head's partial sums -> loss buffer + running statistics, off the training queue.  The next head kernel
             # overwrites the partials only behind the next gather, which is ordered behind this stream's embedding update
             ops.head_finish(self._head_scratch, B, buf["loss"], stream=side, acc=self.stat_acc)
-        ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
-                             cg.touched if self.multi else None, stream=side)
+        if sv is not None:
+            ops.embbag_bwd_apply_sorted(ctx, n, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work, sv[0], sv[1], sv[3],
+                                        self._phase, once, cg.touched if self.multi else None, stream=side)
+        else:
+            ops.embbag_bwd_apply(ctx, n, lS_o, dfeat[:, 1:, :], dfeat.stride(0), D, self.lr_embeds, emb_work,
+                                 cg.touched if self.multi else None, stream=side)
         emb_done = ev["emb_done"]
         rec(emb_done.record, side)
         self._emb_done = emb_done
@@ -1359,7 +1465,7 @@ class TrainEngine:
                 ops.embbag_take(ctx, next_idx, self._next_res[0], self._next_res[1], res[0], aux_phase=0, stream=side)
             else:
                 res = ops.embbag_probe(ctx, next_idx, stream=side, out=self._probe_bufs(n, which))
-            chain_sort = chain and not (self.sort_after_fwd and fused and attach)
+            chain_sort = chain and not (self.sort_after_fwd and fused and attach) and self._next_sorted is None
             if chain_sort:
                 # ... and the sort of the next batch's slot ids for ITS backward: here it ends well before the step does; issued
                 # at the head of the next step it shared HBM with that step's gather (the roofline kernel).  (sort_after_fwd: the
@@ -1507,7 +1613,8 @@ class TrainEngine:
                self._gslot is not None, self.loss_sync,
                (int(self._pending_resolve["cols"].shape[1]), self._pending_resolve["cols"].stride(0)) if self._mark_this else None,
                self.tape_lanes, self.tape_lanes_below, self.attach_events, self.fold_top_wait, self.top_wgrad_after,
-               self.fuse_gather, self.sort_after_fwd, self.wide_gemm, self.wide_gemm_bottom,
+               self.fuse_gather, self.sort_after_fwd, self.wide_gemm, self.wide_gemm_bottom, self.fuse_once,
+               None if self._cur_sorted is None else self._cur_sorted[3], self._next_sorted is not None,
                self._res[0].stride(0) if (self._res is not None and not hit) else 0,
                self._next_res[0].stride(0) if self._next_res is not None else 0)
         tape = self._tapes.get(key)
@@ -1530,6 +1637,9 @@ class TrainEngine:
             if self._next_res is not None:
                 cells["nws"] = C.c_void_p(self._next_res[0].data_ptr())
                 cells["nwsrc"] = C.c_void_p(self._next_res[1].data_ptr())
+            if self._cur_sorted is not None:
+                sv = self._cur_sorted
+                cells["skeys"], cells["smeta"], cells["sonce"] = C.c_void_p(sv[0]), C.c_void_p(sv[1]), C.c_void_p(sv[2])
             if self._gslot is not None:
                 cells["g0"], cells["g1"] = C.c_void_p(self._gslot[0].handle), C.c_void_p(self._gslot[1].handle)
             if self._mark_this:             # the placed resolve's chunk: index columns, ring slot, the slot's event
@@ -1573,6 +1683,9 @@ class TrainEngine:
         if "nws" in cells:
             cells["nws"].value = self._next_res[0].data_ptr()
             cells["nwsrc"].value = self._next_res[1].data_ptr()
+        if "skeys" in cells:
+            sv = self._cur_sorted
+            cells["skeys"].value, cells["smeta"].value, cells["sonce"].value = sv[0], sv[1], sv[2]
         if "g0" in cells:
             cells["g0"].value, cells["g1"].value = self._gslot[0].handle, self._gslot[1].handle
         if "rcols" in cells:

@@ -210,8 +210,13 @@ def embbag_fwd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.Tenso
 
 
 def embbag_bwd_work(ctx: CacheCtx, n: int, device) -> torch.Tensor:
+    """(zero-filled: embbag_bwd_apply_sorted uses the buffer's scratch without a prepare in front)"""
     nbytes = int(_lib.lib().cdlrm_embbag_bwd_work_bytes(ctx.T, n, ctx.D))
-    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+    work = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+    # the fill runs on the CURRENT stream, the buffer's first user (a prepare) on a side stream of the caller's: it has to have
+    # landed before anything else touches the buffer (once per buffer)
+    torch.cuda.current_stream(device).synchronize()
+    return work
 
 
 def embbag_bwd_sgd(ctx: CacheCtx, slots: torch.Tensor, offsets: Optional[torch.Tensor], grad: torch.Tensor,
@@ -235,6 +240,56 @@ def embbag_bwd_apply(ctx: CacheCtx, n: int, offsets: Optional[torch.Tensor], gra
     check(_lib.lib().cdlrm_embbag_bwd_apply(ctx.handle, ptr(offsets), n, nb, 0 if offsets is None else offsets.stride(0),
                                             grad.data_ptr(), ld_bag, ld_table, float(lr), work.data_ptr(), ptr(touched),
                                             stream_ptr(stream)))
+
+
+def embbag_bwd_apply_rest(ctx: CacheCtx, n: int, offsets: Optional[torch.Tensor], grad: torch.Tensor, ld_bag: int,
+                          ld_table: int, lr: float, work: torch.Tensor, touched: Optional[torch.Tensor] = None, stream=None):
+    """embbag_bwd_apply behind gather_interact_bwd_sgd: the once-only slots are done, the runs of >= 2 lookups are left."""
+    nb = n if offsets is None else offsets.shape[1]
+    check(_lib.lib().cdlrm_embbag_bwd_apply_rest(ctx.handle, ptr(offsets), n, nb, 0 if offsets is None else offsets.stride(0),
+                                                 grad.data_ptr(), ld_bag, ld_table, float(lr), work.data_ptr(), ptr(touched),
+                                                 stream_ptr(stream)))
+
+
+def embbag_bwd_once_flags(ctx: CacheCtx, work: torch.Tensor, n: int) -> int:
+    """Address of the once-only flags (uint8 [T, n]) a prepare left in `work`."""
+    import ctypes as C
+    out = C.c_void_p()
+    check(_lib.lib().cdlrm_embbag_bwd_once_flags(ctx.handle, work.data_ptr(), n, C.byref(out)))
+    return int(out.value)
+
+
+def embbag_bwd_sorted(ctx: CacheCtx, nb: int, n: int, device) -> torch.Tensor:
+    """Caller-owned buffer for the sorted slot lists of a look-ahead chunk of nb batches of n lookups per table."""
+    nbytes = int(_lib.lib().cdlrm_embbag_bwd_sorted_bytes(ctx.T, nb, n))
+    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+
+
+def embbag_bwd_prepare_window(ctx: CacheCtx, wslots: torch.Tensor, batch_len: int, nb: int, n: int, sorted_buf: torch.Tensor,
+                              stream=None, j0: int = 0, count: Optional[int] = None):
+    """Sort the slot ids of batches [j0, j0 + count) of a chunk of nb (default: all of them), every table, at once: wslots int32
+    [T, >= (nb - 1) * batch_len + n] (the resolver's chunk, or a view starting at this rank's first column)."""
+    assert wslots.dtype == torch.int32 and wslots.stride(1) == 1
+    check(_lib.lib().cdlrm_embbag_bwd_prepare_window(ctx.handle, wslots.data_ptr(), wslots.stride(0), batch_len, nb, n, int(j0),
+                                                     int(nb - j0 if count is None else count), sorted_buf.data_ptr(),
+                                                     stream_ptr(stream)))
+
+
+def embbag_bwd_sorted_views(ctx: CacheCtx, sorted_buf: torch.Tensor, nb: int, n: int, j: int):
+    """(keys, meta, once) addresses of batch j inside a sorted chunk; table t's lists lie t * nb * n elements further."""
+    import ctypes as C
+    k, m, o = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(_lib.lib().cdlrm_embbag_bwd_sorted_views(ctx.handle, sorted_buf.data_ptr(), nb, n, j, C.byref(k), C.byref(m), C.byref(o)))
+    return int(k.value), int(m.value), int(o.value)
+
+
+def embbag_bwd_apply_sorted(ctx: CacheCtx, n: int, grad: torch.Tensor, ld_bag: int, ld_table: int, lr: float, work: torch.Tensor,
+                            keys: int, meta: int, tstride: int, aux_phase: int, rest: bool,
+                            touched: Optional[torch.Tensor] = None, stream=None):
+    """embbag_bwd_apply / _apply_rest over a sorted chunk's lists (addresses from embbag_bwd_sorted_views)."""
+    check(_lib.lib().cdlrm_embbag_bwd_apply_sorted(ctx.handle, n, grad.data_ptr(), ld_bag, ld_table, float(lr), work.data_ptr(),
+                                                   keys, meta, tstride, int(aux_phase), int(bool(rest)), ptr(touched),
+                                                   stream_ptr(stream)))
 
 
 # ---- look-ahead window plan -------------------------------------------------------------------------
@@ -458,6 +513,18 @@ def gather_interact_bwd(ctx: CacheCtx, slots: torch.Tensor, x: torch.Tensor, dR:
     check(_lib.lib().cdlrm_gather_interact_bwd(ctx.handle, slots.data_ptr(), slots.stride(0), x.data_ptr(), x.stride(0),
                                                dR.data_ptr(), dR.stride(0), B, int(bool(itself)), int(x_act),
                                                dfeat.data_ptr(), stream_ptr(stream)))
+
+
+def gather_interact_bwd_sgd(ctx: CacheCtx, slots: torch.Tensor, x: torch.Tensor, dR: torch.Tensor, itself: bool,
+                            dfeat: torch.Tensor, once: int, ld_once: int, lr: float, stream=None, x_act: int = 0):
+    """gather_interact_bwd + the SGD step of the slots the batch reads once (their gradient rows are not written).  once: address
+    of the sort's flags (embbag_bwd_once_flags, ld_once = n; embbag_bwd_sorted_views, ld_once = nb * n).  embbag_bwd_apply_rest /
+    embbag_bwd_apply_sorted(rest=True) does the other slots."""
+    B = x.shape[0]
+    assert slots.dtype == torch.int32 and slots.stride(1) == 1 and x.stride(1) == 1 and dfeat.is_contiguous()
+    check(_lib.lib().cdlrm_gather_interact_bwd_sgd(ctx.handle, slots.data_ptr(), slots.stride(0), x.data_ptr(), x.stride(0),
+                                                   dR.data_ptr(), dR.stride(0), B, int(bool(itself)), int(x_act),
+                                                   dfeat.data_ptr(), int(once), int(ld_once), float(lr), stream_ptr(stream)))
 
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}

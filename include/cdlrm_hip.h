@@ -162,6 +162,35 @@ int cdlrm_embbag_bwd_apply(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, in
 int cdlrm_embbag_bwd_sgd(cdlrm_ctx* ctx, const int32_t* slots, const int64_t* offsets, int64_t n,
                          int64_t n_bags, int64_t ld_off, const float* grad, int64_t ld_bag,
                          int64_t ld_table, float lr, void* work, uint8_t* touched, void* stream);
+/* `apply` behind cdlrm_gather_interact_bwd_sgd (below): the rows of slots that the batch reads ONCE were updated by that launch
+ * and their gradient rows never written; this call sums and applies the runs of two and more lookups (and sets the touched
+ * flags of all of them).  Same arguments as cdlrm_embbag_bwd_apply; together the two calls leave the cache rows bit for bit as
+ * cdlrm_gather_interact_bwd + cdlrm_embbag_bwd_apply do (nn.EmbeddingBag backward + optim.SGD, main_no_ddp.py:376, 409, 413). */
+int cdlrm_embbag_bwd_apply_rest(cdlrm_ctx* ctx, const int64_t* offsets, int64_t n, int64_t n_bags,
+                                int64_t ld_off, const float* grad, int64_t ld_bag, int64_t ld_table, float lr,
+                                void* work, uint8_t* touched, void* stream);
+/* The once-only flags `prepare` left in `work`: uint8 [T, n], 1 where the lookup's slot occurs once in the batch (host-side
+ * pointer arithmetic, no launch). */
+int cdlrm_embbag_bwd_once_flags(cdlrm_ctx* ctx, void* work, int64_t n, const uint8_t** once);
+/* The slot sort of a whole look-ahead CHUNK at once (round 6).  Slot ids of a window do not change while it trains
+ * (cdlrm_window_resolve), so the `prepare` of its batches need not wait for their steps: nb batches x T tables are sorted by
+ * one set of launches, on the resolver's stream, into the caller-owned `sorted` (cdlrm_embbag_bwd_sorted_bytes; 256-byte
+ * aligned).  wslots: the resolver's int32 [T, ld_w]; batch j's n slot ids of table t at wslots[t * ld_w + j * batch_len ..]
+ * (a rank passes wslots + its first column and n = its slice).  Aux slots are phase-0 slots, as the resolver writes them.
+ * A call sorts `count` of the chunk's batches from batch j0 on (a SLICE: the trainer spreads a chunk's sort over several steps);
+ * the lists of the other batches are left alone.
+ *   _sorted_views: batch j's sorted keys / run distances / once-only flags; table t's at + t * nb * n elements.
+ *   _apply_sorted: cdlrm_embbag_bwd_apply (rest = 0) or _apply_rest (rest = 1) over those lists instead of `work`'s own sort:
+ *     `work` lends its scratch only (a buffer no `prepare` ever touched must be zero-filled); aux_phase: the aux region the
+ *     batch trains on (what cdlrm_embbag_take was given).  One lookup per bag and table.  Same rows, bit for bit. */
+uint64_t cdlrm_embbag_bwd_sorted_bytes(int32_t num_tables, int32_t nb, int64_t n);
+int cdlrm_embbag_bwd_prepare_window(cdlrm_ctx* ctx, const int32_t* wslots, int64_t ld_w, int64_t batch_len, int32_t nb,
+                                    int64_t n, int32_t j0, int32_t count, void* sorted, void* stream);
+int cdlrm_embbag_bwd_sorted_views(cdlrm_ctx* ctx, void* sorted, int32_t nb, int64_t n, int32_t j, const uint64_t** keys,
+                                  const int32_t** meta, const uint8_t** once);
+int cdlrm_embbag_bwd_apply_sorted(cdlrm_ctx* ctx, int64_t n, const float* grad, int64_t ld_bag, int64_t ld_table, float lr,
+                                  void* work, const uint64_t* keys, const int32_t* meta, int64_t tstride, int32_t aux_phase,
+                                  int32_t rest, uint8_t* touched, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Look-ahead window path: Prefetcher.process_batch_slice (cache_manager.py:28-46) and
@@ -377,6 +406,16 @@ int cdlrm_gather_interact_fwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, c
 int cdlrm_gather_interact_bwd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
                               const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act, float* dfeat,
                               void* stream);
+/* The same with the sparse SGD step of the once-only slots folded in (main_no_ddp.py:376 backward + :413 optimizer_embeds.step()
+ * for those rows).  once: uint8 flags of the batch's lookups, table t's at once + t * ld_once (cdlrm_embbag_bwd_once_flags of
+ * the batch's prepared work buffer, ld_once = n; or cdlrm_embbag_bwd_sorted_views, ld_once = nb * n) -- written by a sort that has
+ * COMPLETED (the caller orders the streams); lr: the embedding learning rate.  A lookup whose slot no other lookup of the batch
+ * shares gets W[slot] -= lr * g in this launch (one addend: no order to keep) and its gradient row in dfeat is left UNDEFINED
+ * (not written, but for stray words of the last table's); every other lookup's gradient row is written as before.  Follow
+ * with cdlrm_embbag_bwd_apply_rest / _apply_sorted(rest = 1) on the same sort. */
+int cdlrm_gather_interact_bwd_sgd(cdlrm_ctx* ctx, const int32_t* slots, int64_t n, const float* x, int64_t ld_x,
+                                  const float* dR, int64_t ld_r, int64_t B, int32_t itself, int32_t x_act, float* dfeat,
+                                  const uint8_t* once, int64_t ld_once, float lr, void* stream);
 /* Linear + activation (create_mlp, model_no_ddp.py:244-270): Y = act(X W^T + b).
  * X [M, K] ld_x, W [N, K] row-major (nn.Linear.weight), Y [M, N] ld_y. act: 0 none, 1 ReLU, 2 sigmoid. */
 /* CDLRM_GEMM_ALONE, or-ed into `act` of cdlrm_linear_fwd / cdlrm_linear_bwd: the caller's promise that no other GEMM runs beside

@@ -170,8 +170,9 @@ def _run_full_size(config, host, L, n_windows, steps_per_window, max_ind_range=-
     eng.finish()
     cg.ctx.check()
     torch.cuda.synchronize()
-    out = dict(losses=torch.cat(losses).cpu(), tags=cg.tags.clone(), wsum=cg.weight.data.sum(dtype=torch.float64).item(),
-               feats=feats, params=eng.param_flat.clone())
+    # (in pieces: a float64 sum of the whole cache converts it at once -- 65 GiB at c5, beside everything else of the run)
+    wsum = sum(c.sum(dtype=torch.float64).item() for c in cg.weight.data.split(1 << 21))
+    out = dict(losses=torch.cat(losses).cpu(), tags=cg.tags.clone(), wsum=wsum, feats=feats, params=eng.param_flat.clone())
     del w, cg, eng, pipe, syn
     torch.cuda.empty_cache()
     return out

@@ -613,6 +613,152 @@ def test_fused_gather_interaction_equals_the_two_operators(ops, B, T, D, itself,
             np.testing.assert_allclose(dfeat2.cpu().numpy(), f.grad.float().numpy(), rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("B,T,D,itself,x_act,span", [(3000, 26, 128, 0, 1, 20000), (1, 26, 128, 0, 1, 50), (5, 16, 32, 1, 0, 4),
+                                                     (1023, 31, 64, 0, 2, 700), (2100, 26, 256, 1, 1, 90000),
+                                                     (8192, 26, 128, 0, 1, 6000), (20000, 26, 128, 0, 1, 3)])
+def test_once_only_slots_updated_by_the_interaction_backward(ops, B, T, D, itself, x_act, span):
+    """cdlrm_gather_interact_bwd_sgd + cdlrm_embbag_bwd_apply_rest (the SGD step of the slots a batch reads once folded into
+    the interaction backward, the sorted path left with the repeated slots) against cdlrm_gather_interact_bwd +
+    cdlrm_embbag_bwd_apply on the same prepared work buffer: the cache rows, the touched flags and the dense feature's gradient
+    bit for bit; the gradient rows of the repeated slots bit for bit, those of the once-only slots never written (the poison
+    stays; the last table's are undefined).  Slot ranges from "almost every slot once" to "three slots per table"; aux rows are slot targets (never flagged)."""
+    rng = np.random.RandomState(B + T + D + span)
+    ln = [int(v) for v in rng.randint(50, 90000, size=T)]
+    P, ways, aux = 6007, 4, 512
+    cs = [min(P, v) for v in ln]
+    dev = torch.device(DEV)
+    ctx = ops.CacheCtx(ln, cs, D, ways, aux, dev)
+    tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+    w0 = torch.from_numpy(rng.randn(ctx.total_rows, D).astype(np.float32)).to(DEV)
+    weight = w0.clone()
+    ctx.bind_cache(tags, weight)
+    rows_of = [cs[k] * ways + aux for k in range(T)]
+    slots = torch.stack([torch.from_numpy((rows_of[k] - 1 - rng.randint(0, min(span, rows_of[k]), size=B)).astype(np.int32))
+                         for k in range(T)]).to(DEV)
+    F = T + 1
+    npairs = F * (F + 1) // 2 if itself else F * (F - 1) // 2
+    ld = (D + npairs + 3) // 4 * 4
+    x = torch.from_numpy(rng.rand(B, D).astype(np.float32)).to(DEV)
+    dR = torch.from_numpy(rng.randn(B, ld).astype(np.float32)).to(DEV)
+    work = ops.embbag_bwd_work(ctx, B, dev)
+    lr = 0.37
+    # the two operators
+    dfeat = torch.empty(B, F, D, device=DEV)
+    touched = torch.zeros(ctx.total_rows, dtype=torch.uint8, device=DEV)
+    ops.embbag_bwd_prepare(ctx, slots, work)
+    ops.gather_interact_bwd(ctx, slots, x, dR, bool(itself), dfeat, x_act=x_act)
+    ops.embbag_bwd_apply(ctx, B, None, dfeat[:, 1:, :], F * D, D, lr, work, touched)
+    torch.cuda.synchronize()
+    w_ref = weight.clone()
+    # folded
+    weight.copy_(w0)
+    POISON = 12345.0
+    dfeat2 = torch.full((B, F, D), POISON, device=DEV)
+    touched2 = torch.zeros_like(touched)
+    ops.embbag_bwd_prepare(ctx, slots, work)
+    ops.gather_interact_bwd_sgd(ctx, slots, x, dR, bool(itself), dfeat2, ops.embbag_bwd_once_flags(ctx, work, B), B, lr,
+                                x_act=x_act)
+    ops.embbag_bwd_apply_rest(ctx, B, None, dfeat2[:, 1:, :], F * D, D, lr, work, touched2)
+    torch.cuda.synchronize()
+    assert torch.equal(weight, w_ref)
+    assert torch.equal(touched, touched2)
+    assert torch.equal(dfeat[:, 0, :], dfeat2[:, 0, :])
+    sl = slots.cpu().numpy()
+    once = np.zeros((T, B), dtype=bool)
+    for k in range(T):
+        _, inv, cnt = np.unique(sl[k], return_inverse=True, return_counts=True)
+        once[k] = cnt[inv] == 1
+    once_t = torch.from_numpy(once.T.copy()).to(DEV)                    # [B, T]
+    g1, g2 = dfeat[:, 1:, :], dfeat2[:, 1:, :]
+    assert torch.equal(g1[~once_t], g2[~once_t])
+    # ... of tables 0 .. T-2: the store's spare lanes repeat the LAST row's last word (an unread duplicate), whatever its flag
+    assert bool((g2[:, :T - 1][once_t[:, :T - 1]] == POISON).all())
+    assert once.any() or span <= 4
+    # an aux row (transient copy of a host row) is updated but never flagged
+    rb = torch.tensor(ctx.row_base[:T], device=DEV).view(T, 1)
+    aux_first = torch.tensor([cs[k] * ways for k in range(T)], device=DEV).view(T, 1)
+    is_aux = (slots.to(torch.int64) >= aux_first)
+    assert not bool(touched2[(slots.to(torch.int64) + rb)[is_aux]].any())
+
+
+@pytest.mark.parametrize("T,D,n,nb,batch_len,col0,span", [(26, 128, 2048, 5, 2048, 0, 3000), (26, 128, 1000, 3, 2500, 700, 40),
+                                                          (19, 32, 8192, 2, 8192, 0, 100000), (26, 64, 3000, 4, 3000, 0, 5),
+                                                          (26, 128, 20000, 2, 20000, 0, 9000)])
+def test_window_sorted_chunk_equals_per_batch_sort(ops, T, D, n, nb, batch_len, col0, span):
+    """cdlrm_embbag_bwd_prepare_window (nb batches x T tables sorted by one set of launches, out of the resolver's [T, nb *
+    batch_len] phase-0 slot ids, a rank's slice starting at col0) + cdlrm_embbag_bwd_apply_sorted against the per-batch
+    cdlrm_embbag_bwd_prepare + _apply on the slot ids cdlrm_embbag_take would hand that batch (aux slots moved to the batch's aux
+    region): cache rows and touched flags bit for bit, with the once-only slots in the sorted path (rest = 0) and folded into the
+    interaction backward (rest = 1); the chunk's once-only flags equal the per-batch sort's."""
+    rng = np.random.RandomState(T + D + n + nb + span)
+    ln = [int(v) for v in rng.randint(50, 90000, size=T)]
+    P, ways, aux = 6007, 4, 1024
+    cs = [min(P, v) for v in ln]
+    dev = torch.device(DEV)
+    ctx = ops.CacheCtx(ln, cs, D, ways, aux, dev, aux_phases=2)
+    tags = torch.full((ctx.total_tags,), -1, dtype=torch.int64, device=DEV)
+    w0 = torch.from_numpy(rng.randn(ctx.total_rows, D).astype(np.float32)).to(DEV)
+    weight = w0.clone()
+    ctx.bind_cache(tags, weight)
+    width = nb * batch_len
+    first_aux = [cs[k] * ways for k in range(T)]
+    # phase-0 slots: cache rows [first_aux - span, first_aux) and aux rows [first_aux, first_aux + aux)
+    wsl = torch.stack([torch.from_numpy((first_aux[k] + rng.randint(-min(span, first_aux[k]), min(aux, max(span // 8, 2)), size=width))
+                                        .astype(np.int32)) for k in range(T)]).to(DEV)
+    sorted_buf = ops.embbag_bwd_sorted(ctx, nb, n, dev)
+    if nb > 2:          # in slices of two batches (the trainer spreads a chunk's sort over several steps), last slice first
+        for j0 in reversed(range(0, nb, 2)):
+            ops.embbag_bwd_prepare_window(ctx, wsl[:, col0:], batch_len, nb, n, sorted_buf, j0=j0, count=min(2, nb - j0))
+    else:
+        ops.embbag_bwd_prepare_window(ctx, wsl[:, col0:], batch_len, nb, n, sorted_buf)
+    F = T + 1
+    npairs = F * (F - 1) // 2
+    ld = (D + npairs + 3) // 4 * 4
+    lr = 0.21
+    work = ops.embbag_bwd_work(ctx, n, dev)
+    work2 = ops.embbag_bwd_work(ctx, n, dev)
+    fa = torch.tensor(first_aux, dtype=torch.int32, device=DEV).view(T, 1)
+    fused = ops.gather_interact_supported(ctx)
+    for j in range(nb):
+        phase = j & 1
+        sl = wsl[:, j * batch_len + col0: j * batch_len + col0 + n].clone()
+        sl = torch.where(sl >= fa, sl + phase * aux, sl).contiguous()
+        x = torch.from_numpy(rng.rand(n, D).astype(np.float32)).to(DEV)
+        dR = torch.from_numpy(rng.randn(n, ld).astype(np.float32)).to(DEV)
+        dfeat = torch.empty(n, F, D, device=DEV)
+        touched = torch.zeros(ctx.total_rows, dtype=torch.uint8, device=DEV)
+        weight.copy_(w0)
+        ops.embbag_bwd_prepare(ctx, sl, work)
+        if fused:
+            ops.gather_interact_bwd(ctx, sl, x, dR, False, dfeat, x_act=1)
+        else:
+            dfeat.copy_(torch.from_numpy(rng.randn(n, F, D).astype(np.float32)))
+        ops.embbag_bwd_apply(ctx, n, None, dfeat[:, 1:, :], F * D, D, lr, work, touched)
+        torch.cuda.synchronize()
+        w_ref = weight.clone()
+        keys, meta, once = ops.embbag_bwd_sorted_views(ctx, sorted_buf, nb, n, j)
+        # the flags: [T, n] at pitch nb * n inside the chunk against the per-batch sort's
+        o0 = once - sorted_buf.data_ptr()
+        got = torch.stack([sorted_buf[o0 + k * nb * n: o0 + k * nb * n + n] for k in range(T)])
+        r0 = ops.embbag_bwd_once_flags(ctx, work, n) - work.data_ptr()
+        assert torch.equal(got, work[r0:r0 + T * n].view(T, n))
+        # rest = 0: every run in the sorted path
+        weight.copy_(w0)
+        t2 = torch.zeros_like(touched)
+        ops.embbag_bwd_apply_sorted(ctx, n, dfeat[:, 1:, :], F * D, D, lr, work2, keys, meta, nb * n, phase, False, t2)
+        torch.cuda.synchronize()
+        assert torch.equal(weight, w_ref) and torch.equal(touched, t2)
+        if fused:
+            weight.copy_(w0)
+            t3 = torch.zeros_like(touched)
+            dfeat3 = torch.full((n, F, D), 777.0, device=DEV)
+            ops.gather_interact_bwd_sgd(ctx, sl, x, dR, False, dfeat3, once, nb * n, lr, x_act=1)
+            ops.embbag_bwd_apply_sorted(ctx, n, dfeat3[:, 1:, :], F * D, D, lr, work2, keys, meta, nb * n, phase, True, t3)
+            torch.cuda.synchronize()
+            assert torch.equal(weight, w_ref) and torch.equal(touched, t3)
+            assert torch.equal(dfeat[:, 0, :], dfeat3[:, 0, :])
+
+
 def test_fused_gather_interaction_refuses_other_shapes(ops):
     """Shapes outside the slab kernels (F <= 16, an embedding width that is none of 32 / 64 / 128 / 256) are refused with a
     message -- the caller issues the two operators -- and a timed launch leaves its stamps in the armed events."""

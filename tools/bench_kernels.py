@@ -85,6 +85,23 @@ def main():
         us_a = timeit(lambda: ops.embbag_bwd_apply(ctx, B, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched))
         print("  prepare (slot sort) %7.1f us | apply (sums + row update) %7.1f us = %.1f GB/s = %.1f%% of 8 TB/s" % (
             us_p, us_a, look * (12 * D + 8) / us_a / 1e3, look * (12 * D + 8) / us_a / 1e3 / 80))
+        # the apply by kernel form (cdlrm_debug_set 6 bit 64: a lane group per block of 32 sorted positions instead of per position) and by
+        # workgroups per CU (key 1); both forms must leave the same rows behind
+        from cdlrm_amd import _lib
+        w0 = weight.clone()
+        res = {}
+        for form in (0, 64):
+            _lib.raw().cdlrm_debug_set(6, form)
+            weight.copy_(w0)
+            ops.embbag_bwd_sgd(ctx, slots, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched)
+            res[form] = weight.clone()
+            for cap in (0, 4, 24, -1):
+                _lib.raw().cdlrm_debug_set(1, cap)
+                us_a = timeit(lambda: ops.embbag_bwd_apply(ctx, B, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched))
+                print("  apply form %2d  cap %2d per CU: %7.1f us" % (form, cap, us_a))
+            _lib.raw().cdlrm_debug_set(1, 0)
+        _lib.raw().cdlrm_debug_set(6, 0)
+        print("  block form (64) == position form (0), bitwise:", bool(torch.equal(res[0], res[64])))
 
     if want("gather_beside"):
         # how much does the gather (the roofline kernel) lose when it runs beside MFMA-bound GEMMs on another stream?
