@@ -852,6 +852,9 @@ def main():
                        # (the reference's host Exp(1) draws, bit-exact ways) is what the golden tests run
                        "insert_rng": "device-philox",
                        "wide_gemm": bool(eng.wide_gemm),
+                       # the embedding backward's slot sort per look-ahead chunk slice (off the step's queues) and the SGD step
+                       # of once-only slots inside the interaction backward
+                       "sort_chunks": bool(eng.sort_chunks), "fuse_once": bool(eng.fuse_once),
                        # FLAT copies of the figures that matter (the driver's parse keeps scalars only): the whole-window leg --
                        # L steps with exactly one background plan and one commit inside, the figure that matches the metric's
                        # "wall incl. refills" -- and the roofline kernel alone / the stand-alone gather operator

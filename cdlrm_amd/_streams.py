@@ -61,6 +61,21 @@ def background_stream(device):
     return st
 
 
+def low_priority_stream(device):
+    """Another stream of the least urgent priority, distinct from background_stream's (the engine's chunk sort: work whose
+    result is needed many steps later must not queue behind a plan's DMA copies, nor in front of anything a step waits for)."""
+    if not is_hip(device):
+        return _NullStream()
+    from . import _lib
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        h = _lib.raw().cdlrm_stream_create(1 << 20)
+    if not h:
+        raise _lib.CdlrmError(-22, _lib.raw().cdlrm_last_error().decode("utf-8", "replace"))
+    return torch.cuda.ExternalStream(int(h), device=torch.device("cuda", idx))
+
+
 def current_stream(device):
     return torch.cuda.current_stream(device) if is_hip(device) else _NullStream()
 

@@ -515,7 +515,11 @@ class WindowResolver:
         # interaction backward finds the once-only flags there (TrainEngine.fuse_once) without waiting for anything: the
         # slice's event is waited for by the stream that runs the batch's take, which the step's gather waits for anyway.
         self.sort_chunks = bool(getattr(engine, "sort_chunks", False)) and S.is_hip(engine.dev) and self.width > 0
-        self.SL = max(1, min(int(getattr(engine, "sort_slice", 4)), self.CH))
+        # (short batches: the slice's four runtime calls are host time the issuing thread does not have every other step --
+        #  per-rank 1024: 0.1852 ms with slices of 2 against 0.1824 with the per-step sort on the launch tape -- and its kernels
+        #  are small: as many batches as make ~16 k lookups per table)
+        sl = int(getattr(engine, "sort_slice", 2))
+        self.SL = max(1, min(max(sl, (sl * 8192) // max(self.width, 1)), self.CH))
         self.sorted_upto = 0        # batches [0, sorted_upto) of the window have had their slice's turn
         self._sorted_at = {}        # first batch of a slice whose sort was issued -> batches in it (engine.sort_chunks at that time)
         engine._sev_waited = None   # (the slice events are shared by every resolver of the engine)
@@ -613,10 +617,18 @@ class WindowResolver:
             j0 = b0 - c * self.CH
             cnt = min(self.SL, nbc - j0)
             if getattr(eng, "sort_chunks", True):       # (switched per slice by tools/ab_step.py)
-                eng.side.wait_event(ev)                 # the chunk's resolve (prefetch stream)
+                st = eng.sort_stream()
+                st.wait_event(ev)                       # the chunk's resolve (prefetch stream)
+                # the ring slot's previous lists were read by embedding updates three chunks back; what the wait really picks is
+                # WHERE in the step the sort runs: behind the last step's embedding update = in that step's tail
+                after = getattr(eng, "sort_after", "emb_done")
+                if after == "interacted":
+                    st.wait_event(eng._events["interacted"])
+                elif eng._emb_done is not None:
+                    st.wait_event(eng._emb_done)
                 ops.embbag_bwd_prepare_window(self.ctx, ws[:, self.col0:], self.B, nbc, self.width,
-                                              self._sorted_ring[c % self.RING], stream=eng.side, j0=j0, count=cnt)
-                self._sorted_ev[c % self.RING][j0 // self.SL].record(eng.side)
+                                              self._sorted_ring[c % self.RING], stream=st, j0=j0, count=cnt)
+                self._sorted_ev[c % self.RING][j0 // self.SL].record(st)
                 self._sorted_at[b0] = cnt
             self.sorted_upto = b0 + cnt
             self._sorted_at.pop(b0 - 3 * self.CH, None)
@@ -777,7 +789,11 @@ class TrainEngine:
         # the slot sort of the embedding backward per look-ahead chunk slice instead of per step (WindowResolver.ensure_sorted);
         # steps of batches without sorted lists (no resolver, multi-hot bags) sort their own
         self.sort_chunks = True
-        self.sort_slice = 4
+        # batches per slice.  tools/ab_step.py, one box, four rounds each, c3, against the per-step sort (0.547-0.552 ms): slices of
+        # 1 / 2 / 4 / 8 / 16 batches -1.1 / -1.5 .. -2.2 / -1.1 / -0.8 / +0.4 %: what pays is the sort OFF the queues a step waits for
+        # and the folded once-only update it allows, not the batching -- a long slice is a long visitor in one step's tail
+        self.sort_slice = 2
+        self.sort_after = "emb_done"
         self._cur_sorted = self._next_sorted = None
         self._sev_waited = None
         # --evict-victim-cache (main_no_ddp.py:96, parsed and unused by the reference): behind every step's embedding update
@@ -912,6 +928,15 @@ class TrainEngine:
         self.mark_next = False
         if pr is not None:
             self._issue_resolve(pr, lambda fn, *a: fn(*a), S.current_stream(self.dev), placed=False)
+
+    def sort_stream(self):
+        """Where a look-ahead chunk's slot lists are sorted (WindowResolver.ensure_sorted): a stream of its own, least urgent --
+        on the side stream the sort sat in front of the `gathered` record the next step's interaction forward waits for (a 36 us
+        bubble on the training queue in every step that followed a slice), on the prefetch stream in front of the next take."""
+        if getattr(self, "_sort_stream", None) is None:
+            which = getattr(self, "sort_on", "own")
+            self._sort_stream = {"side": self.side, "pref": self.pref}.get(which) or S.low_priority_stream(self.dev)
+        return self._sort_stream
 
     def _fused_gather(self, lS_o) -> bool:
         """This step's gather rides in the interaction kernels (fuse_gather)."""

@@ -102,6 +102,12 @@ def main():
             _lib.raw().cdlrm_debug_set(1, 0)
         _lib.raw().cdlrm_debug_set(6, 0)
         print("  block form (64) == position form (0), bitwise:", bool(torch.equal(res[0], res[64])))
+        # what cdlrm_embbag_bwd_apply_rest is left with once the interaction backward has done the once-only slots
+        for cap in (0, 4, 24, -1):
+            _lib.raw().cdlrm_debug_set(1, cap)
+            us_r = timeit(lambda: ops.embbag_bwd_apply_rest(ctx, B, None, grad[:, 1:, :], (T + 1) * D, D, 0.01, work, touched))
+            print("  apply_rest (runs of >= 2 lookups)  cap %2d per CU: %7.1f us" % (cap, us_r))
+        _lib.raw().cdlrm_debug_set(1, 0)
 
     if want("gather_beside"):
         # how much does the gather (the roofline kernel) lose when it runs beside MFMA-bound GEMMs on another stream?
