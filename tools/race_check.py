@@ -32,6 +32,12 @@ VARIANTS = {
     "top weight gradients behind the bottom input gradients": {"top_wgrad_after": "bot_dz"},
     "top weight gradients behind the bottom weight gradients": {"top_wgrad_after": "bot_wg"},
     "gather + interaction as two launches (the block written and read back)": {"fuse_gather": False},
+    "slot sort per step (no chunk slices, no folded once-only update)": {"sort_chunks": False},
+    "chunk slices, once-only slots in the sorted path": {"fuse_once": False},
+    "slices of one batch": {"sort_slice": 1},
+    "slices of five batches, sorted on the side stream": {"sort_slice": 5, "sort_on": "side"},
+    "slices sorted on the prefetch stream, chained take": {"sort_on": "pref", "gather_alone_min": 1},
+    "slices behind the interaction backward": {"sort_after": "interacted"},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
 }
