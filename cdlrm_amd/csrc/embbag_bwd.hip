@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) k_bwd_chunks(const TableDesc* __restrict_
 // heads become two bit masks (a ballot), and the heads of the block are worked FOUR AT A TIME with four gradient rows each in
 // flight (16 rows when the block holds one head: the inside of a long run).  Two dependent reads per block instead of four per
 // position.
-template <int LPR, bool ARANGE>
+template <int LPR, bool ARANGE, int HU = 4, int RA = 16>
 __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict__ tab, int D4,
                                                     float4* __restrict__ weight, const uint64_t* __restrict__ keys,
                                                     const int32_t* __restrict__ meta,
@@ -412,17 +412,17 @@ __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict_
                     float4 w;
                     if (single) w = weight[(row_base + slot) * D4 + cc];
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int q = 0; q < len; q += 16) {
-                        float4 v[16];
+                    for (int q = 0; q < len; q += RA) {
+                        float4 v[RA];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u)
+                        for (int u = 0; u < RA; ++u)
                             if (q + u < len) {
                                 const int64_t pos = s_pos[gid][j + q + u];
                                 const int64_t bag = ARANGE ? pos : bag_of(off, n_bags, pos);
                                 v[u] = *reinterpret_cast<const float4*>(g + bag * ld_bag + cc * 4);
                             }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u)
+                        for (int u = 0; u < RA; ++u)
                             if (q + u < len) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
                     }
                     if (single) {
@@ -446,12 +446,12 @@ __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict_
                 continue;
             }
             // up to four heads, four gradient rows of each in flight
-            int hj[4], hlen[4];
-            bool hhead[4], hsingle[4], hmore[4];
-            uint32_t hslot[4];
+            int hj[HU], hlen[HU];
+            bool hhead[HU], hsingle[HU], hmore[HU];
+            uint32_t hslot[HU];
             int maxlen = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < HU; ++u) {
                 hlen[u] = 0; hj[u] = 0; hhead[u] = false; hsingle[u] = false; hmore[u] = false; hslot[u] = 0;
                 if (H) {
                     const int j = __ffs((int)H) - 1;
@@ -468,16 +468,16 @@ __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict_
                 }
             }
             for (int cc = c; cc < D4; cc += LPR) {
-                float4 w[4], acc[4];
+                float4 w[HU], acc[HU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < HU; ++u) {
                     acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (hsingle[u]) w[u] = weight[(row_base + hslot[u]) * D4 + cc];
                 }
                 for (int q = 0; q < maxlen; q += 4) {
-                    float4 v[4][4];
+                    float4 v[HU][4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < HU; ++u)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (q + k < hlen[u]) {
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict_
                                 v[u][k] = *reinterpret_cast<const float4*>(g + bag * ld_bag + cc * 4);
                             }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < HU; ++u)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (q + k < hlen[u]) {
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict_
                             }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < HU; ++u) {
                     if (hlen[u] == 0) continue;
                     if (hsingle[u]) {
                         w[u].x = fmaf(-lr, acc[u].x, w[u].x); w[u].y = fmaf(-lr, acc[u].y, w[u].y);
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_bwd_blocks(const TableDesc* __restrict_
             }
             if (c == 0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < HU; ++u) {
                     if (hlen[u] == 0) continue;
                     const int64_t p = p0 + hj[u];
                     if (hsingle[u]) {
@@ -807,6 +807,13 @@ static int cdlrm_embbag_bwd_apply_core(cdlrm_ctx* ctx, const int64_t* offsets, i
         const int64_t cap = cdiv((int64_t)256 * per_cu, T);
         if (g_cdlrm_debug[1] >= 0 && bx > cap) bx = cap;
         dim3 bgrid((unsigned)bx, (unsigned)T);
+#define BLK_CALL_LEAN(L)                                                                                           \
+    hipLaunchKernelGGL((k_bwd_blocks<L, true, 2, 8>), bgrid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,  \
+                       n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,      \
+                       touched, aux_total, w.runend, skip_once, kstride, ways, aux_add)
+        if (!offsets && (g_cdlrm_debug[6] & 128)) {
+            DISPATCH_LPR_B(lpr, BLK_CALL_LEAN)
+        } else {
 #define BLK_CALL(L)                                                                                                \
     if (offsets)                                                                                                   \
         hipLaunchKernelGGL((k_bwd_blocks<L, false>), bgrid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,   \
@@ -818,6 +825,8 @@ static int cdlrm_embbag_bwd_apply_core(cdlrm_ctx* ctx, const int64_t* offsets, i
                            touched, aux_total, w.runend, skip_once, kstride, ways, aux_add)
         DISPATCH_LPR_B(lpr, BLK_CALL)
 #undef BLK_CALL
+        }
+#undef BLK_CALL_LEAN
     } else {
         int64_t gx = cdiv(n, gpb);
         if (gx > 65535) gx = 65535;
