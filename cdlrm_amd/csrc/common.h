@@ -86,7 +86,8 @@ void cdlrm_set_error(const char* fmt, ...);
 //      gradients (all / the 512-wide ones) on the wide kernel.  Different contraction order inside a 16-deep group than
 //      k_gemm2: equal to fp32 rounding, not bit for bit.  64 = the embedding backward's sums (cdlrm_embbag_bwd_apply) with a lane group
 //      per block of 32 sorted positions (k_bwd_blocks, the kernel of cdlrm_embbag_bwd_apply_rest) instead of per position
-//      (k_bwd_chunks): bit-identical.
+//      (k_bwd_chunks): bit-identical.  128 = cdlrm_embbag_bwd_apply_rest / _apply_sorted(rest) with four heads x four rows
+//      (sixteen for a lone head) in flight instead of one head x four (eight): bit-identical.
 //      -DCDLRM_DEV builds ONLY (timing experiments that SKIP work; the shipped library refuses them): 1 = no embedding
 //      update, 2 = no slot sort
 //   7: bits: 1 = the epilogues before round 5 (operands fetched behind, not ahead of, their use); 2 = the fused gather +

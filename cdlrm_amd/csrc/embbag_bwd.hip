@@ -807,11 +807,17 @@ static int cdlrm_embbag_bwd_apply_core(cdlrm_ctx* ctx, const int64_t* offsets, i
         const int64_t cap = cdiv((int64_t)256 * per_cu, T);
         if (g_cdlrm_debug[1] >= 0 && bx > cap) bx = cap;
         dim3 bgrid((unsigned)bx, (unsigned)T);
-#define BLK_CALL_LEAN(L)                                                                                           \
-    hipLaunchKernelGGL((k_bwd_blocks<L, true, 2, 8>), bgrid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n,  \
+#define BLK_LEAN(L, HU_, RA_)                                                                                      \
+    hipLaunchKernelGGL((k_bwd_blocks<L, true, HU_, RA_>), bgrid, dim3(256), 0, s, ctx->d_tab, D4, wt, cur, meta, offsets, n, \
                        n_bags, ld_off, grad, ld_bag, ld_table, lr, w.partials, w.pstride, w.longlist, w.longcount,      \
                        touched, aux_total, w.runend, skip_once, kstride, ways, aux_add)
-        if (!offsets && (g_cdlrm_debug[6] & 128)) {
+#define BLK_CALL_LEAN(L) BLK_LEAN(L, 1, 8)
+        // The runs of >= 2 lookups, one lookup per bag: ONE head at a time with four rows in flight (eight when the block holds one
+        // head) -- 4 x 4 / 16 rows in flight need 239 registers, and beside the weight-gradient GEMMs it is the kernel's footprint on
+        // a SIMD, not its own latency chain, that the step pays for (alone it finishes in 30 us either way).  c3, tools/ab_step.py,
+        // one box, 4 rounds: heads x rows / lone-head rows 4x4/16: 0.5393 ms, 2x4/8: 0.5357, 1x4/8: 0.5332, 2x4/4: 0.5362,
+        // 1x4/4: 0.5350.  cdlrm_debug_set(6, 128): the 4x4/16 form.
+        if (!offsets && skip_once && !(g_cdlrm_debug[6] & 128)) {
             DISPATCH_LPR_B(lpr, BLK_CALL_LEAN)
         } else {
 #define BLK_CALL(L)                                                                                                \
@@ -827,6 +833,7 @@ static int cdlrm_embbag_bwd_apply_core(cdlrm_ctx* ctx, const int64_t* offsets, i
 #undef BLK_CALL
         }
 #undef BLK_CALL_LEAN
+#undef BLK_LEAN
     } else {
         int64_t gx = cdiv(n, gpb);
         if (gx > 65535) gx = 65535;
