@@ -285,6 +285,83 @@ def test_window_resolver_ring_never_recycles_a_live_chunk(monkeypatch, CH, nb, s
     assert set(eng._bufs) == {("wres", CH * B), ("wres_ev",)}      # one ring of buffers, one ring of events: nothing per chunk
 
 
+@pytest.mark.parametrize("CH,SL,nb,B", [(16, 2, 100, 8192), (4, 4, 37, 8192), (3, 2, 20, 8192), (16, 2, 70, 1024), (2, 1, 9, 8192)])
+def test_window_resolver_sorts_slices_ahead_of_their_steps(monkeypatch, CH, SL, nb, B):
+    """engine.WindowResolver.ensure_sorted (the embedding backward's slot sort per look-ahead chunk slice): host-side protocol with
+    the library calls stubbed out.  After the ensure() that follows step j the lists of batch j + 2 are sorted (the next step
+    issues that batch's take, whose stream waits for the slice); a slice is issued after its chunk's resolve and into the
+    chunk's ring slot only when every batch of the slot's previous holder has been stepped; a batch handed to a step has
+    sorted lists unless the engine's switch was off when its slice fell due (then it has none and the step sorts its own)."""
+    import cdlrm_amd.engine as engine
+    S = engine.S
+    monkeypatch.setattr(S, "is_hip", lambda dev: True)
+    monkeypatch.setattr(S, "new_event", lambda dev, timing=False: S._NullEvent())
+    monkeypatch.setattr(S, "current_stream", lambda dev: S._NullStream())
+    log = []
+
+    class Ctx:
+        T = 2
+
+    class Eng:
+        ctx, world, rank, dev = Ctx(), 1, 0, torch.device("cpu")
+        pref = side = S._NullStream()
+        sort_chunks, sort_slice, sort_after, _emb_done, _events = True, SL, "emb_done", None, {}
+
+        def __init__(self):
+            self._bufs, self._pending_resolve, self.mark_next = {}, None, False
+
+        def sort_stream(self):
+            return S._NullStream()
+
+    monkeypatch.setattr(engine.ops, "window_resolve",
+                        lambda ctx, cols, lbs, ws, wsrc, stream=None, batch_len=0: log.append(("resolve", ws.data_ptr())))
+    monkeypatch.setattr(engine.ops, "embbag_bwd_sorted", lambda ctx, nbc, n, dev: torch.zeros(8, dtype=torch.uint8))
+    monkeypatch.setattr(engine.ops, "embbag_bwd_prepare_window",
+                        lambda ctx, ws, batch_len, nbc, n, buf, stream=None, j0=0, count=None:
+                        log.append(("sort", ws.data_ptr(), buf.data_ptr(), nbc, j0, count, batch_len, n)))
+    monkeypatch.setattr(engine.ops, "embbag_bwd_sorted_views", lambda ctx, buf, nbc, n, jl: (buf.data_ptr(), nbc, jl))
+    win = torch.zeros(2, nb * B, dtype=torch.int64)
+    eng = Eng()
+    rs = engine.WindowResolver(eng, win, B, chunk=CH)
+    sl = rs.SL
+    assert sl == max(1, min(max(SL, SL * 8192 // B), CH)), "slice length: ~16 k lookups per table at short batches"
+    first_sorted = {}                                       # batch -> index in the log of the sort that covers it
+    seen = [0]
+
+    def check_new_sorts(stepped):
+        before, seen[0] = seen[0], len(log)
+        for k in range(before, len(log)):
+            if log[k][0] != "sort":
+                continue
+            _, wsp, bufp, nbc, j0, cnt, batch_len, n = log[k]
+            c = next(cc for cc in range(-(-nb // CH)) if rs._ring[cc % 3][0].data_ptr() == wsp and cc * CH + j0 > stepped)
+            assert ("resolve", wsp) in log[:k], "a slice is sorted after its chunk's resolve was issued"
+            assert c < 3 or (c - 3) * CH + CH - 1 <= stepped, "the ring slot's previous lists may still be read"
+            assert batch_len == B and n == B and 1 <= cnt <= sl and j0 % sl == 0 and j0 + cnt <= nbc
+            for b in range(c * CH + j0, c * CH + j0 + cnt):
+                first_sorted[b] = k
+
+    check_new_sorts(-1)                                     # the window's first slices are issued by the constructor
+    assert 0 in first_sorted and 1 in first_sorted or nb < 2
+    off_at = nb // 2                                        # the engine's switch goes off for one slice in the middle
+    for j in range(nb):
+        r = rs.batch(j)
+        if j + 1 < nb:
+            rs.batch(j + 1)
+        v = r[3][0].sorted_views(r[3][1])
+        if j in first_sorted:
+            assert v is not None and v[2] == j % CH, (j, v)
+        else:
+            assert v is None
+        eng.sort_chunks = not (off_at <= j < off_at + 1)
+        rs.ensure(j + rs.CH + 2)
+        check_new_sorts(j)
+        if eng.sort_chunks and j + 2 < nb and not (off_at - 3 * sl <= j <= off_at + 3 * sl):
+            assert j + 2 in first_sorted, "the batch after next has its lists before the step that issues its take"
+    assert len(first_sorted) >= nb - 2 * sl - 2
+    assert rs.sorted_views(nb) is None
+
+
 def test_window_resolver_hands_due_chunks_to_the_next_step(monkeypatch):
     """Long batches: a chunk that falls due is handed to the engine (`_pending_resolve` + `mark_next`) and issued by the NEXT
     step behind its interaction forward, one chunk per step; the first chunks of a window and a chunk whose batches are
