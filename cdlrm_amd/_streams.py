@@ -61,19 +61,27 @@ def background_stream(device):
     return st
 
 
+_LOW = {}               # device index -> the process's second least-urgent stream (created once, never destroyed)
+
+
 def low_priority_stream(device):
     """Another stream of the least urgent priority, distinct from background_stream's (the engine's chunk sort: work whose
-    result is needed many steps later must not queue behind a plan's DMA copies, nor in front of anything a step waits for)."""
+    result is needed many steps later must not queue behind a plan's DMA copies, nor in front of anything a step waits for).
+    One per device and process, like background_stream's."""
     if not is_hip(device):
         return _NullStream()
     from . import _lib
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    with torch.cuda.device(idx):
-        h = _lib.raw().cdlrm_stream_create(1 << 20)
-    if not h:
-        raise _lib.CdlrmError(-22, _lib.raw().cdlrm_last_error().decode("utf-8", "replace"))
-    return torch.cuda.ExternalStream(int(h), device=torch.device("cuda", idx))
+    st = _LOW.get(idx)
+    if st is None:
+        with torch.cuda.device(idx):
+            h = _lib.raw().cdlrm_stream_create(1 << 20)
+        if not h:
+            raise _lib.CdlrmError(-22, _lib.raw().cdlrm_last_error().decode("utf-8", "replace"))
+        st = torch.cuda.ExternalStream(int(h), device=torch.device("cuda", idx))
+        _LOW[idx] = st
+    return st
 
 
 def current_stream(device):
