@@ -522,7 +522,7 @@ class WindowResolver:
         self.SL = max(1, min(max(sl, (sl * 8192) // max(self.width, 1)), self.CH))
         self.sorted_upto = 0        # batches [0, sorted_upto) of the window have had their slice's turn
         self._sorted_at = {}        # first batch of a slice whose sort was issued -> batches in it (engine.sort_chunks at that time)
-        engine._sev_waited = None   # (the slice events are shared by every resolver of the engine)
+        engine._sev_waited = engine._sev_waited_cur = None   # (the slice events are shared by every resolver of the engine)
         if self.sort_chunks:
             skey = ("wsorted", self.CH, self.width)
             if skey not in engine._bufs:
@@ -553,6 +553,12 @@ class WindowResolver:
     def _prepare(self, c: int):
         ctx = self.ctx
         self.chunks.pop(c - self.RING, None)
+        last = getattr(self.eng, "_last_sort_ev", None)
+        if last is not None:
+            # the slice sorts read the ring slots' slot ids on a least-priority stream of their own: a sort whose batches were never
+            # trained (a window left early) has no take behind it -- the resolve that recycles a slot (prefetch stream, issued
+            # after this call) is ordered behind every sort issued so far
+            self.eng.pref.wait_event(last)
         b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
         cols = self.idx[:, b0 * self.B:b1 * self.B]
         w = int(cols.shape[1])
@@ -626,9 +632,13 @@ class WindowResolver:
                     st.wait_event(eng._events["interacted"])
                 elif eng._emb_done is not None:
                     st.wait_event(eng._emb_done)
+                if getattr(eng, "sort_delay", 0):       # (tools/race_check.py: a late sort shows a consumer that is not ordered behind it)
+                    with torch.cuda.stream(st):
+                        torch.cuda._sleep(int(eng.sort_delay))
                 ops.embbag_bwd_prepare_window(self.ctx, ws[:, self.col0:], self.B, nbc, self.width,
                                               self._sorted_ring[c % self.RING], stream=st, j0=j0, count=cnt)
                 self._sorted_ev[c % self.RING][j0 // self.SL].record(st)
+                eng._last_sort_ev = self._sorted_ev[c % self.RING][j0 // self.SL]
                 self._sorted_at[b0] = cnt
             self.sorted_upto = b0 + cnt
             self._sorted_at.pop(b0 - 3 * self.CH, None)
@@ -795,7 +805,9 @@ class TrainEngine:
         self.sort_slice = 2
         self.sort_after = "emb_done"
         self._cur_sorted = self._next_sorted = None
-        self._sev_waited = None
+        self._sev_waited = self._sev_waited_cur = None
+        self.slice_wait = True      # (False: tools/race_check.py --negative -- nobody waits for the slices: the check must notice)
+        self._last_sort_ev = None
         # --evict-victim-cache (main_no_ddp.py:96, parsed and unused by the reference): behind every step's embedding update
         # the trained aux rows of the batch's misses go back to their host rows and to their copies among the window's victim
         # rows (ops.victim_writeback).  One rank only; the step then runs un-pipelined (no take of the next batch ahead of
@@ -1142,12 +1154,23 @@ class TrainEngine:
                 self._cur_sorted = res[3][0].sorted_views(res[3][1])
             if self._next_res is not None and len(next_res) > 3:
                 self._next_sorted = next_res[3][0].sorted_views(next_res[3][1])
-                if self._next_sorted is not None and self._next_sorted[4] is not self._sev_waited:
-                    # the next batch's take (two aux regions: prefetch stream; else the side stream, where the sort ran) waits
-                    # for its slice's sort: this step's successor -- gather, interaction backward (the once-only flags),
-                    # embedding update -- is ordered behind that take
+                if self._next_sorted is not None and self._next_sorted[4] is not self._sev_waited and self.slice_wait:
+                    # the next batch's take (two aux regions: prefetch stream; chained / single region: side stream) waits for
+                    # its slice's sort: this step's successor -- gather, interaction backward (the once-only flags), embedding
+                    # update -- is ordered behind that take
                     self.pref.wait_event(self._next_sorted[4])
+                    self.side.wait_event(self._next_sorted[4])
                     self._sev_waited = self._next_sorted[4]
+            pf = self._pref
+            if (self._cur_sorted is not None and pf is not None and pf["ptr"] == lS_i.data_ptr()
+                    and pf["shape"] == tuple(lS_i.shape) and not pf.get("sorted_ok")):
+                # this batch's take was issued by the previous step, BEFORE its slice's sort (a chunk resolved late: short chunks):
+                # nothing orders this step behind that sort -- it sorts its own slots
+                self._cur_sorted = None
+            if self._cur_sorted is not None and self._cur_sorted[4] is not self._sev_waited_cur and self.slice_wait:
+                # this batch's take, if no earlier step issued it, runs in line on the side stream; its gather follows that stream
+                self.side.wait_event(self._cur_sorted[4])
+                self._sev_waited_cur = self._cur_sorted[4]
         if res is not None:
             # an in-line take (no prefetched result for this batch) runs on the side stream: behind the chunk's resolve
             self.side.wait_event(res[2])
@@ -1327,7 +1350,7 @@ class TrainEngine:
             evp = ev["probed"][ph]
             rec(evp.record, pst)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=ph,
-                              res=(res[0], res[1], res[2], evp))
+                              res=(res[0], res[1], res[2], evp), sorted_ok=self._next_sorted is not None)
         # the backward's sort of the slot ids needs nothing but the probe result: run it on the side, under the MLPs
         emb_work = self._emb_work(n)
         if not side_gather:
@@ -1504,7 +1527,8 @@ class TrainEngine:
             evp = ev["probed"][which]
             rec(evp.record, side)
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=0,
-                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain_sort)
+                              res=(res[0], res[1], res[2], evp), chained_top=chained_top, prepared=chain_sort,
+                              sorted_ok=self._next_sorted is not None)
         dY = dfeat[:, 0, :]
         for i in reversed(range(1, len(self.bot))):         # layer 0 has no input gradient
             l, act = self.bot[i]
@@ -1734,7 +1758,7 @@ class TrainEngine:
         self._pref = None
         if tape["pref"] is not None:
             self._pref = dict(ptr=next_idx.data_ptr(), shape=tuple(next_idx.shape), phase=tape["pref"][0], res=tape["pref"][1],
-                              chained_top=tape["pref"][2], prepared=tape["pref"][3])
+                              chained_top=tape["pref"][2], prepared=tape["pref"][3], sorted_ok=self._next_sorted is not None)
         return not self.multi
 
     # ---- the touched-row merge in deadline order ----------------------------------------------------------------------

@@ -262,7 +262,10 @@ def embbag_bwd_once_flags(ctx: CacheCtx, work: torch.Tensor, n: int) -> int:
 def embbag_bwd_sorted(ctx: CacheCtx, nb: int, n: int, device) -> torch.Tensor:
     """Caller-owned buffer for the sorted slot lists of a look-ahead chunk of nb batches of n lookups per table."""
     nbytes = int(_lib.lib().cdlrm_embbag_bwd_sorted_bytes(ctx.T, nb, n))
-    return torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+    # zero-filled: lists nobody has sorted yet are still lists of valid (slot 0, position 0) keys
+    buf = torch.zeros((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+    torch.cuda.current_stream(device).synchronize()
+    return buf
 
 
 def embbag_bwd_prepare_window(ctx: CacheCtx, wslots: torch.Tensor, batch_len: int, nb: int, n: int, sorted_buf: torch.Tensor,

@@ -25,3 +25,12 @@ def test_every_schedule_ends_on_the_same_bits(batch, steps):
     import race_check
     n = len(race_check.VARIANTS) - 1           # every variant but the first (the reference for the others)
     assert n >= 7 and r.stdout.count("bit-identical") == n and "DIFFERS" not in r.stdout, r.stdout
+
+
+def test_the_check_notices_a_step_that_does_not_wait_for_its_slice_sort():
+    """Negative control of the variants with late slice sorts: when nothing waits for a look-ahead slice's sort (the takes'
+    streams skip the slice event) and the sort arrives late, steps read unsorted lists and stale once-only flags -- the run must
+    leave the reference's bits, i.e. the check above is not blind to this dependency."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "race_check.py"), "--batch", "8192", "--steps", "60", "--negative"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIFFERS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

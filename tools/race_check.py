@@ -38,6 +38,9 @@ VARIANTS = {
     "slices of five batches, sorted on the side stream": {"sort_slice": 5, "sort_on": "side"},
     "slices sorted on the prefetch stream, chained take": {"sort_on": "pref", "gather_alone_min": 1},
     "slices behind the interaction backward": {"sort_after": "interacted"},
+    "slice sorts 0.2 ms late (two aux regions)": {"sort_delay": 400000, "gather_alone_min": 1 << 30},
+    "slice sorts 0.2 ms late (chained take)": {"sort_delay": 400000, "gather_alone_min": 1},
+    "slice sorts 0.2 ms late, slices of one batch, no tape": {"sort_delay": 400000, "sort_slice": 1, "use_tape": False},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
 }
@@ -83,6 +86,7 @@ def run(a, knobs, host):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--negative", action="store_true", help="negative control of the slice-sort ordering (exit 0 = noticed)")
     ap.add_argument("--config", default="c3")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=1500)
@@ -91,6 +95,13 @@ def main():
     torch.cuda.set_device(0)
     host = bench.build_host_tables(a.config, seed=123, dev=torch.device("cuda", 0), max_ind_range=a.max_ind_range)
     ref, bad = None, 0
+    if a.negative:
+        # negative control: slice sorts arrive late and NOTHING waits for them -- the run must leave the reference's bits
+        ref = run(a, {}, host)
+        r = run(a, {"sort_delay": 2000000, "slice_wait": False, "gather_alone_min": 1}, host)
+        same = (r[0] == ref[0] and torch.equal(r[1], ref[1]) and r[2] == ref[2] and torch.equal(r[3], ref[3]))
+        print("late slices, nobody waits:", "bit-identical (the check is blind)" if same else "DIFFERS (as it must)")
+        sys.exit(1 if same else 0)
     for name, knobs in VARIANTS.items():
         r = run(a, knobs, host)
         if ref is None:
