@@ -554,10 +554,12 @@ class WindowResolver:
         ctx = self.ctx
         self.chunks.pop(c - self.RING, None)
         last = getattr(self.eng, "_last_sort_ev", None)
-        if last is not None:
-            # the slice sorts read the ring slots' slot ids on a least-priority stream of their own: a sort whose batches were never
-            # trained (a window left early) has no take behind it -- the resolve that recycles a slot (prefetch stream, issued
-            # after this call) is ordered behind every sort issued so far
+        if last is not None and c < self.RING:
+            # The slice sorts read the ring slots' slot ids on a least-priority stream of their own.  Inside a window the slot's
+            # previous holder is chunk c - 3, whose slices were all waited for by the takes of its batches, long ago; the first
+            # chunks of a window recycle slots of the PREVIOUS window, which may have been left early -- a sort whose batches
+            # were never trained has no take behind it: this resolve (prefetch stream, issued after this call) is ordered behind
+            # every sort issued so far
             self.eng.pref.wait_event(last)
         b0, b1 = c * self.CH, min(self.nb, (c + 1) * self.CH)
         cols = self.idx[:, b0 * self.B:b1 * self.B]
