@@ -1160,8 +1160,13 @@ class TrainEngine:
                     # the next batch's take (two aux regions: prefetch stream; chained / single region: side stream) waits for
                     # its slice's sort: this step's successor -- gather, interaction backward (the once-only flags), embedding
                     # update -- is ordered behind that take
-                    self.pref.wait_event(self._next_sorted[4])
-                    self.side.wait_event(self._next_sorted[4])
+                    if self.ctx.aux_phases >= 2 and not self._chain(B, next_idx, lS_o):
+                        self.pref.wait_event(self._next_sorted[4])
+                    else:
+                        # (not on both: with two aux regions the `gathered` record THIS step's fused forward waits for sits on the
+                        #  side stream -- a wait for a sort that is still running would hold the training queue, as in round 6's
+                        #  first placement of the sort)
+                        self.side.wait_event(self._next_sorted[4])
                     self._sev_waited = self._next_sorted[4]
             pf = self._pref
             if (self._cur_sorted is not None and pf is not None and pf["ptr"] == lS_i.data_ptr()
