@@ -7,9 +7,12 @@ libcdlrm_hip.so launches on preallocated buffers -- no autograd graph, no per-ta
           -> interaction bwd -> fused embedding bwd + sparse SGD || bottom dgrad chain || weight gradients
           -> grad all-reduce (RCCL) -> dense SGD -> every table_agg_freq steps: touched-row merge across ranks
 
-Four HIP streams: main (the chain above), side (slot sort, embedding backward), pref (the NEXT batch's tag probe and
-aux-row fill into the other aux region; at long batches also the top MLP's weight gradients), and the window
-plan's.  The launch sequence of a step is recorded once per control path and replayed (`_step_taped`).
+Five HIP streams: main (the chain above), side (embedding backward; the slot sort of batches without a look-ahead
+window), pref (the NEXT batch's take / tag probe and aux-row fill into the other aux region; at long batches also the top
+MLP's weight gradients), the window plan's, and a least-priority one on which `WindowResolver` sorts the slot ids of a
+look-ahead chunk slice by slice, batches ahead of their steps (the embedding backward's sort, off every queue a step waits
+for; its once-only flags let the interaction backward update the slots a batch reads once).  The launch sequence of a step is
+recorded once per control path and replayed (`_step_taped`).
 
 `WindowPipeline` is the look-ahead side: it plans window w+1 (unique scan, tag probe, way choice, winners-
 only pinned-host -> HBM row fetch) on a side HIP stream while window w trains, and commits it at the
