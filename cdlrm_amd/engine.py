@@ -809,6 +809,15 @@ class TrainEngine:
         # and the folded once-only update it allows, not the batching -- a long slice is a long visitor in one step's tail
         self.sort_slice = 2
         self.sort_after = "emb_done"
+        # The stream of the slice sorts: "pref" -- issued behind a step, they follow that step's top-MLP weight gradients (and its
+        # `top_updated` record) on the prefetch stream and run in the step's tail; the next take on that stream is behind them in
+        # order, the one after needs them.  "side": behind the embedding update; "own": a least-priority stream of their own.
+        # tools/ab_step.py, one box: c3 0.5364 / 0.5397 / 0.5380 ms, per-rank 1024 0.1804 / 0.1815 / 0.1835, c5 3.651 / 3.615 /
+        # 3.575.  "own" wins at c5 but is fragile: in the CLI's process (tools/run_cli_c3.sh, same kernels, same schedule) the
+        # step took 1.15 ms instead of 0.54 with it -- whatever hardware queue the runtime gives a SIXTH stream there, the
+        # training queue's kernels ended up behind the sort's waits -- and 0.61 again under rocprofv3; no extra stream, no such
+        # dependence on the runtime's queue mapping.  (The slice lengths above were measured with "own".)
+        self.sort_on = "pref"
         self._cur_sorted = self._next_sorted = None
         self._sev_waited = self._sev_waited_cur = None
         self.slice_wait = True      # (False: tools/race_check.py --negative -- nobody waits for the slices: the check must notice)
@@ -947,13 +956,12 @@ class TrainEngine:
             self._issue_resolve(pr, lambda fn, *a: fn(*a), S.current_stream(self.dev), placed=False)
 
     def sort_stream(self):
-        """Where a look-ahead chunk's slot lists are sorted (WindowResolver.ensure_sorted): a stream of its own, least urgent --
-        on the side stream the sort sat in front of the `gathered` record the next step's interaction forward waits for (a 36 us
-        bubble on the training queue in every step that followed a slice), on the prefetch stream in front of the next take."""
-        if getattr(self, "_sort_stream", None) is None:
-            which = getattr(self, "sort_on", "own")
-            self._sort_stream = {"side": self.side, "pref": self.pref}.get(which) or S.low_priority_stream(self.dev)
-        return self._sort_stream
+        """Where a look-ahead chunk's slot lists are sorted (WindowResolver.ensure_sorted): `sort_on`."""
+        if self.sort_on == "side":
+            return self.side
+        if self.sort_on == "pref":
+            return self.pref
+        return S.low_priority_stream(self.dev)
 
     def _fused_gather(self, lS_o) -> bool:
         """This step's gather rides in the interaction kernels (fuse_gather)."""

@@ -393,6 +393,11 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
     eng = TrainEngine(cache_group, dlrm, emb_tables, lr=args.learning_rate, lr_embeds=args.lr_embeds, world_size=world,
                       rank=rank, table_agg_freq=args.table_agg_freq, table_agg_op=args.table_agg_op,
                       loss=args.loss_function, loss_weights=loss_ws, defer_top_update=True)
+    for kv in filter(None, os.environ.get("CDLRM_ENGINE_ATTR", "").split(",")):
+        # development (as bench.py --engine-attr): TrainEngine schedule knobs for same-box A/B runs of the CLI, 'name=value,...'
+        k_, v_ = kv.split("=")
+        assert hasattr(eng, k_), k_
+        setattr(eng, k_, eval(v_))
     L = args.lookahead
     # --device-rng (performance mode): the plan of window w+1 is made while window w trains -- what the reference's
     # Prefetcher process is for (cache_manager.py:66-115) -- with its rows gathered by CPU threads in the background.  The

@@ -36,11 +36,13 @@ VARIANTS = {
     "chunk slices, once-only slots in the sorted path": {"fuse_once": False},
     "slices of one batch": {"sort_slice": 1},
     "slices of five batches, sorted on the side stream": {"sort_slice": 5, "sort_on": "side"},
-    "slices sorted on the prefetch stream, chained take": {"sort_on": "pref", "gather_alone_min": 1},
+    "slices sorted on the side stream, chained take": {"sort_on": "side", "gather_alone_min": 1},
     "slices behind the interaction backward": {"sort_after": "interacted"},
-    "slice sorts 0.2 ms late (two aux regions)": {"sort_delay": 400000, "gather_alone_min": 1 << 30},
-    "slice sorts 0.2 ms late (chained take)": {"sort_delay": 400000, "gather_alone_min": 1},
-    "slice sorts 0.2 ms late, slices of one batch, no tape": {"sort_delay": 400000, "sort_slice": 1, "use_tape": False},
+    "slices on a least-priority stream of their own": {"sort_on": "own"},
+    "slice sorts 0.2 ms late on their own stream (two aux regions)": {"sort_on": "own", "sort_delay": 400000, "gather_alone_min": 1 << 30},
+    "slice sorts 0.2 ms late on their own stream (chained take)": {"sort_on": "own", "sort_delay": 400000, "gather_alone_min": 1},
+    "slice sorts 0.2 ms late, slices of one batch, no tape": {"sort_on": "own", "sort_delay": 400000, "sort_slice": 1, "use_tape": False},
+    "slice sorts 0.2 ms late on the prefetch stream": {"sort_delay": 400000},
     "python tape": {"native_tape": False},
     "no tape": {"use_tape": False},
 }
@@ -98,7 +100,7 @@ def main():
     if a.negative:
         # negative control: slice sorts arrive late and NOTHING waits for them -- the run must leave the reference's bits
         ref = run(a, {}, host)
-        r = run(a, {"sort_delay": 2000000, "slice_wait": False, "gather_alone_min": 1}, host)
+        r = run(a, {"sort_on": "own", "sort_delay": 2000000, "slice_wait": False, "gather_alone_min": 1}, host)
         same = (r[0] == ref[0] and torch.equal(r[1], ref[1]) and r[2] == ref[2] and torch.equal(r[3], ref[3]))
         print("late slices, nobody waits:", "bit-identical (the check is blind)" if same else "DIFFERS (as it must)")
         sys.exit(1 if same else 0)
