@@ -310,7 +310,7 @@ def test_window_resolver_sorts_slices_ahead_of_their_steps(monkeypatch, CH, SL, 
         def __init__(self):
             self._bufs, self._pending_resolve, self.mark_next = {}, None, False
 
-        def sort_stream(self):
+        def sort_stream(self, local_batch=0):
             return S._NullStream()
 
     monkeypatch.setattr(engine.ops, "window_resolve",
