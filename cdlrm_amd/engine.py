@@ -807,6 +807,8 @@ class TrainEngine:
         # batches per slice.  tools/ab_step.py, one box, four rounds each, c3, against the per-step sort (0.547-0.552 ms): slices of
         # 1 / 2 / 4 / 8 / 16 batches -1.1 / -1.5 .. -2.2 / -1.1 / -0.8 / +0.4 %: what pays is the sort OFF the queues a step waits for
         # and the folded once-only update it allows, not the batching -- a long slice is a long visitor in one step's tail
+        # (on the prefetch stream, see sort_on: 1 / 2 / 4 batches -2.7 / -3.3 / -2.7 %, 2 batches behind the interaction backward
+        #  instead of the embedding update -3.1 %)
         self.sort_slice = 2
         self.sort_after = "emb_done"
         # The stream of the slice sorts: "pref" -- issued behind a step, they follow that step's top-MLP weight gradients (and its
