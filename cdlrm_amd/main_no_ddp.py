@@ -499,7 +499,12 @@ def Run(rank, m_spa, ln_emb, ln_bot, ln_top, train_ld, test_ld, batch_fifo, evic
             def rank_indices(li):       # this rank's slice of a batch's indices, on the device
                 li = torch.as_tensor(li) if not isinstance(li, (list, tuple)) else torch.stack(
                     [torch.as_tensor(s).reshape(-1) for s in li])
-                return li[:, sl].contiguous().to(dev)      # the day-file loader hands out X_cat^T (a strided view)
+                v = li[:, sl]
+                if v.device.type != "cuda" or v.stride(1) != 1:     # (the day-file loader hands out X_cat^T, a strided view)
+                    v = v.contiguous()
+                # a batch that already lies on the device as columns of its window (the synthetic front end) is used in place:
+                # the take and the probe read rows at a pitch -- packing it cost a 1.7 MB copy kernel on the training queue per step
+                return v.to(dev)
 
             if multi_hot:
                 Or, Ir = square_bags([lS_o[k] for k in range(len(ln_emb))], lS_i, dev)
