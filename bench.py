@@ -247,7 +247,8 @@ def rank_resources(config, world, *, lookahead=-1, batch=-1, max_ind_range=-1, s
     host_tables = int(sum(ln_emb)) * D * 4
     # pinned staging of the plan's row lists (winners + window victims), this rank's 1/world slice (sharded fetch)
     staging = int(1.25 * (cap_win + victims0) * (4 * D + 8) / world)
-    streams = ["train (priority -1)", "side (embedding backward, take, sort)", "pref / weight gradients",
+    streams = ["train (priority -1)", "side (embedding backward, chained take)",
+               "pref / weight gradients / slot sort of the look-ahead slices",
                "window plan (least priority)"] + (["exchange (row merge)", "ProcessGroupNCCL's own stream"] if world > 1 else [])
     out = {
         "config": config, "world": world, "global_batch": B, "local_batch": lbs, "lookahead": L,
@@ -866,8 +867,9 @@ def main():
                        # which take schedule the local batch gets (TrainEngine.gather_alone_min, decided by samples/s)
                        "schedule": ("two aux regions: next batch's take at the head of the step, beside the bottom MLP and the "
                                     "interaction forward" if eng._side_gather(lbs) else
-                                    "chained take: one aux region, take + slot sort behind the embedding update; the interaction "
-                                    "forward runs alone"),
+                                    "chained take: one aux region, take behind the embedding update; the interaction "
+                                    "forward runs alone") + ("; slot sort per look-ahead slice on the prefetch stream, once-only "
+                                                             "slots updated by the interaction backward" if eng.sort_chunks else ""),
                        # GPU kept busy (scratch GEMMs, no training state) between the W warm-up steps and the timed region
                        "gpu_prewarm_ms": a.prewarm_ms,
                        # the same step right after the warm-up, BEFORE the pre-warm (rank 0's clock over a bounded pass of
