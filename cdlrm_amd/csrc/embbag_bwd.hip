@@ -200,18 +200,44 @@ __global__ void __launch_bounds__(256) k_merge_pass(const uint64_t* __restrict__
 // meta for tables sorted in several chunks: distance to the run start by binary search
 __global__ void __launch_bounds__(256) k_seg_meta(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ meta,
                                                   uint8_t* __restrict__ once, int nb, int nbt, int j0) {
+    // A tile of 256 consecutive sorted positions per pass: the run start of a position is the LAST run start at or in front of
+    // it -- an inclusive max-scan inside the tile (wave shuffles + one LDS hop) -- and only the run that reaches into the tile
+    // from the left needs a search over the keys, ONE per tile instead of one per position (round 6: a tiny table's run is
+    // thousands of positions, each of which walked 13 dependent loads; 12-31 us beside the step for 2 x 26 lists).
+    __shared__ int wlast[4];
+    __shared__ int64_t left_start;
     const int t = blockIdx.y;
     const int ol = (t / nb) * nbt + j0 + t % nb;
     const uint64_t* kt = keys + (int64_t)ol * n;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = kt[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t p0 = (int64_t)blockIdx.x * 256; p0 < n; p0 += (int64_t)gridDim.x * 256) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool in = p < n;
+        const uint64_t key = in ? kt[p] : 0ull;
         const uint64_t s = key >> 32;
-        int32_t r = 0;
-        if (p > 0 && (kt[p - 1] >> 32) == s) r = (int32_t)(p - lower_bound_u64(kt, 0, p, s << 32));
-        meta[(int64_t)ol * n + p] = r;
-        // a slot this batch reads ONCE, flagged at the lookup's position in the batch (see k_sort_chunks)
-        const bool last = p + 1 >= n || (kt[p + 1] >> 32) != s;
-        once[(int64_t)ol * n + (uint32_t)key] = (r == 0 && last) ? 1 : 0;
+        const bool start = in && (p == 0 || (kt[p - 1] >> 32) != s);
+        if (threadIdx.x == 0) left_start = -1;
+        // last run start at or in front of this thread, inside the tile (-1: none)
+        int v = start ? (int)threadIdx.x : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d, 64);
+            if (lane >= d) v = max(v, o);
+        }
+        if (lane == 63) wlast[wave] = v;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) v = max(v, wlast[w]);
+        if (in && v < 0 && threadIdx.x == 0) left_start = lower_bound_u64(kt, 0, p0, s << 32);      // the run of the tile's first key
+        __syncthreads();
+        if (in) {
+            const int64_t st = v >= 0 ? p0 + v : left_start;
+            const int32_t r = (int32_t)(p - st);
+            meta[(int64_t)ol * n + p] = r;
+            // a slot this batch reads ONCE, flagged at the lookup's position in the batch (see k_sort_chunks)
+            const bool last = p + 1 >= n || (kt[p + 1] >> 32) != s;
+            once[(int64_t)ol * n + (uint32_t)key] = (r == 0 && last) ? 1 : 0;
+        }
+        __syncthreads();
     }
 }
 
