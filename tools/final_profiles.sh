@@ -26,6 +26,8 @@ run c3_a0_whole_window_n1 --alpha 0 --steps 3000 --no-cpu-baseline
 run c3_batch4096_n1 --batch 4096 --steps 1000 --warmup 100 --no-cpu-baseline
 run c3_batch2048_n1 --batch 2048 --steps 1000 --warmup 100 --no-cpu-baseline
 if [ -n "$C5" ]; then run c5_whole_window_n1 --config c5 --steps 8000 --no-cpu-baseline; fi
+# the drop-in CLI at the README configuration (its own progress lines: ms per iteration without the caching overhead)
+echo "== cli_c3_n1: tools/run_cli_c3.sh 4000"; bash tools/run_cli_c3.sh 4000 > $OUT/${TAG}_cli_c3_n1.log 2>&1; grep Finished $OUT/${TAG}_cli_c3_n1.log | tail -2 | cut -c1-70
 fi
 if [ "${PART:-all}" = lines ]; then ls -la $OUT; exit 0; fi
 echo "== rocprofv3 passes (c3)"
